@@ -1,0 +1,422 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the REAL reference.
+
+Runs ONLY in the build container (needs /root/reference, Cython, gcc).  The
+reference never travels: it is compiled into a scratch directory outside the
+repository (default /tmp/apmf_ref_build, deleted afterwards unless --keep) and
+only *data* - seeded inputs and the outputs the reference computed for them -
+is written under tests/golden/.  No reference source, bytecode or .so is copied
+into /root/repo.
+
+Scratch-copy edits (ordinary NumPy-2 / SciPy era breakage):
+  * numpy.float/int/complex aliases are restored before import;
+  * normal_exps_cy.pyx: np.int_t -> np.intp_t (type no longer in the NumPy-2 pxd);
+  * pmf_cy.pyx add_ratings: drop copy=False (NumPy-2 semantics);
+  * active_pmf.py kl_divergence: int() cast of the float-valued (i, j) of a rating row;
+  * bayes_pmf.py sample_wishart: integer `size`;
+  * get_key_evals: index with a tuple, not a list, of index sequences (NumPy >= 1.23).
+The arithmetic of every function on the hot path is untouched.
+
+Usage:  python tests/golden/make_golden.py [--keep] [--scratch DIR]
+"""
+import argparse
+import os
+import random
+import shutil
+import subprocess
+import sys
+import time
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build_reference(scratch):
+    src = os.path.join(REF, 'python-pmf')
+    if os.path.exists(scratch):
+        shutil.rmtree(scratch)
+    os.makedirs(scratch)
+    for fn in os.listdir(src):
+        if fn.endswith(('.py', '.pyx', '.pxd')):
+            shutil.copy(os.path.join(src, fn), scratch)
+    shutil.copy(os.path.join(REF, 'generate.py'), scratch)
+
+    def edit(fn, old, new, count=None):
+        p = os.path.join(scratch, fn)
+        s = open(p).read()
+        assert old in s, (fn, old)
+        s = s.replace(old, new) if count is None else s.replace(old, new, count)
+        open(p, 'w').write(s)
+
+    edit('normal_exps_cy.pyx', 'np.int_t', 'np.intp_t')
+    edit('pmf_cy.pyx', 'extra = np.array(extra, copy=False, ndmin=2)',
+         'extra = np.array(extra, ndmin=2)')
+    edit('active_pmf.py', 'for i, j, rating in self.ratings)',
+         'for i, j, rating in ((int(a), int(b), c) for a, b, c in self.ratings))')
+    edit('bayes_pmf.py', 'size=(n*(n-1)/2.)', 'size=(n*(n-1)//2)')
+    for fn in ('mn_active_pmf.py', 'active_pmf.py'):
+        edit(fn, 'evals[list(zip(*pool))]', 'evals[tuple(zip(*pool))]')
+    edit('generate.py', 'otypes=[np.float]', 'otypes=[float]')
+    edit('generate.py', 'np.array(min_fracs, copy=False)', 'np.asarray(min_fracs)')
+    edit('generate.py', 'np.array(max_fracs, copy=False)', 'np.asarray(max_fracs)')
+
+    open(os.path.join(scratch, 'setup_scratch.py'), 'w').write(
+        "from setuptools import setup, Extension\n"
+        "import numpy as np\n"
+        "setup(ext_modules=[Extension(n, [n + '.c'], include_dirs=[np.get_include()],\n"
+        "      extra_compile_args=['-O2', '-w'])\n"
+        "      for n in ('pmf_cy', 'normal_exps_cy', 'matrix_normal_exps_cy')])\n")
+    subprocess.check_call(['cython', '-3', 'pmf_cy.pyx', 'normal_exps_cy.pyx',
+                           'matrix_normal_exps_cy.pyx'], cwd=scratch)
+    subprocess.check_call([sys.executable, 'setup_scratch.py', '-q', 'build_ext',
+                           '--inplace'], cwd=scratch,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
+    ap.add_argument('--keep', action='store_true')
+    args = ap.parse_args()
+
+    build_reference(args.scratch)
+    sys.path.insert(0, args.scratch)
+
+    import warnings
+    warnings.simplefilter('ignore')
+    import numpy as np
+    np.float = float
+    np.int = int
+    np.complex = complex
+
+    import pmf_cy
+    import matrix_normal_exps_cy as mnx
+    import normal_exps_cy as nx
+    import mn_active_pmf
+    import active_pmf
+    import bayes_pmf
+    import generate
+
+    # keep the reference quiet
+    import builtins
+    _print = builtins.print
+    for mod in (mn_active_pmf, active_pmf, bayes_pmf):
+        mod.print = lambda *a, **k: None
+
+    def save(name, **arrs):
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **arrs)
+        _print('wrote %-28s %7.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
+
+    def seed(s):
+        np.random.seed(s)
+        random.seed(s)
+
+    def fake(n, m, d, per_user, noise=.25):
+        # same recipe as pmf_cy.fake_ratings (pmf_cy.pyx:461-474)
+        return pmf_cy.fake_ratings(noise=noise, num_users=n, num_items=m,
+                                   num_ratings=per_user, latent_dimension=d)
+
+    timings = {}
+
+    # ------------------------------------------------------------------ A. PMF
+    def pmf_case(name, ratings, d, subtract_mean, fit=True, sig=None):
+        p = pmf_cy.ProbabilisticMatrixFactorization(
+            ratings.copy(), latent_d=d, subtract_mean=subtract_mean)
+        if sig is not None:
+            p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq = sig
+        U0, V0 = p.users.copy(), p.items.copy()
+        gU, gV = p.gradient()
+        ll = p.log_likelihood()
+        half = ratings.shape[0] // 3 + 1
+        gUb, gVb = p.gradient(p.ratings[2:2 + half])
+        out = dict(ratings=ratings, d=d, subtract_mean=int(subtract_mean),
+                   sigma=np.array([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq]),
+                   mean_rating=p.mean_rating,
+                   U0=U0, V0=V0, gU=gU, gV=gV, ll=ll, full_ll=p.full_ll(),
+                   batch_lo=2, batch_hi=2 + half, gU_batch=gUb, gV_batch=gVb,
+                   pred0=p.predicted_matrix())
+        if fit:
+            trace = np.array(list(p.fit_lls()))
+            out.update(ll_trace=trace, U_fit=p.users.copy(), V_fit=p.items.copy())
+            real = np.dot(U0, V0.T)  # any dense target will do for rmse()
+            out.update(rmse_target=real, rmse=np.float64(p.rmse(real)))
+            on = np.zeros(real.shape, bool)
+            on[::2, 1::3] = True
+            out.update(rmse_on_mask=on, rmse_on=np.float64(p.rmse(real, on)))
+            # closed-form variance updates (pmf_cy.pyx:225-255)
+            p.update_sigma()
+            p.update_sigma_uv()
+            out.update(sigma_after=np.array([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq]))
+        save(name, **out)
+
+    # config 1: generate.py 10x10 rank-2 discrete, known diagonal
+    seed(1)
+    real_c1 = generate.gen_known_diag_counts(m=10, n=10, rank=2, known_pos=10,
+                                             unknown_pos=90, cutoff=0)
+    known = generate.known_diag(10, 10)
+    ratings_c1 = np.zeros((known.sum(), 3))
+    for idx, (i, j) in enumerate(np.transpose(known.nonzero())):
+        ratings_c1[idx] = [i, j, real_c1[i, j]]
+    seed(2)
+    pmf_case('pmf_c1_10x10_d2', ratings_c1, 2, False)
+
+    seed(3)
+    r, _, _ = fake(50, 40, 3, 8)
+    seed(4)
+    pmf_case('pmf_50x40_d3', r, 3, False)
+    seed(5)
+    pmf_case('pmf_50x40_d3_submean', r, 3, True, sig=(0.7, 4.0, 6.0))
+
+    seed(6)
+    r, _, _ = fake(30, 70, 16, 12)
+    seed(7)
+    pmf_case('pmf_30x70_d16', r, 16, False)
+
+    # headline shape, synthetic (inputs regenerated from the seed by the test:
+    # only the outputs are stored).  943 x 1682, d = 10, N = 100 000.
+    def c2_inputs():
+        seed(0)
+        n, m, d, N = 943, 1682, 10, 100000
+        Ut = np.random.normal(0, 2, (n, d))
+        Vt = np.random.normal(0, 2, (m, d))
+        mask = np.zeros((n, m), bool)
+        mask[np.arange(n), np.random.randint(0, m, n)] = True
+        mask[np.random.randint(0, n, m), np.arange(m)] = True
+        free = np.flatnonzero(~mask.ravel())
+        extra = np.random.choice(free, N - int(mask.sum()), replace=False)
+        mask.ravel()[extra] = True
+        ii, jj = mask.nonzero()
+        perm = np.random.permutation(ii.size)
+        ii, jj = ii[perm], jj[perm]
+        vals = (Ut[ii] * Vt[jj]).sum(1) + np.random.normal(0, .25, ii.size)
+        ratings = np.column_stack([ii, jj, vals]).astype(float)
+        U0 = np.random.random((n, d))
+        V0 = np.random.random((m, d))
+        return ratings, U0, V0
+    ratings, U0, V0 = c2_inputs()
+    p = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    p.users, p.items = U0.copy(), V0.copy()
+    t0 = time.perf_counter(); gU, gV = p.gradient(); t1 = time.perf_counter()
+    ll = p.log_likelihood(); t2 = time.perf_counter()
+    timings['c2_gradient_s'] = t1 - t0
+    timings['c2_loglik_s'] = t2 - t1
+    save('pmf_c2_943x1682_d10', ratings_head=ratings[:64], N=ratings.shape[0],
+         ratings_sum=ratings.sum(0), U0_sum=U0.sum(), V0_sum=V0.sum(),
+         gU=gU, gV=gV, ll=ll)
+
+    # --------------------------------------------------- B. matrix-normal ActivePMF
+    def mn_case(name, ratings, d, random_cov, rating_values=None, grad=True):
+        a = mn_active_pmf.MNActivePMF(ratings.copy(), latent_d=d,
+                                      rating_values=rating_values)
+        a.do_fit()
+        a.initialize_approx(random_cov=random_cov)
+        if random_cov:
+            # keep the random covariances well conditioned but non-trivial
+            a.cov_useritems /= a.cov_useritems.shape[0]
+            a.cov_latents /= d
+        n, m = a.num_users, a.num_items
+        p_mean, p_var = a.approx_pred_means_vars()
+        e2 = np.array([[mnx.exp_dotprod_sq(n, a.mean, a.cov_useritems,
+                                           a.cov_latents, i, j)
+                        for j in range(m)] for i in range(n)])
+        pool = list(a.unrated)
+        vals = a._get_key_vals(pool, mn_active_pmf.MNActivePMF.pred_variance, 1, None)
+        pick_max = a.pick_query_point(key=mn_active_pmf.MNActivePMF.pred_variance)
+        evals = a.get_key_evals(key=mn_active_pmf.MNActivePMF.pred_variance)
+        out = dict(ratings=ratings, d=d, users=a.users, items=a.items,
+                   mean=a.mean, cov_useritems=a.cov_useritems,
+                   cov_latents=a.cov_latents, p_mean=p_mean, p_var=p_var, e2=e2,
+                   pool=np.array(pool), pool_vals=np.array(vals),
+                   pick_max=np.array(pick_max), key_evals=evals,
+                   kl=a.kl_divergence(),
+                   total_variance=a._total_variance())
+        if grad:
+            g_mean, g_cu, g_cl = mnx.matrixnormal_gradient(a)
+            out.update(g_mean=g_mean, g_cov_useritems=g_cu, g_cov_latents=g_cl,
+                       sigma=np.array([a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq]))
+            kls = []
+            for k, kl in enumerate(a.fit_normal_kls()):
+                kls.append(kl)
+                if k >= 2:
+                    break
+            out.update(kl_trace=np.array(kls), mean_fit=a.mean,
+                       cov_useritems_fit=a.cov_useritems,
+                       cov_latents_fit=a.cov_latents)
+            pm2, pv2 = a.approx_pred_means_vars()
+            out.update(p_mean_fit=pm2, p_var_fit=pv2)
+        save(name, **out)
+
+    seed(10)
+    mn_case('mn_c1_10x10_d2_eye', ratings_c1, 2, False, rating_values=(1, 2, 3, 4, 5))
+    seed(11)
+    mn_case('mn_c1_10x10_d2_rand', ratings_c1, 2, True, rating_values=(1, 2, 3, 4, 5))
+    seed(12)
+    r, _, _ = fake(24, 17, 5, 4)
+    seed(13)
+    mn_case('mn_24x17_d5_rand', r, 5, True)
+    seed(14)
+    r, _, _ = fake(12, 20, 10, 5)
+    seed(15)
+    mn_case('mn_12x20_d10_rand', r, 10, True, grad=False)
+
+    # timing of the reference scoring loop (for BASELINE.md; not a fixture)
+    seed(16)
+    r, _, _ = fake(300, 200, 10, 20)
+    a = mn_active_pmf.MNActivePMF(r, latent_d=10)
+    a.initialize_approx(random_cov=True)
+    pool = list(a.unrated)[:20000]
+    t0 = time.perf_counter()
+    a._get_key_vals(pool, mn_active_pmf.MNActivePMF.pred_variance, 1, None)
+    timings['mn_pred_variance_per_cand_s'] = (time.perf_counter() - t0) / len(pool)
+
+    # ------------------------------------------------- C. full-covariance ActivePMF
+    def full_case(name, ratings, d):
+        a = active_pmf.ActivePMF(ratings.copy(), latent_d=d)
+        a.do_fit()
+        a.initialize_approx()
+        a.cov /= 8.0
+        p_mean, p_var = a.approx_pred_means_vars()
+        pool = list(a.unrated)
+        vals = a._get_key_vals(pool, active_pmf.ActivePMF.pred_variance, 1, None)
+        pick = a.pick_query_point(key=active_pmf.ActivePMF.pred_variance)
+        save(name, ratings=ratings, d=d, users=a.users, items=a.items,
+             mean=a.mean, cov=a.cov, p_mean=p_mean, p_var=p_var,
+             pool=np.array(pool), pool_vals=np.array(vals), pick_max=np.array(pick),
+             kl=a.kl_divergence(), u_idx=a.u, v_idx=a.v)
+
+    seed(20)
+    r, _, _ = fake(6, 5, 3, 2)
+    seed(21)
+    full_case('full_6x5_d3', r, 3)
+    seed(22)
+    r, _, _ = fake(12, 9, 5, 3)
+    seed(23)
+    full_case('full_12x9_d5', r, 5)
+
+    # ------------------------------------------------------------- D. BayesianPMF
+    def bayes_case(name, ratings, d, subtract_mean, S, rating_values=None):
+        b = bayes_pmf.BayesianPMF(ratings.copy(), latent_d=d,
+                                  subtract_mean=subtract_mean,
+                                  rating_values=rating_values)
+        b.fit()
+        users, items = b.users.copy(), b.items.copy()
+        out = dict(ratings=ratings, d=d, subtract_mean=int(subtract_mean),
+                   users=users, items=items, mean_rating=b.mean_rating)
+
+        # one sample_feature call with every operand recorded
+        seed(100)
+        mu = np.random.normal(size=d)
+        A = np.random.normal(size=(d, d))
+        alpha = A.dot(A.T) + d * np.eye(d)
+        idx = np.flatnonzero(ratings[:, 0] == 0)
+        rated = ratings[idx, 1].astype(int)
+        rvals = ratings[idx, 2]
+        seed(101)
+        z = np.random.normal(0, 1, d)
+        seed(101)
+        feat = b.sample_feature(0, True, mu, alpha, items, rated, rvals)
+        out.update(sf_mu=mu, sf_alpha=alpha, sf_rated=rated, sf_ratings=rvals,
+                   sf_z=z, sf_out=feat)
+
+        # hyper-parameter draw
+        seed(102)
+        hmu, halpha = b.sample_hyperparam(users, True)
+        out.update(hp_seed=102, hp_mu=hmu, hp_alpha=halpha)
+
+        # chain prefix: S yields from seed 103
+        seed(103)
+        from itertools import islice
+        samps = list(islice(b.samples(), S))
+        out.update(chain_seed=103,
+                   chain_U=np.array([u for u, v in samps]),
+                   chain_V=np.array([v for u, v in samps]))
+        unr = np.array(list(b.unrated)).T
+        which = tuple(unr)
+        out.update(which=unr,
+                   pred_variance=b.pred_variance(samps, which=which),
+                   pred_variance_full=b.pred_variance(samps),
+                   predict_full=b.predict(samps),
+                   prob_ge=b.prob_ge_cutoff(samps, 3.5, which=which),
+                   prob_ge_full=b.prob_ge_cutoff(samps, 0.5),
+                   total_variance=b.total_variance(samps, which=which),
+                   pick_argmax=unr[:, np.argmax(b.pred_variance(samps, which=which))])
+        save(name, **out)
+
+    seed(30)
+    r, _, _ = fake(20, 15, 4, 5)
+    seed(31)
+    bayes_case('bayes_20x15_d4', r, 4, True, 8)
+    seed(32)
+    bayes_case('bayes_c1_10x10_d2', ratings_c1, 2, False, 6,
+               rating_values=(1, 2, 3, 4, 5))
+    # dof = d + N_rows > 81 + d  -> the chi-square/Bartlett branch of sample_wishart
+    seed(33)
+    r, _, _ = fake(100, 90, 15, 20)
+    seed(34)
+    bayes_case('bayes_100x90_d15', r, 15, True, 3)
+
+    # timing: one samples() yield at the headline Gibbs shape (d = 15)
+    ratings, _, _ = c2_inputs()
+    b = bayes_pmf.BayesianPMF(ratings, latent_d=15)
+    it = b.samples()
+    seed(35)
+    next(it)
+    t0 = time.perf_counter(); next(it)
+    timings['gibbs_yield_943x1682_d15_s'] = time.perf_counter() - t0
+
+    # --------------------------------------- E. config-1 selection trace (plumbing)
+    seed(40)
+    res = mn_active_pmf.compare(['random', 'pred-variance'], real_c1, ratings_c1,
+                                rating_vals=(1, 2, 3, 4, 5), latent_d=2,
+                                do_threading=False, steps=5)
+    out = dict(real=real_c1, ratings=ratings_c1, seed=40)
+    for key in ('random', 'pred-variance'):
+        steps = res[key]
+        out[key + '_n_rated'] = np.array([s[0] for s in steps])
+        out[key + '_rmse'] = np.array([s[1] for s in steps], dtype=np.float64)
+        out[key + '_picks'] = np.array([s[2] for s in steps[1:]])
+        for k, s in enumerate(steps[1:]):
+            out['%s_vals_%d' % (key, k)] = np.array(s[3], dtype=np.float64)
+    init = res['_initial_apmf']
+    out.update(init_users=init.users, init_items=init.items, init_mean=init.mean,
+               init_cov_useritems=init.cov_useritems,
+               init_cov_latents=init.cov_latents)
+    save('trace_c1_mn', **out)
+
+    # ------------------------- F. moments (what test_normal_exps.py pins statistically)
+    seed(50)
+    dim = 6
+    mn_ = np.random.normal(0, 3, dim)
+    cov_ = active_pmf.project_psd(np.random.normal(0, 2, (dim, dim)), 1e-5)
+    save('moments_full',
+         mean=mn_, cov=cov_,
+         tripexpect=nx.tripexpect(mn_, cov_, 0, 1, 2),
+         quadexpect=nx.quadexpect(mn_, cov_, 0, 1, 2, 3),
+         exp_squared=nx.exp_squared(mn_, cov_, 1, 4),
+         exp_a2bc=nx.exp_a2bc(mn_, cov_, 2, 3, 5),
+         exp_dotprod_sq=nx.exp_dotprod_sq(
+             np.arange(3).reshape(1, 3).T, np.arange(3, 6).reshape(1, 3).T,
+             mn_, cov_, 0, 0))
+    M_ = np.random.normal(0, 2, (5, 3))
+    R_ = active_pmf.project_psd(np.random.normal(0, 1, (5, 5)), 1e-5)
+    C_ = active_pmf.project_psd(np.random.normal(0, 1, (3, 3)), 1e-5)
+    save('moments_mn', mean=M_, cov_rows=R_, cov_cols=C_,
+         tripexpect=mnx.tripexpect(M_, R_, C_, 0, 0, 1, 1, 2, 2),
+         quadexpect=mnx.quadexpect(M_, R_, C_, 0, 0, 1, 1, 2, 2, 3, 0),
+         exp_squared=mnx.exp_squared(M_, R_, C_, 0, 1, 4, 2),
+         exp_a2bc=mnx.exp_a2bc(M_, R_, C_, 1, 1, 2, 0, 4, 2),
+         exp_dotprod_sq=mnx.exp_dotprod_sq(2, M_, R_, C_, 1, 2))
+
+    with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
+        import json
+        json.dump(dict(timings, host='build container, 1 thread',
+                       note='reference Cython timed by make_golden.py'), f, indent=1)
+    _print(timings)
+
+    if not args.keep:
+        shutil.rmtree(args.scratch)
+
+
+if __name__ == '__main__':
+    main()
