@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    """Golden vectors written by tests/golden/make_golden.py from the real reference."""
+    with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+def c2_inputs():
+    """The headline 943 x 1682, d = 10, N = 100 000 synthetic PMF inputs, regenerated from
+    seed 0 exactly as make_golden.py builds them (only outputs are stored as fixtures)."""
+    import random
+    np.random.seed(0)
+    random.seed(0)
+    n, m, d, N = 943, 1682, 10, 100000
+    Ut = np.random.normal(0, 2, (n, d))
+    Vt = np.random.normal(0, 2, (m, d))
+    mask = np.zeros((n, m), bool)
+    mask[np.arange(n), np.random.randint(0, m, n)] = True
+    mask[np.random.randint(0, n, m), np.arange(m)] = True
+    free = np.flatnonzero(~mask.ravel())
+    extra = np.random.choice(free, N - int(mask.sum()), replace=False)
+    mask.ravel()[extra] = True
+    ii, jj = mask.nonzero()
+    perm = np.random.permutation(ii.size)
+    ii, jj = ii[perm], jj[perm]
+    vals = (Ut[ii] * Vt[jj]).sum(1) + np.random.normal(0, .25, ii.size)
+    ratings = np.column_stack([ii, jj, vals]).astype(float)
+    U0 = np.random.random((n, d))
+    V0 = np.random.random((m, d))
+    return ratings, U0, V0

@@ -1,0 +1,174 @@
+"""The CPU oracle (oracle/apmf_oracle.c) pinned against golden vectors produced by the
+REAL reference (tests/golden/make_golden.py).  CPU-only; this is what makes the oracle
+trustworthy as the checker of the HIP path."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, c2_inputs
+from oracle import oracle as orc
+
+EPS = np.finfo(np.float64).eps
+
+PMF_CASES = ['pmf_c1_10x10_d2', 'pmf_50x40_d3', 'pmf_50x40_d3_submean', 'pmf_30x70_d16']
+
+
+def _pmf_args(g):
+    sig, sig_u, sig_v = g['sigma']
+    return dict(sig=sig, sig_u=sig_u, sig_v=sig_v, subtract_mean=bool(g['subtract_mean']),
+                mean_rating=float(g['mean_rating']))
+
+
+@pytest.mark.parametrize('name', PMF_CASES)
+def test_pmf_gradient_and_ll(name):
+    g = load_golden(name)
+    kw = _pmf_args(g)
+    gU, gV = orc.pmf_gradient(g['ratings'], g['U0'], g['V0'], **kw)
+    # reference: pmf_cy.pyx:204-223.  Only np.dot's internal summation order differs.
+    np.testing.assert_allclose(gU, g['gU'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(gV, g['gV'], rtol=1e-12, atol=1e-12)
+    ll = orc.pmf_log_likelihood(g['ratings'], g['U0'], g['V0'], **kw)
+    assert abs(ll - g['ll']) <= 1e-13 * abs(g['ll'])
+    lo, hi = int(g['batch_lo']), int(g['batch_hi'])
+    gUb, gVb = orc.pmf_gradient(g['ratings'][lo:hi], g['U0'], g['V0'], **kw)
+    np.testing.assert_allclose(gUb, g['gU_batch'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(gVb, g['gV_batch'], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', PMF_CASES)
+def test_pmf_fit_lls_trace(name):
+    g = load_golden(name)
+    U, V, trace = orc.pmf_fit_lls(g['ratings'], g['U0'], g['V0'], **_pmf_args(g))
+    # same number of accepted steps = same accept/reject control flow (pmf_cy.pyx:265-291)
+    assert trace.size == g['ll_trace'].size
+    np.testing.assert_allclose(trace, g['ll_trace'], rtol=1e-10)
+    np.testing.assert_allclose(U, g['U_fit'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(V, g['V_fit'], rtol=1e-8, atol=1e-10)
+
+
+def test_pmf_headline_shape():
+    g = load_golden('pmf_c2_943x1682_d10')
+    ratings, U0, V0 = c2_inputs()
+    assert ratings.shape[0] == int(g['N'])
+    np.testing.assert_array_equal(ratings[:64], g['ratings_head'])
+    np.testing.assert_allclose(ratings.sum(0), g['ratings_sum'], rtol=1e-13)
+    gU, gV = orc.pmf_gradient(ratings, U0, V0)
+    np.testing.assert_allclose(gU, g['gU'], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(gV, g['gV'], rtol=1e-11, atol=1e-11)
+    ll = orc.pmf_log_likelihood(ratings, U0, V0)
+    assert abs(ll - g['ll']) <= 1e-13 * abs(g['ll'])
+
+
+MN_CASES = ['mn_c1_10x10_d2_eye', 'mn_c1_10x10_d2_rand', 'mn_24x17_d5_rand', 'mn_12x20_d10_rand']
+
+
+@pytest.mark.parametrize('name', MN_CASES)
+def test_mn_grids(name):
+    g = load_golden(name)
+    n, m = g['p_mean'].shape
+    pm, pv, e2 = orc.mn_pred_means_vars(n, m, g['mean'], g['cov_useritems'], g['cov_latents'],
+                                        want_e2=True)
+    # exp_dotprod_sq is pure C arithmetic in the reference (matrix_normal_exps_cy.pyx:126-154):
+    # the restatement reproduces it bit for bit.
+    np.testing.assert_array_equal(e2, g['e2'])
+    # mean/var go through numpy scalar ops (pow, sum) in mn_active_pmf.py:311-315
+    assert np.max(np.abs(pm - g['p_mean'])) <= 4 * EPS * np.max(np.abs(g['p_mean']))
+    assert np.all(np.abs(pv - g['p_var']) <= 8 * EPS * np.abs(g['e2']))
+    # compact state (cross block + diagonal) gives the same numbers
+    R = g['cov_useritems']
+    pm2, pv2 = orc.mn_pred_means_vars_compact(n, m, g['mean'], R[:n, n:], np.diag(R).copy(),
+                                              g['cov_latents'])
+    np.testing.assert_array_equal(pm2, pm)
+    np.testing.assert_array_equal(pv2, pv)
+    # the selection the reference made (first max in pool order, mn_active_pmf.py:728-729)
+    pool = [tuple(x) for x in g['pool']]
+    vals = [pv[i, j] for i, j in pool]
+    np.testing.assert_allclose(vals, g['pool_vals'], rtol=0, atol=8 * EPS * np.abs(g['e2']).max())
+    pick = max(zip(pool, vals), key=lambda t: t[1])[0]
+    assert pick == tuple(g['pick_max'])
+    assert abs(pv.sum() - g['total_variance']) <= 1e-12 * abs(g['total_variance'])
+
+
+def test_mn_moments():
+    g = load_golden('moments_mn')
+    a = (g['mean'], g['cov_rows'], g['cov_cols'])
+    assert orc.mn_moment('tripexpect', *a, 0, 0, 1, 1, 2, 2) == g['tripexpect']
+    assert orc.mn_moment('quadexpect', *a, 0, 0, 1, 1, 2, 2, 3, 0) == g['quadexpect']
+    assert orc.mn_moment('exp_squared', *a, 0, 1, 4, 2) == g['exp_squared']
+    assert orc.mn_moment('exp_a2bc', *a, 1, 1, 2, 0, 4, 2) == g['exp_a2bc']
+    assert orc.mn_exp_dotprod_sq(2, *a, 1, 2) == g['exp_dotprod_sq']
+
+
+def test_full_moments():
+    g = load_golden('moments_full')
+    a = (g['mean'], g['cov'])
+    assert orc.full_moment('tripexpect', *a, 0, 1, 2) == pytest.approx(g['tripexpect'], rel=1e-15)
+    assert orc.full_moment('quadexpect', *a, 0, 1, 2, 3) == g['quadexpect']
+    assert orc.full_moment('exp_squared', *a, 1, 4) == pytest.approx(g['exp_squared'], rel=1e-15)
+    assert orc.full_moment('exp_a2bc', *a, 2, 3, 5) == g['exp_a2bc']
+    assert orc.full_exp_dotprod_sq(1, 3, *a, 0, 0) == pytest.approx(g['exp_dotprod_sq'], rel=1e-15)
+
+
+def test_moments_monte_carlo():
+    """What the reference's own test_normal_exps.py pins: the closed forms agree with a
+    Monte-Carlo estimate to 2 % (test_normal_exps.py:22-63), here for the oracle."""
+    rs = np.random.RandomState(7)
+    for _ in range(2):
+        dim = 6
+        mn = rs.normal(0, 10, dim)
+        s = rs.normal(0, 5, (dim, dim))
+        w, v = np.linalg.eigh((s + s.T) / 2)
+        cov = (v * np.maximum(w, 1e-5)) @ v.T
+        cov = (cov + cov.T) / 2
+        x = rs.multivariate_normal(mn, cov, 400000)
+        u = x[:, :3]
+        vv = x[:, 3:]
+        monte = np.mean(np.sum(u * vv, axis=1) ** 2)
+        e = orc.full_exp_dotprod_sq(1, 3, mn, cov, 0, 0)
+        assert abs(monte - e) / e < .02
+        monte4 = np.mean(x[:, 0] * x[:, 1] * x[:, 2] * x[:, 3])
+        e4 = orc.full_moment('quadexpect', mn, cov, 0, 1, 2, 3)
+        assert abs(monte4 - e4) / abs(e4) < .05
+
+
+@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
+def test_full_grids(name):
+    g = load_golden(name)
+    n, m = g['p_mean'].shape
+    d = int(g['d'])
+    pm, pv, e2 = orc.full_pred_means_vars(n, m, d, g['mean'], g['cov'], want_e2=True)
+    scale = np.abs(e2)
+    assert np.all(np.abs(pm - g['p_mean']) <= 8 * EPS * (np.abs(g['p_mean']) + 1))
+    assert np.all(np.abs(pv - g['p_var']) <= 16 * EPS * scale)
+    pool = [tuple(x) for x in g['pool']]
+    vals = [pv[i, j] for i, j in pool]
+    pick = max(zip(pool, vals), key=lambda t: t[1])[0]
+    assert pick == tuple(g['pick_max'])
+
+
+BAYES_CASES = ['bayes_20x15_d4', 'bayes_c1_10x10_d2', 'bayes_100x90_d15']
+
+
+@pytest.mark.parametrize('name', BAYES_CASES)
+def test_sample_feature(name):
+    g = load_golden(name)
+    sub = float(g['mean_rating']) if int(g['subtract_mean']) else 0.
+    out = orc.sample_feature(g['items'], g['sf_rated'], g['sf_ratings'], g['sf_alpha'],
+                             g['sf_mu'], 2.0, sub, g['sf_z'])
+    # bayes_pmf.py:189-216 (LAPACK inv/cholesky vs plain LU/Cholesky: rounding only)
+    np.testing.assert_allclose(out, g['sf_out'], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', BAYES_CASES)
+def test_sample_stats(name):
+    g = load_golden(name)
+    add = float(g['mean_rating']) if int(g['subtract_mean']) else 0.
+    mean, var, _ = orc.sample_stats(g['chain_U'], g['chain_V'], add=add)
+    np.testing.assert_allclose(mean, g['predict_full'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(var, g['pred_variance_full'], rtol=1e-9, atol=1e-13)
+    which = tuple(g['which'])
+    np.testing.assert_allclose(var[which], g['pred_variance'], rtol=1e-9, atol=1e-13)
+    assert tuple(g['which'][:, np.argmax(var[which])]) == tuple(g['pick_argmax'])
+    _, _, p35 = orc.sample_stats(g['chain_U'], g['chain_V'], add=add, cutoff=3.5)
+    np.testing.assert_array_equal(p35[which], g['prob_ge'])
+    _, _, p05 = orc.sample_stats(g['chain_U'], g['chain_V'], add=add, cutoff=0.5)
+    np.testing.assert_array_equal(p05, g['prob_ge_full'])
