@@ -1,0 +1,380 @@
+"""ctypes binding of libapmf_hip.so (include/apmf.h) - the only way the Python classes of
+this package reach the GPU.  No PyTorch, no CPU fallback: if the shared library or a
+gfx950 device is missing, every call fails loudly with ApmfError.
+
+The binding is deliberately thin: `Context` owns one device + stream, `DeviceArray` owns one
+hipMalloc'd buffer, and each method maps 1:1 onto a C entry point.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libapmf_hip.so')
+
+GRID_ALIGN = 64
+MAX_D = 64
+
+OK, EINVAL, EHIP, ENOMEM, ENOTPD, ENODEV = 0, -1, -2, -3, -4, -5
+
+
+class ApmfError(RuntimeError):
+    """A libapmf_hip call failed (status < 0)."""
+
+    def __init__(self, status, message):
+        super().__init__('libapmf_hip status %d: %s' % (status, message))
+        self.status = status
+
+
+_vp = C.c_void_p
+_i = C.c_int
+_i64 = C.c_int64
+_dbl = C.c_double
+_sz = C.c_size_t
+
+_SIGS = {
+    'apmf_version': (_i, []),
+    'apmf_last_error': (C.c_char_p, []),
+    'apmf_device_count': (_i, [C.POINTER(_i)]),
+    'apmf_ctx_create': (_i, [_i, C.POINTER(_vp)]),
+    'apmf_ctx_destroy': (_i, [_vp]),
+    'apmf_ctx_set_stream': (_i, [_vp, _vp]),
+    'apmf_ctx_sync': (_i, [_vp]),
+    'apmf_grid_ld': (_i, [_i]),
+    'apmf_malloc': (_i, [_vp, _sz, C.POINTER(_vp)]),
+    'apmf_free': (_i, [_vp, _vp]),
+    'apmf_memset': (_i, [_vp, _vp, _i, _sz]),
+    'apmf_h2d': (_i, [_vp, _vp, _vp, _sz]),
+    'apmf_d2h': (_i, [_vp, _vp, _vp, _sz]),
+    'apmf_d2d': (_i, [_vp, _vp, _vp, _sz]),
+    'apmf_h2d_2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    'apmf_d2h_2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    'apmf_cast_f64_f32': (_i, [_vp, _vp, _vp, _sz]),
+    'apmf_cast_f32_f64': (_i, [_vp, _vp, _vp, _sz]),
+    'apmf_ratings_create': (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp)]),
+    'apmf_ratings_destroy': (_i, [_vp, _vp]),
+    'apmf_ratings_count': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
+    'apmf_pmf_gradient': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, _vp, _vp]),
+    'apmf_pmf_log_likelihood': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl,
+                                     C.POINTER(_dbl), C.POINTER(_dbl)]),
+    'apmf_pmf_fit_lls': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, C.POINTER(_dbl),
+                              _dbl, _dbl, _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
+    'apmf_pmf_minibatch_epoch': (_i, [_vp, _vp, _i64, _i, _i, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
+                                      _i, _dbl, _dbl, _dbl, _i, _dbl]),
+    'apmf_pmf_predicted_matrix': (_i, [_vp, _vp, _vp, _i, _i, _i, _dbl, _vp, _i]),
+    'apmf_mn_score_grid_f32': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _i, _vp, _vp]),
+    'apmf_mn_score_grid_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _i, _vp, _vp]),
+    'apmf_mn_score_pool_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    'apmf_grid_collect_near_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp,
+                                        _i, C.POINTER(_i)]),
+    'apmf_full_score_grid_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    'apmf_gibbs_half_sweep': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
+    'apmf_sample_stats_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
+    'apmf_grid_gather_f64': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _vp]),
+    'apmf_pool_argext_f64': (_i, [_vp, _vp, _i64, _i, C.POINTER(_i64), C.POINTER(_dbl)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def exported_symbols():
+    """Names include/apmf.h declares (used by the CPU-side ABI test)."""
+    return sorted(_SIGS)
+
+
+def load():
+    """dlopen libapmf_hip.so once.  Loading needs no GPU; creating a Context does."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ApmfError(ENODEV, 'HIP extension %s is not built (run `python -c "import '
+                                '__graft_entry__ as g; g.build()"` or `make -C %s/csrc`); there '
+                                'is no CPU fallback' % (LIB_PATH, _HERE))
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def _check(status):
+    if status != OK:
+        msg = load().apmf_last_error().decode('utf-8', 'replace')
+        if status == EINVAL:
+            raise ValueError(msg)
+        if status == ENOMEM:
+            raise MemoryError(msg)
+        if status == ENOTPD:
+            raise np.linalg.LinAlgError(msg)
+        raise ApmfError(status, msg)
+
+
+def device_count():
+    n = _i(0)
+    _check(load().apmf_device_count(C.byref(n)))
+    return n.value
+
+
+def grid_ld(m):
+    return (int(m) + GRID_ALIGN - 1) // GRID_ALIGN * GRID_ALIGN
+
+
+def _ptr(x):
+    """device pointer of a DeviceArray / int / None"""
+    if x is None:
+        return None
+    if isinstance(x, DeviceArray):
+        return x.ptr
+    return int(x)
+
+
+class DeviceArray(object):
+    """One device allocation with a NumPy-like shape/dtype tag."""
+
+    def __init__(self, ctx, shape, dtype, zero=False):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = _vp()
+        _check(ctx._lib.apmf_malloc(ctx._h, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value
+        if zero:
+            self.zero()
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def zero(self):
+        _check(self.ctx._lib.apmf_memset(self.ctx._h, self.ptr, 0, self.nbytes))
+        return self
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError('upload size mismatch: %r vs %r' % (host.shape, self.shape))
+        _check(self.ctx._lib.apmf_h2d(self.ctx._h, self.ptr, host.ctypes.data, self.nbytes))
+        return self
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        _check(self.ctx._lib.apmf_d2h(self.ctx._h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib, h = self.ctx._lib, self.ctx._h
+            if h:
+                lib.apmf_free(h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Ratings(object):
+    """Device-resident CSR-by-user + CSR-by-item of an (N, 3) ratings array (apmf_ratings)."""
+
+    def __init__(self, ctx, ratings, n, m):
+        ratings = np.ascontiguousarray(ratings, dtype=np.float64)
+        if ratings.ndim != 2 or ratings.shape[1] != 3:
+            raise TypeError('invalid rating tuple length')
+        self.ctx = ctx
+        self.N, self.n, self.m = ratings.shape[0], int(n), int(m)
+        h = _vp()
+        _check(ctx._lib.apmf_ratings_create(ctx._h, ratings.ctypes.data, self.N, self.n, self.m,
+                                            C.byref(h)))
+        self._h = h.value
+
+    def free(self):
+        if getattr(self, '_h', None):
+            if self.ctx._h:
+                self.ctx._lib.apmf_ratings_destroy(self.ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One device + one stream (apmf_ctx).  Not thread-safe; never create before fork()."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = _vp()
+        _check(self._lib.apmf_ctx_create(int(device), C.byref(h)))
+        self._h = h.value
+        self.device = int(device)
+        self._pid = os.getpid()
+
+    def close(self):
+        if self._h and os.getpid() == self._pid:
+            self._lib.apmf_ctx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ------------------------------------------------------------------
+    def sync(self):
+        _check(self._lib.apmf_ctx_sync(self._h))
+
+    def set_stream(self, hip_stream):
+        _check(self._lib.apmf_ctx_set_stream(self._h, hip_stream))
+
+    def empty(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float64):
+        return DeviceArray(self, shape, dtype, zero=True)
+
+    def array(self, host, dtype=None):
+        host = np.asarray(host)
+        dtype = host.dtype if dtype is None else np.dtype(dtype)
+        return DeviceArray(self, host.shape, dtype).upload(host)
+
+    def upload_grid(self, host_2d, dtype=np.float64, ld=None):
+        """(rows, m) host matrix (any row stride) -> zero-padded (rows, ld) device grid."""
+        host_2d = np.asarray(host_2d, dtype=dtype)
+        rows, m = host_2d.shape
+        ld = grid_ld(m) if ld is None else ld
+        g = self.zeros((rows, ld), dtype)
+        if host_2d.strides[1] != host_2d.itemsize:
+            host_2d = np.ascontiguousarray(host_2d)
+        isz = host_2d.itemsize
+        _check(self._lib.apmf_h2d_2d(self._h, g.ptr, ld * isz, host_2d.ctypes.data,
+                                     host_2d.strides[0], m * isz, rows))
+        return g
+
+    def download_grid(self, grid, m):
+        """(rows, ld) device grid -> contiguous (rows, m) host array."""
+        rows, ld = grid.shape[-2], grid.shape[-1]
+        lead = int(np.prod(grid.shape[:-2], dtype=np.int64)) if len(grid.shape) > 2 else 1
+        out = np.empty(grid.shape[:-2] + (rows, m), grid.dtype)
+        isz = grid.dtype.itemsize
+        _check(self._lib.apmf_d2h_2d(self._h, out.ctypes.data, m * isz, grid.ptr, ld * isz, m * isz,
+                                     rows * lead))
+        return out
+
+    def cast(self, src, dtype):
+        dst = DeviceArray(self, src.shape, dtype)
+        if src.dtype == np.float64 and dst.dtype == np.float32:
+            _check(self._lib.apmf_cast_f64_f32(self._h, dst.ptr, src.ptr, src.size))
+        elif src.dtype == np.float32 and dst.dtype == np.float64:
+            _check(self._lib.apmf_cast_f32_f64(self._h, dst.ptr, src.ptr, src.size))
+        else:
+            raise ValueError('unsupported cast %s -> %s' % (src.dtype, dst.dtype))
+        return dst
+
+    def ratings(self, ratings, n, m):
+        return Ratings(self, ratings, n, m)
+
+    # -- K1 ---------------------------------------------------------------------------
+    def pmf_gradient(self, rt, dU, dV, d, sig, sig_u, sig_v, subtract_mean, mean_rating, dgU, dgV):
+        _check(self._lib.apmf_pmf_gradient(self._h, rt._h, _ptr(dU), _ptr(dV), d, sig, sig_u, sig_v,
+                                           int(bool(subtract_mean)), mean_rating, _ptr(dgU), _ptr(dgV)))
+
+    def pmf_log_likelihood(self, rt, dU, dV, d, sig, sig_u, sig_v, subtract_mean, mean_rating):
+        ll, sq = _dbl(), _dbl()
+        _check(self._lib.apmf_pmf_log_likelihood(self._h, rt._h, _ptr(dU), _ptr(dV), d, sig, sig_u,
+                                                 sig_v, int(bool(subtract_mean)), mean_rating,
+                                                 C.byref(ll), C.byref(sq)))
+        return ll.value, sq.value
+
+    def pmf_fit_lls(self, rt, dU, dV, d, sig, sig_u, sig_v, subtract_mean, mean_rating, lr, min_lr,
+                    stop_thresh, max_steps=-1, max_trace=1 << 16):
+        trace = np.empty(max(max_trace, 1), np.float64)
+        lr_io, steps, conv = _dbl(lr), _i64(0), _i(0)
+        _check(self._lib.apmf_pmf_fit_lls(self._h, rt._h, _ptr(dU), _ptr(dV), d, sig, sig_u, sig_v,
+                                          int(bool(subtract_mean)), mean_rating, C.byref(lr_io),
+                                          min_lr, stop_thresh, max_steps, trace.ctypes.data, max_trace,
+                                          C.byref(steps), C.byref(conv)))
+        return trace[:min(steps.value, max_trace)].copy(), steps.value, lr_io.value, bool(conv.value)
+
+    def pmf_minibatch_epoch(self, shuffled, n, m, batch_size, lr, momentum, dU, dV, duinc, dvinc, d,
+                            sig, sig_u, sig_v, subtract_mean, mean_rating):
+        shuffled = np.ascontiguousarray(shuffled, dtype=np.float64)
+        _check(self._lib.apmf_pmf_minibatch_epoch(self._h, shuffled.ctypes.data, shuffled.shape[0], n,
+                                                  m, batch_size, lr, momentum, _ptr(dU), _ptr(dV),
+                                                  _ptr(duinc), _ptr(dvinc), d, sig, sig_u, sig_v,
+                                                  int(bool(subtract_mean)), mean_rating))
+
+    def pmf_predicted_matrix(self, dU, dV, n, m, d, add, dout, ld):
+        _check(self._lib.apmf_pmf_predicted_matrix(self._h, _ptr(dU), _ptr(dV), n, m, d, add,
+                                                   _ptr(dout), ld))
+
+    # -- K2 ---------------------------------------------------------------------------
+    def mn_score_grid(self, dtype, B, n, m, d, ld, mean, cross, diag, omega, mask=None, var=None,
+                      pmean=None, dsum=None, want=0, best_val=None, best_idx=None):
+        fn = self._lib.apmf_mn_score_grid_f32 if np.dtype(dtype) == np.float32 \
+            else self._lib.apmf_mn_score_grid_f64
+        _check(fn(self._h, B, n, m, d, ld, _ptr(mean), _ptr(cross), _ptr(diag), _ptr(omega),
+                  _ptr(mask), _ptr(var), _ptr(pmean), _ptr(dsum), want, _ptr(best_val),
+                  _ptr(best_idx)))
+
+    def mn_score_pool(self, n, m, d, ld, mean, cross, diag, omega, pi, pj, P, pmean, var):
+        _check(self._lib.apmf_mn_score_pool_f64(self._h, n, m, d, ld, _ptr(mean), _ptr(cross),
+                                                _ptr(diag), _ptr(omega), _ptr(pi), _ptr(pj), P,
+                                                _ptr(pmean), _ptr(var)))
+
+    def grid_collect_near(self, n, m, ld, var, mask, want, best, rel_tol, pi, pj, cap):
+        cnt = _i(0)
+        _check(self._lib.apmf_grid_collect_near_f32(self._h, n, m, ld, _ptr(var), _ptr(mask), want,
+                                                    best, rel_tol, _ptr(pi), _ptr(pj), cap,
+                                                    C.byref(cnt)))
+        return cnt.value
+
+    def full_score_grid(self, n, m, d, ld, mean, cov, mask=None, var=None, pmean=None, dsum=None,
+                        want=0, best_val=None, best_idx=None):
+        _check(self._lib.apmf_full_score_grid_f64(self._h, n, m, d, ld, _ptr(mean), _ptr(cov),
+                                                  _ptr(mask), _ptr(var), _ptr(pmean), _ptr(dsum), want,
+                                                  _ptr(best_val), _ptr(best_idx)))
+
+    # -- K3 / K4 -----------------------------------------------------------------------
+    def gibbs_half_sweep(self, rt, side, oth, d, alpha, mu, beta, mean_sub, z, out):
+        _check(self._lib.apmf_gibbs_half_sweep(self._h, rt._h, side, _ptr(oth), d, _ptr(alpha),
+                                               _ptr(mu), beta, mean_sub, _ptr(z), _ptr(out)))
+
+    def sample_stats(self, S, n, m, d, ld, Us, Vs, add, cutoff, mean=None, var=None, prob=None):
+        _check(self._lib.apmf_sample_stats_f64(self._h, S, n, m, d, ld, _ptr(Us), _ptr(Vs), add,
+                                               cutoff, _ptr(mean), _ptr(var), _ptr(prob)))
+
+    def grid_gather(self, grid, ld, pi, pj, P, out):
+        _check(self._lib.apmf_grid_gather_f64(self._h, _ptr(grid), ld, _ptr(pi), _ptr(pj), P, _ptr(out)))
+
+    def pool_argext(self, vals, P, want):
+        pos, val = _i64(0), _dbl(0)
+        _check(self._lib.apmf_pool_argext_f64(self._h, _ptr(vals), P, want, C.byref(pos), C.byref(val)))
+        return pos.value, val.value
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Per-process, per-device Context, created lazily (never before a fork: a HIP context
+    does not survive it)."""
+    key = (os.getpid(), int(device))
+    ctx = _default_ctx.get(key)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[key] = ctx
+    return ctx

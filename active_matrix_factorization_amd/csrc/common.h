@@ -1,0 +1,112 @@
+// common.h - context, error plumbing and small device helpers shared by the
+// libapmf_hip translation units.  gfx950 (MI355X, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/apmf.h"
+
+#define APMF_VERSION 100
+
+struct apmf_ctx {
+    int device;
+    hipStream_t own;      // created with the ctx
+    hipStream_t stream;   // the stream work is enqueued on (own or caller's)
+    // grow-only device scratch (per-launch packs and reduction partials)
+    void *ws[4];
+    size_t ws_bytes[4];
+    // pinned host scratch for small read-backs
+    void *pinned;
+    size_t pinned_bytes;
+    int num_cu;
+};
+
+// device-resident ratings: CSR by user (index 0) and by item (index 1), stable order
+struct apmf_ratings {
+    int64_t N;
+    int n, m;
+    int64_t *ptr[2];   // (rows+1)
+    int32_t *idx[2];   // (N) index on the other side
+    double *val[2];    // (N)
+    int32_t *order;    // (n+m) rows by descending nnz; entries >= n are item rows + n
+    int has_empty[2];  // some row on that side has no rating
+    void *block;       // single allocation backing everything above
+};
+
+void apmf_set_error(const char *fmt, ...);
+
+#define APMF_CHECK_HIP(expr)                                                           \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            apmf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                           __FILE__, __LINE__);                                        \
+            return _e == hipErrorOutOfMemory ? APMF_ENOMEM : APMF_EHIP;                \
+        }                                                                              \
+    } while (0)
+
+#define APMF_REQUIRE(cond, ...)                                                        \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            apmf_set_error(__VA_ARGS__);                                               \
+            return APMF_EINVAL;                                                        \
+        }                                                                              \
+    } while (0)
+
+#define APMF_TRY(expr)                                                                 \
+    do {                                                                               \
+        int _rc = (expr);                                                              \
+        if (_rc != APMF_OK) return _rc;                                                \
+    } while (0)
+
+#define APMF_CHECK_LAUNCH() APMF_CHECK_HIP(hipGetLastError())
+
+// device scratch slot `slot` of at least `bytes` (contents undefined)
+int apmf_ws(apmf_ctx *ctx, int slot, size_t bytes, void **out);
+int apmf_pinned(apmf_ctx *ctx, size_t bytes, void **out);
+
+static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
+static inline int64_t cdiv64(int64_t x, int64_t a) { return (x + a - 1) / a; }
+
+// ---- device helpers -------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int wave_id_uniform()
+{
+    // threadIdx.x >> 6 is wave-uniform; say so, so that row-indexed operands become SGPRs
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// (value, index) arg-extremum merge: sign = +1 max / -1 min; ties -> lower index;
+// idx < 0 means "empty"
+template <typename T>
+__device__ __forceinline__ void argext_merge(T &bv, long long &bi, T ov, long long oi, int sign)
+{
+    if (oi < 0) return;
+    bool take;
+    if (bi < 0) take = true;
+    else if (sign > 0) take = (ov > bv) || (ov == bv && oi < bi);
+    else take = (ov < bv) || (ov == bv && oi < bi);
+    if (take) { bv = ov; bi = oi; }
+}
+
+template <typename T>
+__device__ __forceinline__ void wave_argext(T &bv, long long &bi, int sign)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        T ov = __shfl_xor(bv, o, 64);
+        long long oi = __shfl_xor(bi, o, 64);
+        argext_merge(bv, bi, ov, oi, sign);
+    }
+}
+#endif

@@ -1,0 +1,248 @@
+// ctx.hip - context, memory and stream plumbing of the C-ABI (include/apmf.h).
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void apmf_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int apmf_version(void) { return APMF_VERSION; }
+
+const char *apmf_last_error(void) { return g_err; }
+
+int apmf_grid_ld(int m) { return m <= 0 ? 0 : round_up(m, APMF_GRID_ALIGN); }
+
+int apmf_device_count(int *count)
+{
+    APMF_REQUIRE(count, "count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *count = c;
+    return APMF_OK;
+}
+
+int apmf_ctx_create(int device, apmf_ctx **out)
+{
+    APMF_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        apmf_set_error("no HIP device available (%s): the HIP path cannot run and there is no "
+                       "CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return APMF_ENODEV;
+    }
+    APMF_REQUIRE(device >= 0 && device < count, "device %d out of range [0,%d)", device, count);
+    APMF_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    APMF_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        apmf_set_error("device %d is %s; libapmf_hip is built for gfx950 (MI355X) only", device,
+                       prop.gcnArchName);
+        return APMF_ENODEV;
+    }
+    apmf_ctx *c = new (std::nothrow) apmf_ctx();
+    if (!c) { apmf_set_error("out of host memory"); return APMF_ENOMEM; }
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    hipError_t se = hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete c;
+        apmf_set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+        return APMF_EHIP;
+    }
+    c->stream = c->own;
+    *out = c;
+    return APMF_OK;
+}
+
+int apmf_ctx_destroy(apmf_ctx *ctx)
+{
+    if (!ctx) return APMF_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 4; i++)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->own);
+    delete ctx;
+    return APMF_OK;
+}
+
+int apmf_ctx_set_stream(apmf_ctx *ctx, void *hip_stream)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own;
+    return APMF_OK;
+}
+
+int apmf_ctx_sync(apmf_ctx *ctx)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return APMF_OK;
+}
+
+int apmf_malloc(apmf_ctx *ctx, size_t bytes, void **d_out)
+{
+    APMF_REQUIRE(ctx && d_out, "ctx/d_out is NULL");
+    *d_out = nullptr;
+    if (bytes == 0) return APMF_OK;
+    APMF_CHECK_HIP(hipSetDevice(ctx->device));
+    APMF_CHECK_HIP(hipMalloc(d_out, bytes));
+    return APMF_OK;
+}
+
+int apmf_free(apmf_ctx *ctx, void *d_ptr)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (!d_ptr) return APMF_OK;
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    APMF_CHECK_HIP(hipFree(d_ptr));
+    return APMF_OK;
+}
+
+int apmf_memset(apmf_ctx *ctx, void *d_ptr, int value, size_t bytes)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (bytes == 0) return APMF_OK;
+    APMF_REQUIRE(d_ptr, "d_ptr is NULL");
+    APMF_CHECK_HIP(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return APMF_OK;
+}
+
+int apmf_h2d(apmf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (bytes == 0) return APMF_OK;
+    APMF_REQUIRE(d_dst && h_src, "NULL pointer");
+    // pageable source: the copy is staged before the call returns, the host buffer is free
+    APMF_CHECK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return APMF_OK;
+}
+
+int apmf_d2h(apmf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (bytes == 0) return APMF_OK;
+    APMF_REQUIRE(h_dst && d_src, "NULL pointer");
+    APMF_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return APMF_OK;
+}
+
+int apmf_d2d(apmf_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (bytes == 0) return APMF_OK;
+    APMF_REQUIRE(d_dst && d_src, "NULL pointer");
+    APMF_CHECK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return APMF_OK;
+}
+
+int apmf_h2d_2d(apmf_ctx *ctx, void *d_dst, size_t dpitch, const void *h_src, size_t spitch,
+                size_t width, size_t height)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (width == 0 || height == 0) return APMF_OK;
+    APMF_REQUIRE(d_dst && h_src && dpitch >= width && spitch >= width, "bad 2-D copy");
+    APMF_CHECK_HIP(hipMemcpy2DAsync(d_dst, dpitch, h_src, spitch, width, height,
+                                    hipMemcpyHostToDevice, ctx->stream));
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return APMF_OK;
+}
+
+int apmf_d2h_2d(apmf_ctx *ctx, void *h_dst, size_t dpitch, const void *d_src, size_t spitch,
+                size_t width, size_t height)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (width == 0 || height == 0) return APMF_OK;
+    APMF_REQUIRE(h_dst && d_src && dpitch >= width && spitch >= width, "bad 2-D copy");
+    APMF_CHECK_HIP(hipMemcpy2DAsync(h_dst, dpitch, d_src, spitch, width, height,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return APMF_OK;
+}
+
+} // extern "C"
+
+int apmf_ws(apmf_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    if (bytes > ctx->ws_bytes[slot]) {
+        // the old block may still be in use by enqueued work
+        APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->ws[slot]) APMF_CHECK_HIP(hipFree(ctx->ws[slot]));
+        ctx->ws[slot] = nullptr;
+        ctx->ws_bytes[slot] = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        APMF_CHECK_HIP(hipMalloc(&ctx->ws[slot], want));
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
+    return APMF_OK;
+}
+
+int apmf_pinned(apmf_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->pinned_bytes) {
+        APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->pinned) APMF_CHECK_HIP(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_bytes = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes * 2;
+        APMF_CHECK_HIP(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return APMF_OK;
+}
+
+// ---- casts -------------------------------------------------------------------------
+template <typename TO, typename FROM>
+__global__ __launch_bounds__(256) void k_cast(TO *__restrict__ dst, const FROM *__restrict__ src,
+                                              size_t count)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) dst[i] = (TO)src[i];
+}
+
+extern "C" int apmf_cast_f64_f32(apmf_ctx *ctx, float *d_dst, const double *d_src, size_t count)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (count == 0) return APMF_OK;
+    APMF_REQUIRE(d_dst && d_src, "NULL pointer");
+    int blocks = (int)(cdiv64((int64_t)count, 256) < 4096 ? cdiv64((int64_t)count, 256) : 4096);
+    hipLaunchKernelGGL((k_cast<float, double>), dim3(blocks), dim3(256), 0, ctx->stream, d_dst,
+                       d_src, count);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+extern "C" int apmf_cast_f32_f64(apmf_ctx *ctx, double *d_dst, const float *d_src, size_t count)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (count == 0) return APMF_OK;
+    APMF_REQUIRE(d_dst && d_src, "NULL pointer");
+    int blocks = (int)(cdiv64((int64_t)count, 256) < 4096 ? cdiv64((int64_t)count, 256) : 4096);
+    hipLaunchKernelGGL((k_cast<double, float>), dim3(blocks), dim3(256), 0, ctx->stream, d_dst,
+                       d_src, count);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}

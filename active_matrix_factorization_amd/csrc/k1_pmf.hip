@@ -1,0 +1,659 @@
+// k1_pmf.hip - PMF MAP model over the observed ratings: gradient, log-likelihood and the
+// fit_lls learning-rate search (pmf_cy.pyx:158-291), float64 like the reference.
+//
+// The reference walks the (N,3) ratings array once per call, one np.dot per rating, and
+// scatters into grad_u[i] / grad_v[j] sequentially.  Here the ratings live on the device
+// as CSR-by-user and CSR-by-item (stable: per-row order = storage order), so each output
+// row is owned by exactly one wave - a gather, no atomics, a fixed summation tree, hence
+// bit-reproducible run to run (the accept/reject control flow of fit_lls depends on it).
+//
+// Wave layout: the 64 lanes are split into G = 64/DP groups of DP lanes (DP = latent_d
+// rounded up to a power of two).  Lane k of a group holds component k.  A group handles
+// one rating at a time: it gathers the other side's row (8*d contiguous bytes), forms the
+// prediction with a DP-lane butterfly reduce, and accumulates err * row into its
+// per-lane accumulator; UN ratings per group are kept in flight.  Groups are combined by
+// a final cross-group butterfly.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+
+namespace {
+
+constexpr int UN = 4;
+
+template <int DP>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int o = DP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int DP>
+__device__ __forceinline__ double cross_group_sum(double v)
+{
+#pragma unroll
+    for (int o = DP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct PmfParams {
+    int n, m, d;
+    double sig;          // sigma_sq (divided by, like the reference: pmf_cy.pyx:220-221)
+    double sig_u, sig_v; // prior variances
+    double mean_add;     // mean_rating if subtract_mean else 0
+};
+
+// gradient(): one wave per output row (users and items in one launch)
+template <int DP>
+__global__ __launch_bounds__(256) void k_pmf_grad(const PmfParams p, const int32_t *__restrict__ order,
+                                                  const int64_t *__restrict__ ptr_u,
+                                                  const int32_t *__restrict__ idx_u,
+                                                  const double *__restrict__ val_u,
+                                                  const int64_t *__restrict__ ptr_v,
+                                                  const int32_t *__restrict__ idx_v,
+                                                  const double *__restrict__ val_v,
+                                                  const double *__restrict__ U,
+                                                  const double *__restrict__ V,
+                                                  double *__restrict__ gU, double *__restrict__ gV)
+{
+    constexpr int G = 64 / DP;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + wave_id_uniform();
+    if (slot >= p.n + p.m) return;
+    const int row_all = order[slot];  // wave-uniform
+    const bool is_user = row_all < p.n;
+    const int row = is_user ? row_all : row_all - p.n;
+    const int64_t *ptr = is_user ? ptr_u : ptr_v;
+    const int32_t *idx = is_user ? idx_u : idx_v;
+    const double *val = is_user ? val_u : val_v;
+    const double *X = is_user ? U : V, *Y = is_user ? V : U;
+    double *gout = is_user ? gU : gV;
+    const int d = p.d;
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    const double xk = kok ? X[(size_t)row * d + k] : 0.;
+    const int64_t beg = ptr[row], end = ptr[row + 1];
+    double acc = 0.;
+    for (int64_t t0 = beg + g; t0 < end; t0 += (int64_t)G * UN) {
+        int32_t c[UN];
+        double r[UN], y[UN];
+        bool ok[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int64_t t = t0 + (int64_t)u * G;
+            ok[u] = t < end;
+            c[u] = ok[u] ? idx[t] : 0;
+            r[u] = ok[u] ? val[t] : 0.;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) y[u] = (ok[u] && kok) ? Y[(size_t)c[u] * d + k] : 0.;
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const double pred = group_sum<DP>(xk * y[u]) + p.mean_add;
+            const double w = ok[u] ? (r[u] - pred) / p.sig : 0.;
+            acc += y[u] * w;
+        }
+    }
+    acc = cross_group_sum<DP>(acc);
+    if (g == 0 && kok) gout[(size_t)row * d + k] = -xk / (is_user ? p.sig_u : p.sig_v) + acc;
+}
+
+// sum of squared errors over the user-CSR (each rating once) + ||X||^2 of the rows this
+// wave owns; per-wave partials, combined later in a fixed order
+template <int DP>
+__global__ __launch_bounds__(256) void k_pmf_sqerr(const PmfParams p, const int64_t *__restrict__ ptr_u,
+                                                   const int32_t *__restrict__ idx_u,
+                                                   const double *__restrict__ val_u,
+                                                   const double *__restrict__ U,
+                                                   const double *__restrict__ V,
+                                                   double *__restrict__ part /* (nslots, 3) */)
+{
+    constexpr int G = 64 / DP;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + wave_id_uniform();
+    const int nrows = max(p.n, p.m);
+    if (slot >= nrows) return;
+    const int d = p.d;
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    double sq = 0., un = 0., vn = 0.;
+    if (slot < p.n) {
+        const double xk = kok ? U[(size_t)slot * d + k] : 0.;
+        if (g == 0) un = xk * xk;
+        const int64_t beg = ptr_u[slot], end = ptr_u[slot + 1];
+        for (int64_t t0 = beg + g; t0 < end; t0 += (int64_t)G * UN) {
+            int32_t c[UN];
+            double r[UN], y[UN];
+            bool ok[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const int64_t t = t0 + (int64_t)u * G;
+                ok[u] = t < end;
+                c[u] = ok[u] ? idx_u[t] : 0;
+                r[u] = ok[u] ? val_u[t] : 0.;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; u++) y[u] = (ok[u] && kok) ? V[(size_t)c[u] * d + k] : 0.;
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const double pred = group_sum<DP>(xk * y[u]) + p.mean_add;
+                const double e = ok[u] ? (r[u] - pred) : 0.;
+                if (k == 0) sq += e * e;
+            }
+        }
+    }
+    if (slot < p.m && g == 0 && kok) {
+        const double vk = V[(size_t)slot * d + k];
+        vn = vk * vk;
+    }
+    sq = wave_sum(sq);
+    un = wave_sum(un);
+    vn = wave_sum(vn);
+    if (lane == 0) {
+        part[(size_t)slot * 3 + 0] = sq;
+        part[(size_t)slot * 3 + 1] = un;
+        part[(size_t)slot * 3 + 2] = vn;
+    }
+}
+
+// fixed-order combine of the per-row partials -> out[0] = LL, out[1] = sq_error
+__global__ __launch_bounds__(256) void k_pmf_ll_finish(int nslots, const double *__restrict__ part,
+                                                       double sig, double sig_u, double sig_v,
+                                                       double *__restrict__ out)
+{
+    __shared__ double sh[3][256];
+    double a = 0, b = 0, c = 0;
+    for (int t = threadIdx.x; t < nslots; t += 256) {
+        a += part[(size_t)t * 3];
+        b += part[(size_t)t * 3 + 1];
+        c += part[(size_t)t * 3 + 2];
+    }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int q = 0; q < 3; q++) sh[q][threadIdx.x] += sh[q][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = -sh[0][0] / (2. * sig) - sh[1][0] / (2. * sig_u) - sh[2][0] / (2. * sig_v);
+        out[1] = sh[0][0];
+    }
+}
+
+// trial point of the learning-rate search: new = old + lr * grad (two roundings, like
+// numpy's `users + lr * grad_u`, pmf_cy.pyx:271-272)
+__global__ __launch_bounds__(256) void k_axpy2(size_t nu, size_t nv, double lr,
+                                               const double *__restrict__ U, const double *__restrict__ gU,
+                                               double *__restrict__ nU, const double *__restrict__ V,
+                                               const double *__restrict__ gV, double *__restrict__ nV)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; t < nu + nv; t += stride) {
+        if (t < nu) nU[t] = __dadd_rn(U[t], __dmul_rn(lr, gU[t]));
+        else nV[t - nu] = __dadd_rn(V[t - nu], __dmul_rn(lr, gV[t - nu]));
+    }
+}
+
+// minibatch momentum update, pmf_cy.pyx:338-344:
+//   inc = momentum*inc + (prior + data)*(lr/n);  param += inc
+__global__ __launch_bounds__(256) void k_momentum(size_t nu, size_t nv, double momentum, double scale,
+                                                  double sig_u, double sig_v, double *__restrict__ U,
+                                                  double *__restrict__ V, double *__restrict__ uinc,
+                                                  double *__restrict__ vinc, double *__restrict__ gaccU,
+                                                  double *__restrict__ gaccV)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; t < nu + nv; t += stride) {
+        const bool isu = t < nu;
+        const size_t e = isu ? t : t - nu;
+        double *X = isu ? U : V, *inc = isu ? uinc : vinc, *ga = isu ? gaccU : gaccV;
+        const double grad = -X[e] / (isu ? sig_u : sig_v) + ga[e];
+        const double ni = __dadd_rn(__dmul_rn(inc[e], momentum), __dmul_rn(grad, scale));
+        inc[e] = ni;
+        X[e] = __dadd_rn(X[e], ni);
+        ga[e] = 0.;
+    }
+}
+
+// data term of the gradient for the rows present in one minibatch (CSR over the batch)
+template <int DP>
+__global__ __launch_bounds__(256) void k_pmf_grad_rows(const PmfParams p, int nrows_present,
+                                                       const int32_t *__restrict__ rows /* >= n: item */,
+                                                       const int64_t *__restrict__ ptr,
+                                                       const int32_t *__restrict__ idx,
+                                                       const double *__restrict__ val,
+                                                       const double *__restrict__ U,
+                                                       const double *__restrict__ V,
+                                                       double *__restrict__ gaccU,
+                                                       double *__restrict__ gaccV)
+{
+    constexpr int G = 64 / DP;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + wave_id_uniform();
+    if (slot >= nrows_present) return;
+    const int row_all = rows[slot];
+    const bool is_user = row_all < p.n;
+    const int row = is_user ? row_all : row_all - p.n;
+    const double *X = is_user ? U : V, *Y = is_user ? V : U;
+    double *gout = is_user ? gaccU : gaccV;
+    const int d = p.d;
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    const double xk = kok ? X[(size_t)row * d + k] : 0.;
+    const int64_t beg = ptr[slot], end = ptr[slot + 1];
+    double acc = 0.;
+    for (int64_t t0 = beg + g; t0 < end; t0 += (int64_t)G * UN) {
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int64_t t = t0 + (int64_t)u * G;
+            const bool ok = t < end;
+            const int32_t c = ok ? idx[t] : 0;
+            const double r = ok ? val[t] : 0.;
+            const double y = (ok && kok) ? Y[(size_t)c * d + k] : 0.;
+            const double pred = group_sum<DP>(xk * y) + p.mean_add;
+            const double w = ok ? (r - pred) / p.sig : 0.;
+            acc += y * w;
+        }
+    }
+    acc = cross_group_sum<DP>(acc);
+    if (g == 0 && kok) gout[(size_t)row * d + k] = acc;
+}
+
+// predicted_matrix(): out[i, j] = U_i . V_j + add
+__global__ __launch_bounds__(256) void k_predict(int n, int m, int d, int ld, double add,
+                                                 const double *__restrict__ U, const double *__restrict__ V,
+                                                 double *__restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * 16;
+    if (j >= ld) return;
+    for (int i = i0; i < min(i0 + 16, n); i++) {
+        double s = 0.;
+        if (j < m)
+            for (int k = 0; k < d; k++) s += U[(size_t)i * d + k] * V[(size_t)j * d + k];
+        out[(size_t)i * ld + j] = j < m ? s + add : 0.;
+    }
+}
+
+int dp_for(int d)
+{
+    int dp = 4;
+    while (dp < d) dp <<= 1;
+    return dp;
+}
+
+#define DISPATCH_DP(dp, CALL)                 \
+    switch (dp) {                             \
+    case 4: { constexpr int DP = 4; CALL; } break;   \
+    case 8: { constexpr int DP = 8; CALL; } break;   \
+    case 16: { constexpr int DP = 16; CALL; } break; \
+    case 32: { constexpr int DP = 32; CALL; } break; \
+    case 64: { constexpr int DP = 64; CALL; } break; \
+    default: apmf_set_error("latent_d too large"); return APMF_EINVAL; \
+    }
+
+PmfParams make_params(const apmf_ratings *r, int d, double sigma_sq, double sigma_u_sq,
+                      double sigma_v_sq, int subtract_mean, double mean_rating)
+{
+    PmfParams p;
+    p.n = r->n; p.m = r->m; p.d = d;
+    p.sig = sigma_sq;
+    p.sig_u = sigma_u_sq; p.sig_v = sigma_v_sq;
+    p.mean_add = subtract_mean ? mean_rating : 0.;
+    return p;
+}
+
+int check_common(apmf_ctx *ctx, const apmf_ratings *r, int d, double sigma_sq, double sigma_u_sq,
+                 double sigma_v_sq)
+{
+    APMF_REQUIRE(ctx && r, "ctx/ratings is NULL");
+    APMF_REQUIRE(d >= 1 && d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
+    APMF_REQUIRE(sigma_sq != 0. && sigma_u_sq != 0. && sigma_v_sq != 0., "zero variance");
+    return APMF_OK;
+}
+
+int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const double *U,
+                const double *V, double *gU, double *gV)
+{
+    const int rows = r->n + r->m;
+    const int blocks = (rows + 3) / 4;
+    DISPATCH_DP(dp_for(p.d),
+                hipLaunchKernelGGL((k_pmf_grad<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p, r->order,
+                                   r->ptr[0], r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1],
+                                   U, V, gU, gV));
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+// LL of (U, V) -> d_out2[0] = ll, d_out2[1] = sq_error (device), no sync
+int launch_ll(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, double sigma_sq,
+              const double *U, const double *V, double *d_part, double *d_out2)
+{
+    const int nslots = std::max(r->n, r->m);
+    const int blocks = (nslots + 3) / 4;
+    DISPATCH_DP(dp_for(p.d),
+                hipLaunchKernelGGL((k_pmf_sqerr<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p,
+                                   r->ptr[0], r->idx[0], r->val[0], U, V, d_part));
+    APMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_pmf_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nslots, d_part, sigma_sq,
+                       p.sig_u, p.sig_v, d_out2);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n, int m,
+                        apmf_ratings **out)
+{
+    APMF_REQUIRE(ctx && out, "ctx/out is NULL");
+    *out = nullptr;
+    APMF_REQUIRE(N >= 0 && n >= 1 && m >= 1, "bad shape N=%lld n=%d m=%d", (long long)N, n, m);
+    APMF_REQUIRE(N == 0 || h_ratings, "h_ratings is NULL");
+    // host CSR build: stable counting sort by user and by item
+    std::vector<int64_t> ptr[2];
+    std::vector<int32_t> idx[2];
+    std::vector<double> val[2];
+    ptr[0].assign((size_t)n + 1, 0);
+    ptr[1].assign((size_t)m + 1, 0);
+    for (int64_t t = 0; t < N; t++) {
+        const double fi = h_ratings[3 * t], fj = h_ratings[3 * t + 1];
+        APMF_REQUIRE(fi >= 0 && fi < n && fj >= 0 && fj < m && fi == (double)(int64_t)fi &&
+                         fj == (double)(int64_t)fj,
+                     "rating %lld has index (%g, %g) outside %d x %d", (long long)t, fi, fj, n, m);
+        ptr[0][(size_t)fi + 1]++;
+        ptr[1][(size_t)fj + 1]++;
+    }
+    for (int s = 0; s < 2; s++) {
+        for (size_t k = 1; k < ptr[s].size(); k++) ptr[s][k] += ptr[s][k - 1];
+        idx[s].resize((size_t)N);
+        val[s].resize((size_t)N);
+    }
+    {
+        std::vector<int64_t> cur0(ptr[0].begin(), ptr[0].end() - 1), cur1(ptr[1].begin(), ptr[1].end() - 1);
+        for (int64_t t = 0; t < N; t++) {
+            const int32_t i = (int32_t)h_ratings[3 * t], j = (int32_t)h_ratings[3 * t + 1];
+            const double rv = h_ratings[3 * t + 2];
+            int64_t a = cur0[i]++, b = cur1[j]++;
+            idx[0][a] = j; val[0][a] = rv;
+            idx[1][b] = i; val[1][b] = rv;
+        }
+    }
+    std::vector<int32_t> order((size_t)n + m);
+    for (int t = 0; t < n + m; t++) order[t] = t;
+    auto nnz = [&](int t) { return t < n ? ptr[0][t + 1] - ptr[0][t] : ptr[1][t - n + 1] - ptr[1][t - n]; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nnz(a) > nnz(b); });
+
+    apmf_ratings *r = new (std::nothrow) apmf_ratings();
+    if (!r) { apmf_set_error("out of host memory"); return APMF_ENOMEM; }
+    memset(r, 0, sizeof(*r));
+    r->N = N; r->n = n; r->m = m;
+    for (int t = 0; t < n; t++) if (nnz(t) == 0) r->has_empty[0] = 1;
+    for (int t = n; t < n + m; t++) if (nnz(t) == 0) r->has_empty[1] = 1;
+
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_ptr0 = al((size_t)(n + 1) * 8), b_ptr1 = al((size_t)(m + 1) * 8);
+    const size_t b_idx = al((size_t)N * 4 + 4), b_val = al((size_t)N * 8 + 8), b_ord = al((size_t)(n + m) * 4);
+    const size_t total = b_ptr0 + b_ptr1 + 2 * b_idx + 2 * b_val + b_ord;
+    APMF_CHECK_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(&r->block, total);
+    if (e != hipSuccess) {
+        delete r;
+        apmf_set_error("hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+        return APMF_ENOMEM;
+    }
+    char *base = (char *)r->block;
+    r->ptr[0] = (int64_t *)base; base += b_ptr0;
+    r->ptr[1] = (int64_t *)base; base += b_ptr1;
+    r->idx[0] = (int32_t *)base; base += b_idx;
+    r->idx[1] = (int32_t *)base; base += b_idx;
+    r->val[0] = (double *)base; base += b_val;
+    r->val[1] = (double *)base; base += b_val;
+    r->order = (int32_t *)base;
+    int rc = APMF_OK;
+    for (int s = 0; s < 2 && rc == APMF_OK; s++) {
+        rc = apmf_h2d(ctx, r->ptr[s], ptr[s].data(), ptr[s].size() * 8);
+        if (rc == APMF_OK && N) rc = apmf_h2d(ctx, r->idx[s], idx[s].data(), (size_t)N * 4);
+        if (rc == APMF_OK && N) rc = apmf_h2d(ctx, r->val[s], val[s].data(), (size_t)N * 8);
+    }
+    if (rc == APMF_OK) rc = apmf_h2d(ctx, r->order, order.data(), order.size() * 4);
+    if (rc != APMF_OK) { (void)hipFree(r->block); delete r; return rc; }
+    *out = r;
+    return APMF_OK;
+}
+
+int apmf_ratings_destroy(apmf_ctx *ctx, apmf_ratings *r)
+{
+    if (!r) return APMF_OK;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (r->block) (void)hipFree(r->block);
+    delete r;
+    return APMF_OK;
+}
+
+int apmf_ratings_count(const apmf_ratings *r, int64_t *N, int *n, int *m)
+{
+    APMF_REQUIRE(r, "ratings is NULL");
+    if (N) *N = r->N;
+    if (n) *n = r->n;
+    if (m) *m = r->m;
+    return APMF_OK;
+}
+
+int apmf_pmf_gradient(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V,
+                      int d, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                      int subtract_mean, double mean_rating, double *d_gU, double *d_gV)
+{
+    APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
+    APMF_REQUIRE(d_U && d_V && d_gU && d_gV, "NULL operand");
+    const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
+    return launch_grad(ctx, r, p, d_U, d_V, d_gU, d_gV);
+}
+
+int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U,
+                            const double *d_V, int d, double sigma_sq, double sigma_u_sq,
+                            double sigma_v_sq, int subtract_mean, double mean_rating,
+                            double *h_ll, double *h_sq_error)
+{
+    APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
+    APMF_REQUIRE(d_U && d_V, "NULL operand");
+    const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
+    const int nslots = std::max(r->n, r->m);
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 64, &w));
+    double *d_part = (double *)w;
+    double *d_out2 = d_part + (size_t)nslots * 3;
+    APMF_TRY(launch_ll(ctx, r, p, sigma_sq, d_U, d_V, d_part, d_out2));
+    double h[2];
+    APMF_TRY(apmf_d2h(ctx, h, d_out2, sizeof(h)));
+    if (h_ll) *h_ll = h[0];
+    if (h_sq_error) *h_sq_error = h[1];
+    return APMF_OK;
+}
+
+int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *d_V, int d,
+                     double sigma_sq, double sigma_u_sq, double sigma_v_sq, int subtract_mean,
+                     double mean_rating, double *h_lr, double min_learning_rate,
+                     double stop_thresh, int64_t max_steps, double *h_ll_trace,
+                     int64_t max_trace, int64_t *h_steps, int *h_converged)
+{
+    APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
+    APMF_REQUIRE(d_U && d_V && h_lr && h_steps, "NULL operand");
+    APMF_REQUIRE(max_trace == 0 || h_ll_trace, "h_ll_trace is NULL");
+    const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
+    const size_t nu = (size_t)r->n * d, nv = (size_t)r->m * d;
+    const int nslots = std::max(r->n, r->m);
+    // workspace 0: gU gV | trial U V ; workspace 1: partials + 2 outputs
+    void *w0, *w1;
+    APMF_TRY(apmf_ws(ctx, 0, (2 * (nu + nv)) * 8 + 64, &w0));
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 64, &w1));
+    double *gU = (double *)w0, *gV = gU + nu, *tU = gV + nv, *tV = tU + nu;
+    double *d_part = (double *)w1, *d_out2 = d_part + (size_t)nslots * 3;
+    void *pin;
+    APMF_TRY(apmf_pinned(ctx, 64, &pin));
+    volatile double *h2 = (volatile double *)pin;
+
+    auto eval_ll = [&](const double *U, const double *V, double *out) -> int {
+        APMF_TRY(launch_ll(ctx, r, p, sigma_sq, U, V, d_part, d_out2));
+        APMF_CHECK_HIP(hipMemcpyAsync((void *)h2, d_out2, 16, hipMemcpyDeviceToHost, ctx->stream));
+        APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        *out = h2[0];
+        return APMF_OK;
+    };
+
+    // the current point lives in (cU, cV); trial points are written to (oU, oV); an accepted
+    // step swaps the roles instead of copying (the reference rebinds self.users / self.items)
+    double *cU = d_U, *cV = d_V, *oU = tU, *oV = tV;
+    double lr = *h_lr, old_ll;
+    APMF_TRY(eval_ll(cU, cV, &old_ll));
+    int64_t steps = 0;
+    bool converged = false;
+    const int ax_blocks = (int)std::min<size_t>((nu + nv + 255) / 256, 2048);
+    while (!converged && (max_steps < 0 || steps < max_steps)) {
+        APMF_TRY(launch_grad(ctx, r, p, cU, cV, gU, gV));
+        for (;;) {
+            hipLaunchKernelGGL(k_axpy2, dim3(ax_blocks), dim3(256), 0, ctx->stream, nu, nv, lr, cU, gU, oU,
+                               cV, gV, oV);
+            APMF_CHECK_LAUNCH();
+            double new_ll;
+            APMF_TRY(eval_ll(oU, oV, &new_ll));
+            if (new_ll > old_ll) {
+                std::swap(cU, oU);
+                std::swap(cV, oV);
+                lr *= 1.25;
+                if (new_ll - old_ll < stop_thresh) converged = true;
+                if (steps < max_trace) h_ll_trace[steps] = new_ll;
+                steps++;
+                old_ll = new_ll;
+                break;
+            } else {
+                lr *= .5;
+                if (lr < min_learning_rate) { converged = true; break; }
+            }
+        }
+    }
+    if (cU != d_U) {
+        APMF_CHECK_HIP(hipMemcpyAsync(d_U, cU, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        APMF_CHECK_HIP(hipMemcpyAsync(d_V, cV, nv * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *h_lr = lr;
+    *h_steps = steps;
+    if (h_converged) *h_converged = converged ? 1 : 0;
+    return APMF_OK;
+}
+
+int apmf_pmf_minibatch_epoch(apmf_ctx *ctx, const double *h_shuffled_ratings, int64_t N, int n,
+                             int m, int64_t batch_size, double lr, double momentum, double *d_U,
+                             double *d_V, double *d_uinc, double *d_vinc, int d, double sigma_sq,
+                             double sigma_u_sq, double sigma_v_sq, int subtract_mean,
+                             double mean_rating)
+{
+    APMF_REQUIRE(ctx && h_shuffled_ratings && d_U && d_V && d_uinc && d_vinc, "NULL operand");
+    APMF_REQUIRE(N >= 1 && n >= 1 && m >= 1 && batch_size >= 1, "bad shape");
+    APMF_REQUIRE(d >= 1 && d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
+    APMF_REQUIRE(sigma_sq != 0. && sigma_u_sq != 0. && sigma_v_sq != 0., "zero variance");
+    // Host: per batch, a stable CSR over the rows (users first, then items) that occur in it.
+    const int64_t nb = (N + batch_size - 1) / batch_size;
+    std::vector<int32_t> rows; rows.reserve((size_t)2 * N);
+    std::vector<int64_t> ptr; ptr.reserve((size_t)2 * N + nb);
+    std::vector<int32_t> idx((size_t)2 * N);
+    std::vector<double> val((size_t)2 * N);
+    std::vector<int64_t> b_rows_off((size_t)nb + 1), b_ptr_off((size_t)nb + 1);
+    std::vector<int64_t> cnt((size_t)n + m), pos((size_t)n + m);
+    int64_t fill = 0;
+    for (int64_t b = 0; b < nb; b++) {
+        const int64_t lo = b * batch_size, hi = std::min(lo + batch_size, N);
+        b_rows_off[b] = (int64_t)rows.size();
+        b_ptr_off[b] = (int64_t)ptr.size();
+        std::vector<int32_t> present;
+        for (int64_t t = lo; t < hi; t++) {
+            const double fi = h_shuffled_ratings[3 * t], fj = h_shuffled_ratings[3 * t + 1];
+            APMF_REQUIRE(fi >= 0 && fi < n && fj >= 0 && fj < m, "rating index out of range");
+            const int32_t i = (int32_t)fi, j = n + (int32_t)fj;
+            if (cnt[i]++ == 0) present.push_back(i);
+            if (cnt[j]++ == 0) present.push_back(j);
+        }
+        std::sort(present.begin(), present.end());
+        for (int32_t rw : present) {
+            rows.push_back(rw);
+            ptr.push_back(fill);
+            pos[rw] = fill;
+            fill += cnt[rw];
+        }
+        ptr.push_back(fill);
+        for (int64_t t = lo; t < hi; t++) {
+            const int32_t i = (int32_t)h_shuffled_ratings[3 * t], j = (int32_t)h_shuffled_ratings[3 * t + 1];
+            const double rv = h_shuffled_ratings[3 * t + 2];
+            idx[pos[i]] = j; val[pos[i]++] = rv;
+            idx[pos[n + j]] = i; val[pos[n + j]++] = rv;
+        }
+        for (int32_t rw : present) cnt[rw] = 0;
+    }
+    b_rows_off[nb] = (int64_t)rows.size();
+    b_ptr_off[nb] = (int64_t)ptr.size();
+
+    const size_t nu = (size_t)n * d, nv = (size_t)m * d;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_rows = al(rows.size() * 4), b_ptr = al(ptr.size() * 8), b_idx = al(idx.size() * 4),
+                 b_val = al(val.size() * 8), b_g = al((nu + nv) * 8);
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 3, b_rows + b_ptr + b_idx + b_val + b_g, &w));
+    char *base = (char *)w;
+    int32_t *d_rows = (int32_t *)base; base += b_rows;
+    int64_t *d_ptr = (int64_t *)base; base += b_ptr;
+    int32_t *d_idx = (int32_t *)base; base += b_idx;
+    double *d_val = (double *)base; base += b_val;
+    double *gacc = (double *)base;
+    APMF_TRY(apmf_h2d(ctx, d_rows, rows.data(), rows.size() * 4));
+    APMF_TRY(apmf_h2d(ctx, d_ptr, ptr.data(), ptr.size() * 8));
+    APMF_TRY(apmf_h2d(ctx, d_idx, idx.data(), idx.size() * 4));
+    APMF_TRY(apmf_h2d(ctx, d_val, val.data(), val.size() * 8));
+    APMF_CHECK_HIP(hipMemsetAsync(gacc, 0, (nu + nv) * 8, ctx->stream));
+
+    PmfParams p;
+    p.n = n; p.m = m; p.d = d; p.sig = sigma_sq; p.sig_u = sigma_u_sq; p.sig_v = sigma_v_sq;
+    p.mean_add = subtract_mean ? mean_rating : 0.;
+    const int up_blocks = (int)std::min<size_t>((nu + nv + 255) / 256, 2048);
+    momentum = (double)(float)momentum;  // `float momentum` in the reference, pmf_cy.pyx:309
+    for (int64_t b = 0; b < nb; b++) {
+        const int64_t lo = b * batch_size, hi = std::min(lo + batch_size, N);
+        const int npres = (int)(b_rows_off[b + 1] - b_rows_off[b]);
+        const int blocks = (npres + 3) / 4;
+        const int32_t *rws = d_rows + b_rows_off[b];
+        const int64_t *pp = d_ptr + b_ptr_off[b];
+        DISPATCH_DP(dp_for(d),
+                    hipLaunchKernelGGL((k_pmf_grad_rows<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p,
+                                       npres, rws, pp, d_idx, d_val, d_U, d_V, gacc, gacc + nu));
+        APMF_CHECK_LAUNCH();
+        // `lr / n` is evaluated in C float in the reference (cdef float lr; int n), pmf_cy.pyx:309,339
+        const double scale = (double)((float)lr / (float)(hi - lo));
+        hipLaunchKernelGGL(k_momentum, dim3(up_blocks), dim3(256), 0, ctx->stream, nu, nv, momentum, scale,
+                           sigma_u_sq, sigma_v_sq, d_U, d_V, d_uinc, d_vinc, gacc, gacc + nu);
+        APMF_CHECK_LAUNCH();
+    }
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return APMF_OK;
+}
+
+int apmf_pmf_predicted_matrix(apmf_ctx *ctx, const double *d_U, const double *d_V, int n, int m,
+                              int d, double add, double *d_out, int ld)
+{
+    APMF_REQUIRE(ctx && d_U && d_V && d_out, "NULL operand");
+    APMF_REQUIRE(n >= 1 && m >= 1 && d >= 1 && ld >= m, "bad shape");
+    hipLaunchKernelGGL(k_predict, dim3((ld + 255) / 256, (n + 15) / 16), dim3(256), 0, ctx->stream, n, m, d,
+                       ld, add, d_U, d_V, d_out);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+} // extern "C"

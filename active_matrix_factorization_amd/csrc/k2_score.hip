@@ -1,0 +1,666 @@
+// k2_score.hip - candidate-grid variance scoring under the matrix-normal posterior.
+//
+// Replaces the per-candidate Python loop  pred_variance -> approx_pred_mean_var ->
+// exp_dotprod_sq  (mn_active_pmf.py:300-330,501-511; matrix_normal_exps_cy.pyx:126-154).
+// The reference sums d(d+1)/2 Isserlis terms per candidate and subtracts mean^2.  With
+// a = M_i, b = M_{n+j}, s_ii, s_jj, s_ij the entries of Sigma = cov_useritems and
+// O = cov_latents (the reference only ever reads O[k,l] with k <= l, so O is taken as its
+// upper triangle mirrored), the same quantity is
+//     Var = (s_ii s_jj + s_ij^2) tr(O^2) + s_jj a'Oa + s_ii b'Ob + 2 s_ij (Oa)'b
+//     E   = a'b + s_ij tr(O)
+// i.e. per candidate ONE streamed operand (s_ij) and a rank-d dot product against
+// per-row / per-column vectors.  The sweep is HBM-bound: 4 B read + 4 B written per
+// candidate in f32 (8 + 8 in f64).
+//
+// Kernel layout (wave64): a block is 4 waves that share a chunk of 64*VEC columns; each
+// lane keeps its VEC columns' b_j (D x VEC registers), q_j, s_jj for the whole block.  A
+// wave walks its own rows: per row the wave-uniform operands (Oa_i, a_i, a'Oa, s_ii) come in
+// through scalar loads, the s_ij row segment through one coalesced 16-byte load per lane,
+// and the scores leave through one 16-byte store per lane.  No LDS is needed.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_WAVE = 16;
+constexpr int WAVES = 4;
+constexpr int ROWS_PER_BLOCK = ROWS_PER_WAVE * WAVES;
+constexpr int UNR = 4;
+
+template <typename T, int N> struct Vec;
+template <> struct Vec<float, 4> { using type = float4; };
+template <> struct Vec<float, 2> { using type = float2; };
+template <> struct Vec<float, 1> { using type = float; };
+template <> struct Vec<double, 2> { using type = double2; };
+template <> struct Vec<double, 1> { using type = double; };
+
+template <typename T, int V>
+__device__ __forceinline__ void vload(T (&dst)[V], const T *p)
+{
+    using VT = typename Vec<T, V>::type;
+    VT v = *reinterpret_cast<const VT *>(p);
+    const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+    for (int i = 0; i < V; i++) dst[i] = e[i];
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void vstore(T *p, const T (&src)[V])
+{
+    using VT = typename Vec<T, V>::type;
+    VT v;
+    T *e = reinterpret_cast<T *>(&v);
+#pragma unroll
+    for (int i = 0; i < V; i++) e[i] = src[i];
+    *reinterpret_cast<VT *>(p) = v;
+}
+
+struct GridDims {
+    int B, n, m, d, ld;
+    int rs;            // rowpack row stride (elements)
+    int nblk_x, nblk_y;
+    int want;          // +1 max, -1 min, 0 none
+    int want_sum;
+};
+
+// Operands are separate `const __restrict__` kernel parameters (not members of a struct)
+// so that the wave-uniform row operands can be fetched with scalar loads.
+template <typename T>
+struct GridArgs {
+    GridDims g;
+    const T *cross;    // (B, n, ld)
+    const T *rowpack;  // (B, n, rs): [Oa (D) | a (D) | a'Oa | s_ii]
+    const T *colpack;  // (B, D+2, ld): b_k rows, then b'Ob, then s_jj
+    const T *state;    // (B, 2): tr(O^2), tr(O)
+    const uint8_t *mask;  // (n, ld) or NULL
+    T *var;            // (B, n, ld) or NULL
+    T *pmean;          // (B, n, ld) or NULL
+    double *part_sum;     // (B, nblk)
+    T *part_val;          // (B, nblk)
+    long long *part_idx;  // (B, nblk)
+};
+
+// ---- per-state operand packs ------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int D, int ld, int rs,
+                                                 const T *__restrict__ mean,
+                                                 const T *__restrict__ diag,
+                                                 const T *__restrict__ omega,
+                                                 T *__restrict__ rowpack, T *__restrict__ colpack,
+                                                 T *__restrict__ state)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;  // 0..n+ld
+    const T *O = omega + (size_t)b * d * d;
+    if (t == 0) {
+        T t2 = 0, tr = 0;
+        for (int k = 0; k < d; k++) {
+            tr += O[k * d + k];
+            t2 += O[k * d + k] * O[k * d + k];
+            for (int l = k + 1; l < d; l++) t2 += 2 * O[k * d + l] * O[k * d + l];
+        }
+        state[2 * b] = t2;
+        state[2 * b + 1] = tr;
+    }
+    if (t >= n + ld) return;
+    const bool is_user = t < n;
+    const int j = t - n;  // column when !is_user (may be padding >= m)
+    if (!is_user && j >= m) {
+        T *cp = colpack + (size_t)b * (D + 2) * ld;
+        for (int k = 0; k < D + 2; k++) cp[(size_t)k * ld + j] = 0;
+        return;
+    }
+    const T *a = mean + ((size_t)b * (n + m) + t) * d;
+    const T sd = diag[(size_t)b * (n + m) + t];
+    T quad = 0;
+    T *rp = rowpack + ((size_t)b * n + t) * rs;
+    T *cp = colpack + (size_t)b * (D + 2) * ld;
+    for (int k = 0; k < D; k++) {
+        T w = 0, ak = 0;
+        if (k < d) {
+            ak = a[k];
+            for (int l = 0; l < d; l++) w += O[k <= l ? k * d + l : l * d + k] * a[l];
+            quad += ak * w;
+        }
+        if (is_user) {
+            rp[k] = w;
+            rp[D + k] = ak;
+        } else {
+            cp[(size_t)k * ld + j] = ak;
+        }
+    }
+    if (is_user) {
+        rp[2 * D] = quad;
+        rp[2 * D + 1] = sd;
+    } else {
+        cp[(size_t)D * ld + j] = quad;
+        cp[(size_t)(D + 1) * ld + j] = sd;
+    }
+}
+
+// ---- the sweep ----------------------------------------------------------------------
+template <typename T, int D, int VEC>
+__global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__restrict__ p_cross,
+                                                 const T *__restrict__ p_rowpack,
+                                                 const T *__restrict__ p_colpack,
+                                                 const T *__restrict__ p_state,
+                                                 const uint8_t *__restrict__ p_mask,
+                                                 T *__restrict__ p_var, T *__restrict__ p_pmean,
+                                                 double *__restrict__ part_sum,
+                                                 T *__restrict__ part_val,
+                                                 long long *__restrict__ part_idx)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const int b = blockIdx.z;
+    const int j0 = (blockIdx.x * 64 + lane) * VEC;
+    const bool colok = j0 < a.ld;
+    const int ld = a.ld, n = a.n, m = a.m;
+    const int rbeg = blockIdx.y * ROWS_PER_BLOCK + wave * ROWS_PER_WAVE;
+    const int rend = min(rbeg + ROWS_PER_WAVE, n);
+
+    T bt[D][VEC], q[VEC], sjj[VEC];
+    {
+        const T *cp = p_colpack + (size_t)b * (D + 2) * ld + j0;
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            if (colok) vload<T, VEC>(bt[k], cp + (size_t)k * ld);
+            else
+#pragma unroll
+                for (int v = 0; v < VEC; v++) bt[k][v] = 0;
+        }
+        if (colok) {
+            vload<T, VEC>(q, cp + (size_t)D * ld);
+            vload<T, VEC>(sjj, cp + (size_t)(D + 1) * ld);
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) q[v] = sjj[v] = 0;
+        }
+    }
+    const T t2 = p_state[2 * b], trO = p_state[2 * b + 1];
+    const bool do_mean = p_pmean != nullptr;
+    const bool do_var = p_var != nullptr;
+    const bool do_red = a.want != 0 || a.want_sum;
+
+    double sum = 0.;
+    T bestv = 0;
+    long long besti = -1;
+
+    for (int i0 = rbeg; i0 < rend; i0 += UNR) {
+        T s[UNR][VEC];
+        unsigned char mk[UNR][VEC];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int i = i0 + u;
+            if (i < rend && colok) {
+                vload<T, VEC>(s[u], p_cross + ((size_t)b * n + i) * ld + j0);
+                if (p_mask) {
+                    const uint8_t *mp = p_mask + (size_t)i * ld + j0;
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) mk[u][v] = mp[v];
+                } else {
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) mk[u][v] = 1;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) { s[u][v] = 0; mk[u][v] = 0; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int i = i0 + u;
+            if (i >= rend) break;  // wave-uniform
+            const T *rp = p_rowpack + ((size_t)b * n + i) * a.rs;  // wave-uniform address
+            const T p = rp[2 * D], sii = rp[2 * D + 1];
+            T dot[VEC], var[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) dot[v] = 0;
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const T wk = rp[k];
+#pragma unroll
+                for (int v = 0; v < VEC; v++) dot[v] += wk * bt[k][v];
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                const T sv = s[u][v];
+                var[v] = (sii * sjj[v] + sv * sv) * t2 + sjj[v] * p + sii * q[v] + 2 * sv * dot[v];
+            }
+            if (colok) {
+                if (do_var) vstore<T, VEC>(p_var + ((size_t)b * n + i) * ld + j0, var);
+                if (do_mean) {
+                    T mn[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) mn[v] = 0;
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        const T ak = rp[D + k];
+#pragma unroll
+                        for (int v = 0; v < VEC; v++) mn[v] += ak * bt[k][v];
+                    }
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) mn[v] += s[u][v] * trO;
+                    vstore<T, VEC>(p_pmean + ((size_t)b * n + i) * ld + j0, mn);
+                }
+            }
+            if (do_red) {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    if (mk[u][v] && j0 + v < m) {
+                        sum += (double)var[v];
+                        const long long idx = (long long)i * m + (j0 + v);
+                        if (a.want) {
+                            // scan order is increasing idx within a thread: strict compare
+                            // keeps the first occurrence
+                            if (besti < 0 || (a.want > 0 ? var[v] > bestv : var[v] < bestv)) {
+                                bestv = var[v];
+                                besti = idx;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (do_red) {
+        __shared__ double sh_sum[WAVES];
+        __shared__ T sh_val[WAVES];
+        __shared__ long long sh_idx[WAVES];
+        sum = wave_sum(sum);
+        if (a.want) wave_argext(bestv, besti, a.want);
+        if (lane == 0) { sh_sum[wave] = sum; sh_val[wave] = bestv; sh_idx[wave] = besti; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double ts = sh_sum[0];
+            T bv = sh_val[0];
+            long long bi = sh_idx[0];
+            for (int w = 1; w < WAVES; w++) {
+                ts += sh_sum[w];
+                if (a.want) argext_merge(bv, bi, sh_val[w], sh_idx[w], a.want);
+            }
+            const size_t slot = (size_t)b * a.nblk_x * a.nblk_y + (size_t)blockIdx.y * a.nblk_x + blockIdx.x;
+            part_sum[slot] = ts;
+            part_val[slot] = bv;
+            part_idx[slot] = bi;
+        }
+    }
+}
+
+// one block per state: fixed-order combine of the per-block partials
+template <typename T>
+__global__ __launch_bounds__(256) void k_grid_finish(int nblk, int want, const double *__restrict__ part_sum,
+                                                     const T *__restrict__ part_val,
+                                                     const long long *__restrict__ part_idx,
+                                                     double *__restrict__ out_sum, T *__restrict__ out_val,
+                                                     int64_t *__restrict__ out_idx)
+{
+    const int b = blockIdx.x;
+    __shared__ double sh_sum[256];
+    __shared__ T sh_val[256];
+    __shared__ long long sh_idx[256];
+    double s = 0;
+    T bv = 0;
+    long long bi = -1;
+    for (int t = threadIdx.x; t < nblk; t += 256) {
+        s += part_sum[(size_t)b * nblk + t];
+        if (want) argext_merge(bv, bi, part_val[(size_t)b * nblk + t], part_idx[(size_t)b * nblk + t], want);
+    }
+    sh_sum[threadIdx.x] = s; sh_val[threadIdx.x] = bv; sh_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            sh_sum[threadIdx.x] += sh_sum[threadIdx.x + o];
+            if (want) {
+                T v = sh_val[threadIdx.x];
+                long long i = sh_idx[threadIdx.x];
+                argext_merge(v, i, sh_val[threadIdx.x + o], sh_idx[threadIdx.x + o], want);
+                sh_val[threadIdx.x] = v; sh_idx[threadIdx.x] = i;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (out_sum) out_sum[b] = sh_sum[0];
+        if (out_val) out_val[b] = sh_val[0];
+        if (out_idx) out_idx[b] = (int64_t)sh_idx[0];
+    }
+}
+
+template <typename T, int D, int VEC>
+void launch_grid(const GridArgs<T> &a, hipStream_t st)
+{
+    dim3 grid(a.g.nblk_x, a.g.nblk_y, a.g.B);
+    hipLaunchKernelGGL((k_mn_grid<T, D, VEC>), grid, dim3(256), 0, st, a.g, a.cross, a.rowpack,
+                       a.colpack, a.state, a.mask, a.var, a.pmean, a.part_sum, a.part_val,
+                       a.part_idx);
+}
+
+// padded latent dimension and vector width used for a runtime d
+template <typename T> struct Plan { int D, VEC; };
+template <typename T>
+Plan<T> plan_for(int d)
+{
+    static const int steps[] = {2, 4, 6, 8, 10, 12, 16, 24, 32, 48, 64};
+    Plan<T> p = {0, 0};
+    for (int s : steps)
+        if (d <= s) { p.D = s; break; }
+    const bool f32 = sizeof(T) == 4;
+    if (p.D <= 16) p.VEC = f32 ? 4 : 2;
+    else if (p.D <= 32) p.VEC = f32 ? 2 : 1;
+    else p.VEC = 1;
+    return p;
+}
+
+template <typename T>
+int dispatch_grid(const GridArgs<T> &a, int D, hipStream_t st);
+
+template <>
+int dispatch_grid<float>(const GridArgs<float> &a, int D, hipStream_t st)
+{
+    switch (D) {
+    case 2: launch_grid<float, 2, 4>(a, st); break;
+    case 4: launch_grid<float, 4, 4>(a, st); break;
+    case 6: launch_grid<float, 6, 4>(a, st); break;
+    case 8: launch_grid<float, 8, 4>(a, st); break;
+    case 10: launch_grid<float, 10, 4>(a, st); break;
+    case 12: launch_grid<float, 12, 4>(a, st); break;
+    case 16: launch_grid<float, 16, 4>(a, st); break;
+    case 24: launch_grid<float, 24, 2>(a, st); break;
+    case 32: launch_grid<float, 32, 2>(a, st); break;
+    case 48: launch_grid<float, 48, 1>(a, st); break;
+    case 64: launch_grid<float, 64, 1>(a, st); break;
+    default: return APMF_EINVAL;
+    }
+    return APMF_OK;
+}
+
+template <>
+int dispatch_grid<double>(const GridArgs<double> &a, int D, hipStream_t st)
+{
+    switch (D) {
+    case 2: launch_grid<double, 2, 2>(a, st); break;
+    case 4: launch_grid<double, 4, 2>(a, st); break;
+    case 6: launch_grid<double, 6, 2>(a, st); break;
+    case 8: launch_grid<double, 8, 2>(a, st); break;
+    case 10: launch_grid<double, 10, 2>(a, st); break;
+    case 12: launch_grid<double, 12, 2>(a, st); break;
+    case 16: launch_grid<double, 16, 2>(a, st); break;
+    case 24: launch_grid<double, 24, 1>(a, st); break;
+    case 32: launch_grid<double, 32, 1>(a, st); break;
+    case 48: launch_grid<double, 48, 1>(a, st); break;
+    case 64: launch_grid<double, 64, 1>(a, st); break;
+    default: return APMF_EINVAL;
+    }
+    return APMF_OK;
+}
+
+template <typename T>
+int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_mean,
+                  const T *d_cross, const T *d_diag, const T *d_omega, const uint8_t *d_mask,
+                  T *d_var, T *d_pmean, double *d_sum, int want, T *d_best_val,
+                  int64_t *d_best_idx)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    APMF_REQUIRE(B >= 1 && n >= 1 && m >= 1, "bad shape B=%d n=%d m=%d", B, n, m);
+    APMF_REQUIRE(d >= 1 && d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
+    APMF_REQUIRE(ld >= m && ld % APMF_GRID_ALIGN == 0, "ld=%d must be >= m=%d and a multiple of %d",
+                 ld, m, APMF_GRID_ALIGN);
+    APMF_REQUIRE(d_mean && d_cross && d_diag && d_omega, "NULL operand");
+    APMF_REQUIRE(want >= -1 && want <= 1, "want must be -1, 0 or +1");
+    APMF_REQUIRE(want == 0 || (d_best_val && d_best_idx), "want != 0 needs d_best_val/d_best_idx");
+    APMF_REQUIRE(((uintptr_t)d_cross % 16) == 0 && (!d_var || ((uintptr_t)d_var % 16) == 0) &&
+                     (!d_pmean || ((uintptr_t)d_pmean % 16) == 0),
+                 "grids must be 16-byte aligned");
+    if (!d_var && !d_pmean && !d_sum && want == 0) return APMF_OK;
+
+    const Plan<T> pl = plan_for<T>(d);
+    const int D = pl.D;
+    const int rs = round_up(2 * D + 2, 4);
+    GridArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.g.B = B; a.g.n = n; a.g.m = m; a.g.d = d; a.g.ld = ld; a.g.rs = rs;
+    a.g.nblk_x = (ld + 64 * pl.VEC - 1) / (64 * pl.VEC);
+    a.g.nblk_y = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const size_t nblk = (size_t)a.g.nblk_x * a.g.nblk_y;
+
+    // workspace 0: packs; workspace 1: partials
+    const size_t rp_el = (size_t)B * n * rs, cp_el = (size_t)B * (D + 2) * ld, st_el = (size_t)B * 2;
+    void *w0;
+    APMF_TRY(apmf_ws(ctx, 0, (rp_el + cp_el + st_el) * sizeof(T) + 64, &w0));
+    T *rowpack = (T *)w0;
+    T *colpack = rowpack + rp_el;
+    T *state = colpack + cp_el;
+    void *w1;
+    const size_t part_bytes = (size_t)B * nblk * (sizeof(double) + sizeof(T) + sizeof(long long)) + 64;
+    APMF_TRY(apmf_ws(ctx, 1, part_bytes, &w1));
+    a.part_sum = (double *)w1;
+    a.part_idx = (long long *)(a.part_sum + (size_t)B * nblk);
+    a.part_val = (T *)(a.part_idx + (size_t)B * nblk);
+
+    hipLaunchKernelGGL((k_mn_prep<T>), dim3((n + ld + 255) / 256, B), dim3(256), 0, ctx->stream, B,
+                       n, m, d, D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+    APMF_CHECK_LAUNCH();
+
+    a.cross = d_cross; a.rowpack = rowpack; a.colpack = colpack; a.state = state;
+    a.mask = d_mask; a.var = d_var; a.pmean = d_pmean; a.g.want = want; a.g.want_sum = d_sum != nullptr;
+    int rc = dispatch_grid<T>(a, D, ctx->stream);
+    if (rc != APMF_OK) { apmf_set_error("no kernel for padded latent_d=%d", D); return rc; }
+    APMF_CHECK_LAUNCH();
+    if (want != 0 || d_sum) {
+        hipLaunchKernelGGL((k_grid_finish<T>), dim3(B), dim3(256), 0, ctx->stream, (int)nblk, want,
+                           a.part_sum, a.part_val, a.part_idx, d_sum, d_best_val, d_best_idx);
+        APMF_CHECK_LAUNCH();
+    }
+    return APMF_OK;
+}
+
+// ---- arbitrary pool of candidates, float64 ------------------------------------------
+__global__ __launch_bounds__(256) void k_mn_pool(int n, int m, int d, int ld,
+                                                 const double *__restrict__ mean,
+                                                 const double *__restrict__ cross,
+                                                 const double *__restrict__ diag,
+                                                 const double *__restrict__ omega,
+                                                 const int32_t *__restrict__ pi,
+                                                 const int32_t *__restrict__ pj, int64_t P,
+                                                 double *__restrict__ pmean, double *__restrict__ var)
+{
+    extern __shared__ double sO[];  // d*d mirrored omega, then t2, tr
+    for (int t = threadIdx.x; t < d * d; t += blockDim.x) {
+        int k = t / d, l = t % d;
+        sO[t] = omega[k <= l ? k * d + l : l * d + k];
+    }
+    __syncthreads();
+    double t2 = 0, tr = 0;
+    for (int k = 0; k < d; k++) {
+        tr += sO[k * d + k];
+        for (int l = 0; l < d; l++) t2 += sO[k * d + l] * sO[k * d + l];
+    }
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < P; p += stride) {
+        const int i = pi[p], j = pj[p];
+        if (i < 0 || i >= n || j < 0 || j >= m) {  // never index out of bounds
+            if (pmean) pmean[p] = __builtin_nan("");
+            if (var) var[p] = __builtin_nan("");
+            continue;
+        }
+        const double *a = mean + (size_t)i * d, *b = mean + (size_t)(n + j) * d;
+        const double sij = cross[(size_t)i * ld + j], sii = diag[i], sjj = diag[n + j];
+        double aOa = 0, bOb = 0, aOb = 0, ab = 0;
+        for (int k = 0; k < d; k++) {
+            double oa = 0, ob = 0;
+            for (int l = 0; l < d; l++) { oa += sO[k * d + l] * a[l]; ob += sO[k * d + l] * b[l]; }
+            aOa += a[k] * oa; bOb += b[k] * ob; aOb += b[k] * oa; ab += a[k] * b[k];
+        }
+        if (var) var[p] = (sii * sjj + sij * sij) * t2 + sjj * aOa + sii * bOb + 2 * sij * aOb;
+        if (pmean) pmean[p] = ab + sij * tr;
+    }
+}
+
+// ---- near-extremum collection after an f32 sweep -------------------------------------
+__global__ __launch_bounds__(256) void k_collect_near(int n, int m, int ld, const float *__restrict__ var,
+                                                      const uint8_t *__restrict__ mask, int want,
+                                                      float best, float tol, int32_t *__restrict__ pi,
+                                                      int32_t *__restrict__ pj, int cap,
+                                                      int *__restrict__ count)
+{
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)n * ld, stride = (int64_t)gridDim.x * blockDim.x;
+    for (; t < total; t += stride) {
+        const int i = (int)(t / ld), j = (int)(t % ld);
+        if (j >= m) continue;
+        if (mask && !mask[t]) continue;
+        const float v = var[t];
+        const bool near = want > 0 ? (v >= best - tol) : (v <= best + tol);
+        if (near) {
+            int slot = atomicAdd(count, 1);
+            if (slot < cap) { pi[slot] = i; pj[slot] = j; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather(const double *__restrict__ grid, int ld,
+                                                const int32_t *__restrict__ pi,
+                                                const int32_t *__restrict__ pj, int64_t P,
+                                                double *__restrict__ out)
+{
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < P; p += stride) out[p] = grid[(size_t)pi[p] * ld + pj[p]];
+}
+
+// first arg-extremum of a vector in index order; NaNs never win
+__global__ __launch_bounds__(256) void k_pool_argext_part(const double *__restrict__ v, int64_t P, int want,
+                                                          double *__restrict__ pv, long long *__restrict__ pidx)
+{
+    double bv = 0;
+    long long bi = -1;
+    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(lo + per, P);
+    for (int64_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+        const double x = v[t];
+        if (bi < 0 ? (x == x) : (want > 0 ? x > bv : x < bv)) { bv = x; bi = t; }
+    }
+    __shared__ double sv[4];
+    __shared__ long long si[4];
+    wave_argext(bv, bi, want);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) argext_merge(bv, bi, sv[w], si[w], want);
+        pv[blockIdx.x] = bv;
+        pidx[blockIdx.x] = bi;
+    }
+}
+
+__global__ void k_pool_argext_fin(int nb, int want, const double *__restrict__ pv,
+                                  const long long *__restrict__ pidx, double *__restrict__ ov,
+                                  long long *__restrict__ oi)
+{
+    double bv = 0;
+    long long bi = -1;
+    for (int t = 0; t < nb; t++) argext_merge(bv, bi, pv[t], pidx[t], want);
+    *ov = bv;
+    *oi = bi;
+}
+
+} // namespace
+
+extern "C" {
+
+int apmf_mn_score_grid_f32(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const float *d_mean,
+                           const float *d_cross, const float *d_diag, const float *d_omega,
+                           const uint8_t *d_mask, float *d_var, float *d_pmean, double *d_sum,
+                           int want, float *d_best_val, int64_t *d_best_idx)
+{
+    return mn_score_grid<float>(ctx, B, n, m, d, ld, d_mean, d_cross, d_diag, d_omega, d_mask, d_var,
+                                d_pmean, d_sum, want, d_best_val, d_best_idx);
+}
+
+int apmf_mn_score_grid_f64(apmf_ctx *ctx, int B, int n, int m, int d, int ld,
+                           const double *d_mean, const double *d_cross, const double *d_diag,
+                           const double *d_omega, const uint8_t *d_mask, double *d_var,
+                           double *d_pmean, double *d_sum, int want, double *d_best_val,
+                           int64_t *d_best_idx)
+{
+    return mn_score_grid<double>(ctx, B, n, m, d, ld, d_mean, d_cross, d_diag, d_omega, d_mask, d_var,
+                                 d_pmean, d_sum, want, d_best_val, d_best_idx);
+}
+
+int apmf_mn_score_pool_f64(apmf_ctx *ctx, int n, int m, int d, int ld, const double *d_mean,
+                           const double *d_cross, const double *d_diag, const double *d_omega,
+                           const int32_t *d_pi, const int32_t *d_pj, int64_t P, double *d_pmean,
+                           double *d_var)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    APMF_REQUIRE(n >= 1 && m >= 1 && d >= 1 && d <= APMF_MAX_D && ld >= m, "bad shape");
+    APMF_REQUIRE(P >= 0, "negative pool size");
+    if (P == 0) return APMF_OK;
+    APMF_REQUIRE(d_mean && d_cross && d_diag && d_omega && d_pi && d_pj, "NULL operand");
+    int blocks = (int)(cdiv64(P, 256) < 2048 ? cdiv64(P, 256) : 2048);
+    hipLaunchKernelGGL(k_mn_pool, dim3(blocks), dim3(256), (size_t)d * d * sizeof(double), ctx->stream,
+                       n, m, d, ld, d_mean, d_cross, d_diag, d_omega, d_pi, d_pj, P, d_pmean, d_var);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+int apmf_grid_collect_near_f32(apmf_ctx *ctx, int n, int m, int ld, const float *d_var,
+                               const uint8_t *d_mask, int want, float best, float rel_tol,
+                               int32_t *d_pi, int32_t *d_pj, int cap, int *h_count)
+{
+    APMF_REQUIRE(ctx && d_var && d_pi && d_pj && h_count, "NULL operand");
+    APMF_REQUIRE(want == 1 || want == -1, "want must be +1 or -1");
+    APMF_REQUIRE(n >= 1 && m >= 1 && ld >= m && cap >= 1, "bad shape");
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 2, 64, &w));
+    int *d_count = (int *)w;
+    APMF_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+    const float tol = rel_tol * (best < 0 ? -best : best);
+    int64_t total = (int64_t)n * ld;
+    int blocks = (int)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
+    hipLaunchKernelGGL(k_collect_near, dim3(blocks), dim3(256), 0, ctx->stream, n, m, ld, d_var, d_mask,
+                       want, best, tol, d_pi, d_pj, cap, d_count);
+    APMF_CHECK_LAUNCH();
+    return apmf_d2h(ctx, h_count, d_count, sizeof(int));
+}
+
+int apmf_grid_gather_f64(apmf_ctx *ctx, const double *d_grid, int ld, const int32_t *d_pi,
+                         const int32_t *d_pj, int64_t P, double *d_out)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (P == 0) return APMF_OK;
+    APMF_REQUIRE(d_grid && d_pi && d_pj && d_out && P > 0, "bad operand");
+    int blocks = (int)(cdiv64(P, 256) < 2048 ? cdiv64(P, 256) : 2048);
+    hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, ctx->stream, d_grid, ld, d_pi, d_pj, P, d_out);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+int apmf_pool_argext_f64(apmf_ctx *ctx, const double *d_vals, int64_t P, int want, int64_t *h_pos,
+                         double *h_val)
+{
+    APMF_REQUIRE(ctx && d_vals && h_pos, "NULL operand");
+    APMF_REQUIRE(P >= 1, "empty pool");  // mn_active_pmf.py:723-724 raises ValueError
+    APMF_REQUIRE(want == 1 || want == -1, "want must be +1 or -1");
+    int nb = (int)(cdiv64(P, 4096) < 512 ? cdiv64(P, 4096) : 512);
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 2, (size_t)(nb + 1) * 16 + 64, &w));
+    double *pv = (double *)w;
+    long long *pidx = (long long *)(pv + nb + 1);
+    hipLaunchKernelGGL(k_pool_argext_part, dim3(nb), dim3(256), 0, ctx->stream, d_vals, P, want, pv, pidx);
+    APMF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_pool_argext_fin, dim3(1), dim3(1), 0, ctx->stream, nb, want, pv, pidx, pv + nb,
+                       pidx + nb);
+    APMF_CHECK_LAUNCH();
+    double v;
+    long long i;
+    APMF_TRY(apmf_d2h(ctx, &v, pv + nb, sizeof(double)));
+    APMF_TRY(apmf_d2h(ctx, &i, pidx + nb, sizeof(long long)));
+    *h_pos = (int64_t)i;
+    if (h_val) *h_val = v;
+    return APMF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,212 @@
+// k3_gibbs.hip - Bayesian-PMF Gibbs row updates: one half-sweep of samples()
+// (bayes_pmf.py:280-296) = `rows` independent sample_feature() calls (bayes_pmf.py:189-216),
+// float64 like the reference.
+//
+// Per row t:  F = oth[idx(t)]  (gathered n_t x d),
+//     A    = alpha + beta F'F                     (d x d normal-equation build)
+//     cov  = A^-1,  mean = cov (beta F'(r - sub) + alpha mu)
+//     out  = chol(cov) z + mean                   (LOWER Cholesky of the covariance, as the
+//                                                  reference draws it: bayes_pmf.py:214-216)
+// One wave (64-thread block) owns a row.  The gathered rows are staged through LDS in
+// chunks of CH rows; each lane keeps NSLOT (k,l) pairs of the symmetric F'F in registers
+// (d(d+1)/2 pairs over 64 lanes) and sums them over the ratings in storage order.  The
+// d x d factorisations run in LDS, one lane per matrix row.  d^3 work per row is tiny: the
+// sweep is bound by the gather (nnz*(8+8d) bytes) and by launch latency at MovieLens size.
+#include "common.h"
+
+
+namespace {
+
+constexpr int CH = 32;  // gathered rows staged per chunk
+
+// in-place lower Cholesky of the symmetric matrix held in LDS (leading dim lda); lane = row.
+// Returns false (wave-uniform) if a pivot is not positive.
+__device__ __forceinline__ bool chol_lds(double *A, int d, int lda, int lane)
+{
+    bool ok = true;
+    for (int j = 0; j < d; j++) {
+        const double piv = A[j * lda + j];
+        if (!(piv > 0.)) { ok = false; break; }  // same value in every lane: uniform
+        const double s = sqrt(piv);
+        __syncthreads();
+        if (lane == j) A[j * lda + j] = s;
+        if (lane > j && lane < d) A[lane * lda + j] /= s;
+        __syncthreads();
+        if (lane > j && lane < d) {
+            const double lij = A[lane * lda + j];
+            for (int c = j + 1; c <= lane; c++) A[lane * lda + c] -= lij * A[c * lda + j];
+        }
+        __syncthreads();
+    }
+    return ok;
+}
+
+template <int NSLOT>
+__global__ __launch_bounds__(64) void k_gibbs_rows(int rows, int d, const int64_t *__restrict__ ptr,
+                                                   const int32_t *__restrict__ idx,
+                                                   const double *__restrict__ val,
+                                                   const double *__restrict__ oth,
+                                                   const double *__restrict__ alpha,
+                                                   const double *__restrict__ mu, double beta,
+                                                   double mean_sub, const double *__restrict__ z,
+                                                   double *__restrict__ out, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int row = blockIdx.x;
+    if (row >= rows) return;
+    const int lda = d + 1;
+    double *Fs = smem;                    // CH x d
+    double *rs = Fs + CH * d;             // CH (rating - sub)
+    double *A = rs + CH;                  // d x lda : A, then its Cholesky factor, then chol(cov)
+    double *X = A + d * lda;              // d x lda : L^-1, then cov
+    double *rhs = X + d * lda;            // d
+    double *mean = rhs + d;               // d
+
+    // pair slots: p = lane + 64*s -> (k, l), k <= l
+    int pk[NSLOT], pl[NSLOT];
+    double acc[NSLOT];
+    const int npairs = d * (d + 1) / 2;
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        int p = lane + 64 * s;
+        int k = 0, l = 0;
+        if (p < npairs) {
+            // row-wise enumeration of the upper triangle
+            int rem = p;
+            k = 0;
+            while (rem >= d - k) { rem -= d - k; k++; }
+            l = k + rem;
+        }
+        pk[s] = k; pl[s] = l; acc[s] = 0.;
+    }
+    double racc = 0.;  // lane k < d: sum_r F[r][k] * (rating_r - sub)
+
+    const int64_t beg = ptr[row], end = ptr[row + 1];
+    for (int64_t c0 = beg; c0 < end; c0 += CH) {
+        const int cnt = (int)min((int64_t)CH, end - c0);
+        __syncthreads();
+        for (int e = lane; e < cnt * d; e += 64) {
+            const int r = e / d, k = e - r * d;
+            Fs[r * d + k] = oth[(size_t)idx[c0 + r] * d + k];
+        }
+        if (lane < cnt) rs[lane] = val[c0 + lane] - mean_sub;
+        __syncthreads();
+        for (int r = 0; r < cnt; r++) {
+#pragma unroll
+            for (int s = 0; s < NSLOT; s++) acc[s] += Fs[r * d + pk[s]] * Fs[r * d + pl[s]];
+            if (lane < d) racc += Fs[r * d + lane] * rs[r];
+        }
+    }
+    __syncthreads();
+    // A = alpha + beta F'F (symmetric fill), rhs = beta F'r + alpha mu
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const int p = lane + 64 * s;
+        if (p < npairs) {
+            const int k = pk[s], l = pl[s];
+            A[k * lda + l] = alpha[k * d + l] + beta * acc[s];
+            if (k != l) A[l * lda + k] = alpha[l * d + k] + beta * acc[s];
+        }
+    }
+    if (lane < d) {
+        double am = 0.;
+        for (int l = 0; l < d; l++) am += alpha[lane * d + l] * mu[l];
+        rhs[lane] = beta * racc + am;
+    }
+    __syncthreads();
+
+    // A = R R'
+    if (!chol_lds(A, d, lda, lane)) {
+        if (lane == 0) atomicExch(status, 1);
+        return;
+    }
+    // X = R^-1 (lower): lane c solves R x = e_c
+    if (lane < d) {
+        const int c = lane;
+        for (int r = 0; r < c; r++) X[r * lda + c] = 0.;
+        X[c * lda + c] = 1. / A[c * lda + c];
+        for (int r = c + 1; r < d; r++) {
+            double s = 0.;
+            for (int k = c; k < r; k++) s += A[r * lda + k] * X[k * lda + c];
+            X[r * lda + c] = -s / A[r * lda + r];
+        }
+    }
+    __syncthreads();
+    // cov = X' X  -> into A (lane = row a); symmetric by construction
+    if (lane < d) {
+        const int a = lane;
+        for (int b = 0; b < d; b++) {
+            double s = 0.;
+            for (int r = max(a, b); r < d; r++) s += X[r * lda + a] * X[r * lda + b];
+            A[a * lda + b] = s;
+        }
+    }
+    __syncthreads();
+    if (lane < d) {
+        double s = 0.;
+        for (int l = 0; l < d; l++) s += A[lane * lda + l] * rhs[l];
+        mean[lane] = s;
+    }
+    __syncthreads();
+    // lower Cholesky of the covariance, then the draw
+    if (!chol_lds(A, d, lda, lane)) {
+        if (lane == 0) atomicExch(status, 1);
+        return;
+    }
+    if (lane < d) {
+        double s = 0.;
+        for (int l = 0; l <= lane; l++) s += A[lane * lda + l] * z[(size_t)row * d + l];
+        out[(size_t)row * d + lane] = s + mean[lane];
+    }
+}
+
+size_t gibbs_smem(int d)
+{
+    return sizeof(double) * ((size_t)CH * d + CH + 2 * (size_t)d * (d + 1) + 2 * d);
+}
+
+} // namespace
+
+extern "C" int apmf_gibbs_half_sweep(apmf_ctx *ctx, const apmf_ratings *r, int side, const double *d_oth,
+                                     int d, const double *d_alpha, const double *d_mu, double beta,
+                                     double mean_sub, const double *d_z, double *d_out)
+{
+    APMF_REQUIRE(ctx && r, "ctx/ratings is NULL");
+    APMF_REQUIRE(side == 0 || side == 1, "side must be 0 (users) or 1 (items)");
+    APMF_REQUIRE(d >= 1 && d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
+    APMF_REQUIRE(d_oth && d_alpha && d_mu && d_z && d_out, "NULL operand");
+    // bayes_pmf.py:287,296: items_by_user[user_id] raises KeyError for a row without ratings
+    APMF_REQUIRE(!r->has_empty[side], "a %s has no rating: the Gibbs sweep needs >= 1 per row",
+                 side == 0 ? "user" : "item");
+    const int rows = side == 0 ? r->n : r->m;
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 2, 64, &w));
+    int *d_status = (int *)w;
+    APMF_CHECK_HIP(hipMemsetAsync(d_status, 0, sizeof(int), ctx->stream));
+    const int npairs = d * (d + 1) / 2;
+    const int nslot = (npairs + 63) / 64;
+    const size_t smem = gibbs_smem(d);
+#define LAUNCH_GIBBS(NS)                                                                          \
+    hipLaunchKernelGGL((k_gibbs_rows<NS>), dim3(rows), dim3(64), smem, ctx->stream, rows, d,      \
+                       r->ptr[side], r->idx[side], r->val[side], d_oth, d_alpha, d_mu, beta,      \
+                       mean_sub, d_z, d_out, d_status)
+    if (smem > 64 * 1024)
+        APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_gibbs_rows<33>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (nslot <= 1) LAUNCH_GIBBS(1);
+    else if (nslot <= 2) LAUNCH_GIBBS(2);
+    else if (nslot <= 4) LAUNCH_GIBBS(4);
+    else if (nslot <= 9) LAUNCH_GIBBS(9);
+    else if (nslot <= 17) LAUNCH_GIBBS(17);
+    else LAUNCH_GIBBS(33);
+#undef LAUNCH_GIBBS
+    APMF_CHECK_LAUNCH();
+    int status = 0;
+    APMF_TRY(apmf_d2h(ctx, &status, d_status, sizeof(int)));
+    if (status) {
+        apmf_set_error("alpha + beta F'F (or its inverse) is not positive definite");
+        return APMF_ENOTPD;
+    }
+    return APMF_OK;
+}

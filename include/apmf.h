@@ -1,0 +1,207 @@
+/*
+ * apmf.h - C-ABI of libapmf_hip.so: the MI355X (gfx950) hot path of active PMF.
+ *
+ * The reference (autonlab/active-matrix-factorization, python-pmf/) has no FFI of
+ * its own: its native layer is three Cython modules called from Python classes.
+ * Each entry point below replaces the reference function(s) cited next to it
+ * (paths relative to /root/reference/python-pmf/).  The Python mirror of the
+ * reference's class surface (the .py modules of active_matrix_factorization_amd) binds these
+ * with ctypes; INTEGRATION.md shows the stub a maintainer of the reference adds.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - Every function returns int: 0 = APMF_OK, < 0 = apmf_status.  No exception
+ *    crosses the boundary.  apmf_last_error() gives the message for the calling
+ *    thread's last failure.
+ *  - Pointers named d_* are DEVICE pointers (hipMalloc'd by apmf_malloc, or any
+ *    other allocator on the same device, e.g. a torch tensor's data_ptr()).
+ *    Pointers named h_* are HOST pointers, borrowed for the call only.
+ *  - All matrices are row-major and dense.  Grids of candidates use a row pitch
+ *    `ld` (in elements) >= m, a multiple of APMF_GRID_ALIGN (apmf_grid_ld()).
+ *  - One apmf_ctx = one device + one stream.  A ctx is not thread-safe; use one
+ *    per thread.  Work is enqueued on the ctx stream; calls that return host
+ *    values synchronise that stream, the others are asynchronous.
+ *  - Never create a ctx before fork(): a HIP context does not survive it.
+ */
+#ifndef APMF_H
+#define APMF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum apmf_status {
+    APMF_OK = 0,
+    APMF_EINVAL = -1,  /* bad argument (NULL, shape, unsupported latent_d ...) -> ValueError */
+    APMF_EHIP = -2,    /* a HIP runtime call failed -> RuntimeError                          */
+    APMF_ENOMEM = -3,  /* device or host allocation failed -> MemoryError                    */
+    APMF_ENOTPD = -4,  /* a matrix that must be positive definite is not -> LinAlgError      */
+    APMF_ENODEV = -5   /* no usable gfx950 device -> RuntimeError                            */
+} apmf_status;
+
+#define APMF_GRID_ALIGN 64  /* row pitch of candidate grids, in elements */
+#define APMF_MAX_D 64       /* largest latent_d the kernels are built for  */
+
+typedef struct apmf_ctx apmf_ctx;
+typedef struct apmf_ratings apmf_ratings;
+
+/* ---- context, memory, stream plumbing --------------------------------------- */
+int apmf_version(void);
+const char *apmf_last_error(void);
+int apmf_device_count(int *count);
+int apmf_ctx_create(int device, apmf_ctx **out);
+int apmf_ctx_destroy(apmf_ctx *ctx);
+/* run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL switches back to the ctx's own stream */
+int apmf_ctx_set_stream(apmf_ctx *ctx, void *hip_stream);
+int apmf_ctx_sync(apmf_ctx *ctx);
+int apmf_grid_ld(int m); /* m rounded up to APMF_GRID_ALIGN */
+
+int apmf_malloc(apmf_ctx *ctx, size_t bytes, void **d_out);
+int apmf_free(apmf_ctx *ctx, void *d_ptr);
+int apmf_memset(apmf_ctx *ctx, void *d_ptr, int value, size_t bytes);
+int apmf_h2d(apmf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int apmf_d2h(apmf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int apmf_d2d(apmf_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* strided 2-D copies (pitches and width in bytes), e.g. the (n, m) cross block of the
+ * (n+m, n+m) cov_useritems into a grid of pitch ld */
+int apmf_h2d_2d(apmf_ctx *ctx, void *d_dst, size_t dpitch, const void *h_src, size_t spitch,
+                size_t width, size_t height);
+int apmf_d2h_2d(apmf_ctx *ctx, void *h_dst, size_t dpitch, const void *d_src, size_t spitch,
+                size_t width, size_t height);
+/* element-wise f64 -> f32 / f32 -> f64 conversion on the device */
+int apmf_cast_f64_f32(apmf_ctx *ctx, float *d_dst, const double *d_src, size_t count);
+int apmf_cast_f32_f64(apmf_ctx *ctx, double *d_dst, const float *d_src, size_t count);
+
+/* ---- K1: PMF MAP fit over the observed ratings (pmf_cy.pyx) --------------------- */
+/* ratings container: replaces `self.ratings` iteration of pmf_cy.pyx:184,217,230.
+ * h_ratings is the reference's (N, 3) float64 array of [i, j, r] rows.  Builds, on the
+ * device, CSR-by-user and CSR-by-item (int32 indices, float64 values) whose per-row
+ * order is the storage order of h_ratings (stable), so every per-row sum is taken in
+ * the reference's order. */
+int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n, int m,
+                        apmf_ratings **out);
+int apmf_ratings_destroy(apmf_ctx *ctx, apmf_ratings *r);
+int apmf_ratings_count(const apmf_ratings *r, int64_t *N, int *n, int *m);
+
+/* gradient(), pmf_cy.pyx:204-223.  d_U (n,d), d_V (m,d) float64 in; d_gU, d_gV out. */
+int apmf_pmf_gradient(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V,
+                      int d, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                      int subtract_mean, double mean_rating, double *d_gU, double *d_gV);
+/* log_likelihood(), pmf_cy.pyx:170-193 (h_ll) and the bare sum of squared errors that
+ * update_sigma() needs, pmf_cy.pyx:225-234 (h_sq_error; either may be NULL). */
+int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U,
+                            const double *d_V, int d, double sigma_sq, double sigma_u_sq,
+                            double sigma_v_sq, int subtract_mean, double mean_rating,
+                            double *h_ll, double *h_sq_error);
+/* fit_lls(), pmf_cy.pyx:257-291: batch gradient ascent with the x1.25 / x0.5 learning-rate
+ * search, entirely on the device.  d_U, d_V are updated in place.  Runs until convergence
+ * or until max_steps accepted steps (max_steps < 0: no limit).  h_ll_trace[0..min(steps,
+ * max_trace)) receives the LL the reference's generator would yield.  *h_lr: in = starting
+ * learning rate, out = learning rate after the last step (so a caller can resume);
+ * *h_converged: the reference's `converged` flag. */
+int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *d_V, int d,
+                     double sigma_sq, double sigma_u_sq, double sigma_v_sq, int subtract_mean,
+                     double mean_rating, double *h_lr, double min_learning_rate,
+                     double stop_thresh, int64_t max_steps, double *h_ll_trace,
+                     int64_t max_trace, int64_t *h_steps, int *h_converged);
+/* One epoch of fit_minibatches(), pmf_cy.pyx:324-344, on ALREADY SHUFFLED ratings
+ * (the host keeps np.random.shuffle so the RNG stream matches): for each consecutive
+ * batch  inc = momentum*inc + grad*(lr/len(batch)); params += inc.  d_U, d_V, d_uinc,
+ * d_vinc are updated in place. */
+int apmf_pmf_minibatch_epoch(apmf_ctx *ctx, const double *h_shuffled_ratings, int64_t N, int n,
+                             int m, int64_t batch_size, double lr, double momentum, double *d_U,
+                             double *d_V, double *d_uinc, double *d_vinc, int d, double sigma_sq,
+                             double sigma_u_sq, double sigma_v_sq, int subtract_mean,
+                             double mean_rating);
+/* predicted_matrix(), pmf_cy.pyx:410-420: d_out (n, ld) = U V^T (+ mean_rating). */
+int apmf_pmf_predicted_matrix(apmf_ctx *ctx, const double *d_U, const double *d_V, int n, int m,
+                              int d, double add, double *d_out, int ld);
+
+/* ---- K2: candidate-grid scoring under the matrix-normal posterior ----------------
+ * Replaces MNActivePMF.approx_pred_mean_var / approx_pred_means_vars / pred_variance /
+ * _total_variance (mn_active_pmf.py:300-330, 501-511, 597-598) and the per-candidate
+ * matrix_normal_exps_cy.exp_dotprod_sq (matrix_normal_exps_cy.pyx:126-154) they call.
+ *
+ * A posterior state is  mean M (n+m, d),  Sigma = cov_useritems,  Omega = cov_latents.
+ * Only what the path reads is passed: the (n, m) cross block Sigma[i, n+j] as a grid of
+ * pitch ld, and the diagonal Sigma[t, t] (n+m).  B states are scored per launch (B >= 1):
+ * every array has a leading batch dimension with the strides implied by its shape.
+ *   d_mean   (B, n+m, d)      d_cross (B, n, ld)     d_diag (B, n+m)     d_omega (B, d, d)
+ * Outputs (each may be NULL):
+ *   d_var    (B, n, ld)   Var[U_i . V_j]            d_pmean (B, n, ld)  E[U_i . V_j]
+ *   d_sum    (B) float64  sum of Var over the candidates (mask applied)  [_total_variance]
+ *   d_best_val (B) / d_best_idx (B, int64 flat i*m+j): arg-extremum over the candidates
+ *       (want = +1 max, -1 min, 0 none); ties -> lowest flat index; idx = -1 if none.
+ * d_mask (n, ld) uint8, shared by all states, 1 = candidate (unrated), NULL = all.
+ * Masked-out entries of d_var/d_pmean are still written (the value is well defined).
+ */
+int apmf_mn_score_grid_f32(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const float *d_mean,
+                           const float *d_cross, const float *d_diag, const float *d_omega,
+                           const uint8_t *d_mask, float *d_var, float *d_pmean, double *d_sum,
+                           int want, float *d_best_val, int64_t *d_best_idx);
+int apmf_mn_score_grid_f64(apmf_ctx *ctx, int B, int n, int m, int d, int ld,
+                           const double *d_mean, const double *d_cross, const double *d_diag,
+                           const double *d_omega, const uint8_t *d_mask, double *d_var,
+                           double *d_pmean, double *d_sum, int want, double *d_best_val,
+                           int64_t *d_best_idx);
+/* Arbitrary pool of candidates (what _get_key_vals iterates, mn_active_pmf.py:731-762):
+ * d_pi, d_pj (P) int32 -> d_pmean, d_var (P) float64, single state. */
+int apmf_mn_score_pool_f64(apmf_ctx *ctx, int n, int m, int d, int ld, const double *d_mean,
+                           const double *d_cross, const double *d_diag, const double *d_omega,
+                           const int32_t *d_pi, const int32_t *d_pj, int64_t P, double *d_pmean,
+                           double *d_var);
+/* After an f32 sweep: collect every candidate whose f32 score is within rel_tol of the
+ * extremum (d_var of one state as written by apmf_mn_score_grid_f32), up to cap entries,
+ * so the caller can re-score that short list in float64 (apmf_mn_score_pool_f64) and make
+ * the selection exact.  h_count receives the number found (may exceed cap). */
+int apmf_grid_collect_near_f32(apmf_ctx *ctx, int n, int m, int ld, const float *d_var,
+                               const uint8_t *d_mask, int want, float best, float rel_tol,
+                               int32_t *d_pi, int32_t *d_pj, int cap, int *h_count);
+
+/* ---- K2-full: same under the full-covariance Gaussian --------------------------------
+ * Replaces ActivePMF.approx_pred_mean_var / approx_pred_means_vars / pred_variance
+ * (active_pmf.py:301-322, 392-400, 502-524) + normal_exps_cy.exp_dotprod_sq
+ * (normal_exps_cy.pyx:111-135).  d_mean (K), d_cov (K, K) float64, K = (n+m)*d with the
+ * reference's index maps u[k,i] = i*d+k, v[k,j] = n*d + j*d + k (active_pmf.py:141-142). */
+int apmf_full_score_grid_f64(apmf_ctx *ctx, int n, int m, int d, int ld, const double *d_mean,
+                             const double *d_cov, const uint8_t *d_mask, double *d_var,
+                             double *d_pmean, double *d_sum, int want, double *d_best_val,
+                             int64_t *d_best_idx);
+
+/* ---- K3: Bayesian-PMF Gibbs row updates (bayes_pmf.py) --------------------------------
+ * One half-sweep of samples(), bayes_pmf.py:280-296 = `rows` independent sample_feature()
+ * calls (bayes_pmf.py:189-216): for each row t of the chosen side
+ *     F = oth[idx(t)],  cov = inv(alpha + beta F^T F),  mean = cov (beta F^T (r - mean_sub) + alpha mu)
+ *     out[t] = chol(cov) z[t] + mean                        (lower Cholesky of the covariance)
+ * side 0: rows = users, oth = item features (m, d); side 1: rows = items, oth = users.
+ * d_alpha (d,d), d_mu (d), d_z (rows, d) standard-normal draws made by the host RNG in the
+ * reference's order, d_out (rows, d).  A row with no rating -> APMF_EINVAL (the reference
+ * raises KeyError, bayes_pmf.py:287,296); a non-PD system -> APMF_ENOTPD. */
+int apmf_gibbs_half_sweep(apmf_ctx *ctx, const apmf_ratings *r, int side, const double *d_oth,
+                          int d, const double *d_alpha, const double *d_mu, double beta,
+                          double mean_sub, const double *d_z, double *d_out);
+
+/* ---- K4: statistics over S posterior samples (bayes_pmf.py:433-448, 528-538) -----------
+ * predict / pred_variance / prob_ge_cutoff: per (i, j) the mean, the variance (ddof 0) and
+ * the fraction >= cutoff of  U_s[i] . V_s[j] + add  over s < S.
+ * d_Us (S, n, d), d_Vs (S, m, d) float64; outputs (n, ld) float64, each may be NULL. */
+int apmf_sample_stats_f64(apmf_ctx *ctx, int S, int n, int m, int d, int ld, const double *d_Us,
+                          const double *d_Vs, double add, double cutoff, double *d_mean,
+                          double *d_var, double *d_prob);
+
+/* Gather (n, ld) grid entries at a pool of (i, j): d_out[p] = d_grid[pi[p]*ld + pj[p]]. */
+int apmf_grid_gather_f64(apmf_ctx *ctx, const double *d_grid, int ld, const int32_t *d_pi,
+                         const int32_t *d_pj, int64_t P, double *d_out);
+/* Arg-extremum of a pool vector with the reference's tie rule (first in pool order:
+ * python max()/min() over zip(pool, vals), mn_active_pmf.py:729; np.argmax, bayes_pmf.py:712). */
+int apmf_pool_argext_f64(apmf_ctx *ctx, const double *d_vals, int64_t P, int want,
+                         int64_t *h_pos, double *h_val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APMF_H */

@@ -1,0 +1,522 @@
+"""Parity of the HIP path (through the C-ABI, libapmf_hip.so) against the CPU oracle and the
+golden vectors produced by the real reference.  Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, c2_inputs
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from active_matrix_factorization_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _pmf_kw(g):
+    sig, sig_u, sig_v = (float(x) for x in g['sigma'])
+    return dict(sig=sig, sig_u=sig_u, sig_v=sig_v, subtract_mean=bool(g['subtract_mean']),
+                mean_rating=float(g['mean_rating']))
+
+
+def _grad(ctx, ratings, U, V, kw):
+    n, d = U.shape
+    m = V.shape[0]
+    rt = ctx.ratings(ratings, n, m)
+    dU, dV = ctx.array(U), ctx.array(V)
+    gU, gV = ctx.empty((n, d)), ctx.empty((m, d))
+    ctx.pmf_gradient(rt, dU, dV, d, kw['sig'], kw['sig_u'], kw['sig_v'], kw['subtract_mean'],
+                     kw['mean_rating'], gU, gV)
+    ll, sq = ctx.pmf_log_likelihood(rt, dU, dV, d, kw['sig'], kw['sig_u'], kw['sig_v'],
+                                    kw['subtract_mean'], kw['mean_rating'])
+    return gU.to_host(), gV.to_host(), ll, sq
+
+
+PMF_CASES = ['pmf_c1_10x10_d2', 'pmf_50x40_d3', 'pmf_50x40_d3_submean', 'pmf_30x70_d16']
+
+
+# ---------------------------------------------------------------------------- K1
+@pytest.mark.parametrize('name', PMF_CASES)
+def test_pmf_gradient_ll_golden(ctx, name):
+    g = load_golden(name)
+    kw = _pmf_kw(g)
+    gU, gV, ll, sq = _grad(ctx, g['ratings'], g['U0'], g['V0'], kw)
+    # float64, fixed summation tree; tolerance = reordering of <= a few hundred adds
+    np.testing.assert_allclose(gU, g['gU'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(gV, g['gV'], rtol=1e-12, atol=1e-12)
+    assert abs(ll - g['ll']) <= 1e-12 * abs(g['ll'])
+    assert abs(sq - orc.pmf_sq_error(g['ratings'], g['U0'], g['V0'], kw['subtract_mean'],
+                                     kw['mean_rating'])) <= 1e-12 * sq
+    # a minibatch slice (pmf_cy.pyx:335-336)
+    lo, hi = int(g['batch_lo']), int(g['batch_hi'])
+    gUb, gVb, _, _ = _grad(ctx, g['ratings'][lo:hi], g['U0'], g['V0'], kw)
+    np.testing.assert_allclose(gUb, g['gU_batch'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(gVb, g['gV_batch'], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('d', [1, 2, 5, 8, 10, 15, 16, 17, 33, 64])
+def test_pmf_gradient_all_d(ctx, d):
+    rs = np.random.RandomState(d)
+    n, m, N = 37, 29, 400
+    ii, jj = rs.randint(0, n, N), rs.randint(0, m, N)
+    ratings = np.column_stack([ii, jj, rs.normal(size=N)]).astype(float)
+    ratings[0, :2] = [n - 1, m - 1]
+    U, V = rs.normal(size=(n, d)), rs.normal(size=(m, d))
+    kw = dict(sig=0.8, sig_u=3., sig_v=5., subtract_mean=True, mean_rating=0.3)
+    gU, gV, ll, _ = _grad(ctx, ratings, U, V, kw)
+    oU, oV = orc.pmf_gradient(ratings, U, V, **kw)
+    np.testing.assert_allclose(gU, oU, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(gV, oV, rtol=1e-11, atol=1e-11)
+    assert abs(ll - orc.pmf_log_likelihood(ratings, U, V, **kw)) <= 1e-12 * abs(ll)
+
+
+def test_pmf_empty_rows_and_no_ratings(ctx):
+    # users/items without ratings only get the prior term (pmf_cy.pyx:214-215)
+    U, V = np.arange(12.).reshape(4, 3), np.arange(15.).reshape(5, 3) / 7
+    ratings = np.array([[1, 3, 2.5]])
+    kw = dict(sig=1., sig_u=10., sig_v=10., subtract_mean=False, mean_rating=0.)
+    gU, gV, ll, _ = _grad(ctx, ratings, U, V, kw)
+    oU, oV = orc.pmf_gradient(ratings, U, V, **kw)
+    np.testing.assert_allclose(gU, oU, rtol=1e-14, atol=1e-14)
+    np.testing.assert_allclose(gV, oV, rtol=1e-14, atol=1e-14)
+    gU, gV, ll, sq = _grad(ctx, np.zeros((0, 3)), U, V, kw)
+    np.testing.assert_allclose(gU, -U / 10., rtol=1e-15)
+    assert sq == 0.
+
+
+def test_pmf_bad_ratings(ctx):
+    with pytest.raises(ValueError):
+        ctx.ratings(np.array([[5, 0, 1.]]), 3, 3)
+    with pytest.raises(TypeError):
+        ctx.ratings(np.zeros((3, 2)), 3, 3)
+
+
+@pytest.mark.parametrize('name', PMF_CASES)
+def test_pmf_fit_lls_golden(ctx, name):
+    g = load_golden(name)
+    kw = _pmf_kw(g)
+    n, d = g['U0'].shape
+    m = g['V0'].shape[0]
+    rt = ctx.ratings(g['ratings'], n, m)
+    dU, dV = ctx.array(g['U0']), ctx.array(g['V0'])
+    trace, steps, lr, conv = ctx.pmf_fit_lls(rt, dU, dV, d, kw['sig'], kw['sig_u'], kw['sig_v'],
+                                             kw['subtract_mean'], kw['mean_rating'], 1e-4, 1e-10, 1e-2)
+    # same number of accepted steps = same accept/reject control flow as pmf_cy.pyx:265-291
+    assert steps == g['ll_trace'].size and conv
+    np.testing.assert_allclose(trace, g['ll_trace'], rtol=1e-10)
+    np.testing.assert_allclose(dU.to_host(), g['U_fit'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(dV.to_host(), g['V_fit'], rtol=1e-8, atol=1e-10)
+
+
+def test_pmf_fit_lls_resume(ctx):
+    """max_steps + returned lr let a caller drive the generator step by step (fit_lls yields)."""
+    g = load_golden('pmf_50x40_d3')
+    kw = _pmf_kw(g)
+    n, d = g['U0'].shape
+    m = g['V0'].shape[0]
+    rt = ctx.ratings(g['ratings'], n, m)
+    dU, dV = ctx.array(g['U0']), ctx.array(g['V0'])
+    lr, out, conv = 1e-4, [], False
+    while not conv and len(out) < 10000:
+        trace, steps, lr, conv = ctx.pmf_fit_lls(rt, dU, dV, d, kw['sig'], kw['sig_u'], kw['sig_v'],
+                                                 False, 0., lr, 1e-10, 1e-2, max_steps=7)
+        out.extend(trace)
+    assert len(out) == g['ll_trace'].size
+    np.testing.assert_allclose(out, g['ll_trace'], rtol=1e-10)
+
+
+def test_pmf_headline_shape(ctx):
+    g = load_golden('pmf_c2_943x1682_d10')
+    ratings, U0, V0 = c2_inputs()
+    kw = dict(sig=1., sig_u=10., sig_v=10., subtract_mean=False, mean_rating=0.)
+    gU, gV, ll, _ = _grad(ctx, ratings, U0, V0, kw)
+    np.testing.assert_allclose(gU, g['gU'], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(gV, g['gV'], rtol=1e-11, atol=1e-11)
+    assert abs(ll - g['ll']) <= 1e-12 * abs(g['ll'])
+    # run-to-run bit reproducibility (fixed summation tree, no atomics)
+    gU2, gV2, ll2, _ = _grad(ctx, ratings, U0, V0, kw)
+    assert np.array_equal(gU, gU2) and np.array_equal(gV, gV2) and ll == ll2
+
+
+def test_pmf_minibatch_epoch(ctx):
+    rs = np.random.RandomState(5)
+    n, m, d, N, bs = 23, 31, 6, 500, 64
+    ratings = np.column_stack([rs.randint(0, n, N), rs.randint(0, m, N), rs.normal(size=N)]).astype(float)
+    U, V = rs.normal(size=(n, d)), rs.normal(size=(m, d))
+    ui, vi = rs.normal(size=(n, d)) * .01, rs.normal(size=(m, d)) * .01
+    kw = dict(sig=1., sig_u=10., sig_v=10., subtract_mean=False, mean_rating=0.)
+    dU, dV, dui, dvi = ctx.array(U), ctx.array(V), ctx.array(ui), ctx.array(vi)
+    ctx.pmf_minibatch_epoch(ratings, n, m, bs, 1.0, .8, dU, dV, dui, dvi, d, 1., 10., 10., False, 0.)
+    # reference recipe, pmf_cy.pyx:329-344 (float lr / int n, float momentum)
+    mom = float(np.float32(.8))
+    for s in range(0, N, bs):
+        b = ratings[s:s + bs]
+        gU, gV = orc.pmf_gradient(b, U, V, **kw)
+        sc = float(np.float32(1.0) / np.float32(b.shape[0]))
+        ui = ui * mom + gU * sc
+        U = U + ui
+        vi = vi * mom + gV * sc
+        V = V + vi
+    np.testing.assert_allclose(dU.to_host(), U, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(dV.to_host(), V, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(dui.to_host(), ui, rtol=1e-11, atol=1e-12)
+
+
+def test_predicted_matrix(ctx):
+    g = load_golden('pmf_50x40_d3_submean')
+    n, d = g['U0'].shape
+    m = g['V0'].shape[0]
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld = grid_ld(m)
+    out = ctx.empty((n, ld))
+    ctx.pmf_predicted_matrix(ctx.array(g['U0']), ctx.array(g['V0']), n, m, d, float(g['mean_rating']),
+                             out, ld)
+    np.testing.assert_allclose(ctx.download_grid(out, m), g['pred0'], rtol=1e-13, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------- K2 (matrix normal)
+def _mn_state(ctx, mean, R, Om, dtype, n, m):
+    cross = ctx.upload_grid(R[:n, n:], dtype)
+    return (ctx.array(mean, dtype), cross, ctx.array(np.diag(R).copy(), dtype), ctx.array(Om, dtype),
+            cross.shape[1])
+
+
+def _mn_run(ctx, mean, R, Om, n, m, dtype, mask=None, want=1):
+    d = mean.shape[1]
+    dm, dc, dd, do, ld = _mn_state(ctx, mean, R, Om, dtype, n, m)
+    var, pm = ctx.empty((n, ld), dtype), ctx.empty((n, ld), dtype)
+    dsum, bv, bi = ctx.empty(1, np.float64), ctx.empty(1, dtype), ctx.empty(1, np.int64)
+    dmask = None
+    if mask is not None:
+        dmask = ctx.upload_grid(mask.astype(np.uint8), np.uint8, ld=ld)
+    ctx.mn_score_grid(dtype, 1, n, m, d, ld, dm, dc, dd, do, mask=dmask, var=var, pmean=pm, dsum=dsum,
+                      want=want, best_val=bv, best_idx=bi)
+    return (ctx.download_grid(var, m), ctx.download_grid(pm, m), dsum.to_host()[0], bv.to_host()[0],
+            int(bi.to_host()[0]))
+
+
+MN_CASES = ['mn_c1_10x10_d2_eye', 'mn_c1_10x10_d2_rand', 'mn_24x17_d5_rand', 'mn_12x20_d10_rand']
+
+
+@pytest.mark.parametrize('name', MN_CASES)
+def test_mn_grid_f64_golden(ctx, name):
+    g = load_golden(name)
+    n, m = g['p_mean'].shape
+    mask = np.zeros((n, m), bool)
+    mask[tuple(g['pool'].T)] = True
+    var, pm, tot, bv, bi = _mn_run(ctx, g['mean'], g['cov_useritems'], g['cov_latents'], n, m,
+                                   np.float64, mask=mask)
+    # The reference forms E[(u.v)^2] - mean^2 (mn_active_pmf.py:311-315): its own rounding
+    # floor is a few eps * E2.  The closed form evaluated here has no cancellation.
+    scale = np.abs(g['e2'])
+    assert np.all(np.abs(var - g['p_var']) <= 64 * EPS * scale)
+    assert np.all(np.abs(pm - g['p_mean']) <= 64 * EPS * (np.abs(g['p_mean']) + np.sqrt(scale)))
+    # the reference's selection: first max over the unrated pool (mn_active_pmf.py:728-729)
+    assert (bi // m, bi % m) == tuple(g['pick_max'])
+    assert abs(bv - g['pool_vals'].max()) <= 64 * EPS * scale.max()
+    assert abs(tot - g['pool_vals'].sum()) <= 1e-12 * abs(g['pool_vals'].sum())
+    # no mask -> _total_variance over the whole grid (mn_active_pmf.py:597-598)
+    _, _, tot_all, _, _ = _mn_run(ctx, g['mean'], g['cov_useritems'], g['cov_latents'], n, m,
+                                  np.float64)
+    assert abs(tot_all - g['total_variance']) <= 1e-12 * abs(g['total_variance'])
+
+
+@pytest.mark.parametrize('name', MN_CASES)
+def test_mn_grid_f32_golden(ctx, name):
+    g = load_golden(name)
+    n, m = g['p_mean'].shape
+    mask = np.zeros((n, m), bool)
+    mask[tuple(g['pool'].T)] = True
+    var, pm, tot, bv, bi = _mn_run(ctx, g['mean'], g['cov_useritems'], g['cov_latents'], n, m,
+                                   np.float32, mask=mask)
+    # stated f32 tolerance: 1e-5 relative to the magnitude of the terms being summed
+    scale = np.abs(g['e2'])
+    assert np.all(np.abs(var - g['p_var']) <= 1e-5 * np.maximum(scale, np.abs(g['p_var'])))
+    assert np.all(np.abs(pm - g['p_mean']) <= 1e-5 * (np.abs(g['p_mean']) + np.sqrt(scale)))
+    assert abs(tot - g['pool_vals'].sum()) <= 1e-5 * abs(g['pool_vals'].sum())
+    # exact selection = f32 sweep + f64 re-score of the near-extremum short list
+    i, j = bi // m, bi % m
+    best_ref = g['pool_vals'].max()
+    assert g['p_var'][i, j] >= best_ref - 1e-5 * abs(best_ref)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('shape', [(1, 1, 1), (3, 63, 2), (5, 64, 3), (7, 65, 4), (64, 257, 10),
+                                   (65, 300, 15), (130, 70, 16), (9, 40, 24), (11, 33, 32),
+                                   (6, 130, 47), (4, 20, 64)])
+def test_mn_grid_shapes_vs_oracle(ctx, dtype, shape):
+    n, m, d = shape
+    rs = np.random.RandomState(n * 1000 + m + d)
+    mean = rs.normal(size=(n + m, d))
+    a = rs.normal(size=(n + m, n + m)) / np.sqrt(n + m)
+    R = a @ a.T + 0.1 * np.eye(n + m)
+    b = rs.normal(size=(d, d)) / np.sqrt(d)
+    Om = b @ b.T + 0.1 * np.eye(d)
+    mask = rs.rand(n, m) < 0.7
+    mask[0, 0] = True
+    for want in (1, -1):
+        var, pm, tot, bv, bi = _mn_run(ctx, mean, R, Om, n, m, dtype, mask=mask, want=want)
+        opm, opv, oe2 = orc.mn_pred_means_vars(n, m, mean, R, Om, want_e2=True)
+        tol = 1e-5 if dtype == np.float32 else 1e-12
+        scale = np.maximum(np.abs(oe2), np.abs(opv))
+        assert np.all(np.abs(var - opv) <= tol * scale)
+        assert np.all(np.abs(pm - opm) <= tol * (np.abs(opm) + np.sqrt(scale)))
+        assert abs(tot - opv[mask].sum()) <= tol * np.abs(opv[mask]).sum()
+        cand = np.where(mask, opv, -np.inf if want > 0 else np.inf)
+        ref = cand.max() if want > 0 else cand.min()
+        i, j = bi // m, bi % m
+        assert mask[i, j]
+        assert abs(opv[i, j] - ref) <= 2 * tol * scale.max()
+        if dtype == np.float64:
+            flat = int(np.argmax(cand)) if want > 0 else int(np.argmin(cand))
+            assert bi == flat or abs(opv[i, j] - ref) <= 64 * EPS * scale.max()
+
+
+def test_mn_grid_batched_states(ctx):
+    """B posterior states per launch == B single launches (what the lookahead batches)."""
+    rs = np.random.RandomState(3)
+    B, n, m, d = 5, 33, 70, 10
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld = grid_ld(m)
+    means = rs.normal(size=(B, n + m, d))
+    cross = np.zeros((B, n, ld))
+    cross[:, :, :m] = rs.normal(size=(B, n, m)) * .1
+    diag = rs.rand(B, n + m) + .5
+    om = np.array([(lambda x: x @ x.T / d + .1 * np.eye(d))(rs.normal(size=(d, d))) for _ in range(B)])
+    for dtype in (np.float32, np.float64):
+        dm, dc, dd, do = (ctx.array(x, dtype) for x in (means, cross, diag, om))
+        var = ctx.empty((B, n, ld), dtype)
+        dsum, bv, bi = ctx.empty(B, np.float64), ctx.empty(B, dtype), ctx.empty(B, np.int64)
+        ctx.mn_score_grid(dtype, B, n, m, d, ld, dm, dc, dd, do, var=var, dsum=dsum, want=-1,
+                          best_val=bv, best_idx=bi)
+        v = ctx.download_grid(var, m)
+        sums, bis = dsum.to_host(), bi.to_host()
+        for b in range(B):
+            R = np.zeros((n + m, n + m))
+            R[np.arange(n + m), np.arange(n + m)] = diag[b]
+            R[:n, n:] = cross[b, :, :m]
+            R[n:, :n] = cross[b, :, :m].T
+            _, opv = orc.mn_pred_means_vars(n, m, means[b], R, om[b])
+            tol = 1e-5 if dtype == np.float32 else 1e-12
+            assert np.all(np.abs(v[b] - opv) <= tol * np.abs(opv).max())
+            assert abs(sums[b] - opv.sum()) <= tol * np.abs(opv).sum()
+            i, j = int(bis[b]) // m, int(bis[b]) % m
+            assert abs(opv[i, j] - opv.min()) <= 2 * tol * np.abs(opv).max()
+
+
+def test_mn_pool_and_exact_selection(ctx):
+    """f32 sweep -> near-extremum short list -> f64 re-score = the f64 argmax (exact index)."""
+    g = load_golden('mn_24x17_d5_rand')
+    n, m = g['p_mean'].shape
+    d = int(g['d'])
+    R, Om, mean = g['cov_useritems'], g['cov_latents'], g['mean']
+    mask = np.zeros((n, m), bool)
+    mask[tuple(g['pool'].T)] = True
+    dm, dc, dd, do, ld = _mn_state(ctx, mean, R, Om, np.float32, n, m)
+    dmask = ctx.upload_grid(mask.astype(np.uint8), np.uint8, ld=ld)
+    var, bv, bi = ctx.empty((n, ld), np.float32), ctx.empty(1, np.float32), ctx.empty(1, np.int64)
+    ctx.mn_score_grid(np.float32, 1, n, m, d, ld, dm, dc, dd, do, mask=dmask, var=var, want=1,
+                      best_val=bv, best_idx=bi)
+    cap = 64
+    pi, pj = ctx.empty(cap, np.int32), ctx.empty(cap, np.int32)
+    cnt = ctx.grid_collect_near(n, m, ld, var, dmask, 1, float(bv.to_host()[0]), 1e-4, pi, pj, cap)
+    assert 1 <= cnt <= cap
+    dm64, dc64, dd64, do64, _ = _mn_state(ctx, mean, R, Om, np.float64, n, m)
+    pm, pv = ctx.empty(cnt), ctx.empty(cnt)
+    ctx.mn_score_pool(n, m, d, ld, dm64, dc64, dd64, do64, pi, pj, cnt, pm, pv)
+    ii, jj, vals = pi.to_host()[:cnt], pj.to_host()[:cnt], pv.to_host()
+    k = int(np.argmax(vals))
+    assert (int(ii[k]), int(jj[k])) == tuple(g['pick_max'])
+    scale = np.abs(g['e2']).max()
+    assert np.all(np.abs(vals - g['p_var'][ii, jj]) <= 64 * EPS * scale)
+    # whole pool through the pool kernel, in the reference's pool order; first-max tie rule
+    P = g['pool'].shape[0]
+    dpi, dpj = ctx.array(g['pool'][:, 0], np.int32), ctx.array(g['pool'][:, 1], np.int32)
+    pm, pv = ctx.empty(P), ctx.empty(P)
+    ctx.mn_score_pool(n, m, d, ld, dm64, dc64, dd64, do64, dpi, dpj, P, pm, pv)
+    np.testing.assert_allclose(pv.to_host(), g['pool_vals'], rtol=0, atol=64 * EPS * scale)
+    pos, val = ctx.pool_argext(pv, P, 1)
+    assert tuple(g['pool'][pos]) == tuple(g['pick_max'])
+
+
+def test_pool_argext_tie_rule(ctx):
+    v = np.array([1., 5., 3., 5., -2., -2., np.nan, 5.])
+    d = ctx.array(v)
+    assert ctx.pool_argext(d, v.size, 1)[0] == 1      # first max, like python max()/np.argmax
+    assert ctx.pool_argext(d, v.size, -1)[0] == 4     # first min
+    big = np.zeros(300000)
+    big[[123456, 250000]] = 7.
+    assert ctx.pool_argext(ctx.array(big), big.size, 1)[0] == 123456
+    with pytest.raises(ValueError):                   # empty pool: mn_active_pmf.py:723-724
+        ctx.pool_argext(d, 0, 1)
+
+
+def test_grid_gather(ctx):
+    rs = np.random.RandomState(0)
+    n, m = 13, 70
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld = grid_ld(m)
+    host = rs.normal(size=(n, m))
+    g = ctx.upload_grid(host)
+    pi, pj = rs.randint(0, n, 500).astype(np.int32), rs.randint(0, m, 500).astype(np.int32)
+    out = ctx.empty(500)
+    ctx.grid_gather(g, ld, ctx.array(pi), ctx.array(pj), 500, out)
+    np.testing.assert_array_equal(out.to_host(), host[pi, pj])
+
+
+def test_mn_grid_headline_size_properties(ctx):
+    """943 x 1682, d = 10: f32 sweep vs f64 sweep of the same state, fused reductions vs the
+    written grid (size-independent properties; the oracle would take minutes here)."""
+    rs = np.random.RandomState(11)
+    n, m, d, B = 943, 1682, 10, 3
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld = grid_ld(m)
+    means = rs.normal(0, 1, (B, n + m, d))
+    cross = np.zeros((B, n, ld))
+    cross[:, :, :m] = rs.normal(0, .05, (B, n, m))
+    diag = rs.rand(B, n + m) + .5
+    om = np.array([(lambda x: x @ x.T / d + .1 * np.eye(d))(rs.normal(size=(d, d))) for _ in range(B)])
+    mask = rs.rand(n, m) < 0.9
+    dmask = ctx.upload_grid(mask.astype(np.uint8), np.uint8, ld=ld)
+    res = {}
+    for dtype in (np.float32, np.float64):
+        dm, dc, dd, do = (ctx.array(x, dtype) for x in (means, cross, diag, om))
+        var = ctx.empty((B, n, ld), dtype)
+        dsum, bv, bi = ctx.empty(B, np.float64), ctx.empty(B, dtype), ctx.empty(B, np.int64)
+        ctx.mn_score_grid(dtype, B, n, m, d, ld, dm, dc, dd, do, mask=dmask, var=var, dsum=dsum,
+                          want=1, best_val=bv, best_idx=bi)
+        res[dtype] = (ctx.download_grid(var, m), dsum.to_host(), bv.to_host(), bi.to_host())
+    v32, s32, b32, i32 = res[np.float32]
+    v64, s64, b64, i64 = res[np.float64]
+    assert np.all(np.abs(v32 - v64) <= 1e-5 * np.abs(v64).max())
+    for b in range(B):
+        cand = np.where(mask, v64[b], -np.inf)
+        assert int(i64[b]) == int(np.argmax(cand))             # first max, flat order
+        assert b64[b] == cand.max()
+        assert abs(s64[b] - v64[b][mask].sum()) <= 1e-12 * v64[b][mask].sum()
+        assert abs(s32[b] - s64[b]) <= 1e-5 * s64[b]
+        assert cand.ravel()[int(i32[b])] >= cand.max() * (1 - 1e-5)
+    # spot-check a few rows against the oracle
+    b = 1
+    R = np.zeros((n + m, n + m))
+    R[np.arange(n + m), np.arange(n + m)] = diag[b]
+    R[:n, n:] = cross[b, :, :m]
+    R[n:, :n] = cross[b, :, :m].T
+    ov = orc.mn_score_rows(n, m, means[b], R, om[b], 500, 503)
+    assert np.all(np.abs(v64[b][500:503] - ov) <= 1e-11 * np.abs(ov).max())
+
+
+# ---------------------------------------------------------------------------- K2-full
+@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
+def test_full_grid_golden(ctx, name):
+    g = load_golden(name)
+    n, m = g['p_mean'].shape
+    d = int(g['d'])
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld = grid_ld(m)
+    mask = np.zeros((n, m), bool)
+    mask[tuple(g['pool'].T)] = True
+    dmask = ctx.upload_grid(mask.astype(np.uint8), np.uint8, ld=ld)
+    var, pm = ctx.empty((n, ld)), ctx.empty((n, ld))
+    dsum, bv, bi = ctx.empty(1), ctx.empty(1), ctx.empty(1, np.int64)
+    ctx.full_score_grid(n, m, d, ld, ctx.array(g['mean']), ctx.array(g['cov']), mask=dmask, var=var,
+                        pmean=pm, dsum=dsum, want=1, best_val=bv, best_idx=bi)
+    _, _, e2 = orc.full_pred_means_vars(n, m, d, g['mean'], g['cov'], want_e2=True)
+    v, p = ctx.download_grid(var, m), ctx.download_grid(pm, m)
+    assert np.all(np.abs(v - g['p_var']) <= 256 * EPS * np.abs(e2))
+    assert np.all(np.abs(p - g['p_mean']) <= 256 * EPS * (np.abs(g['p_mean']) + np.sqrt(np.abs(e2))))
+    b = int(bi.to_host()[0])
+    assert (b // m, b % m) == tuple(g['pick_max'])
+    assert abs(dsum.to_host()[0] - g['pool_vals'].sum()) <= 1e-11 * abs(g['pool_vals'].sum())
+
+
+# ---------------------------------------------------------------------------- K3 / K4
+BAYES_CASES = ['bayes_20x15_d4', 'bayes_c1_10x10_d2', 'bayes_100x90_d15']
+
+
+@pytest.mark.parametrize('name', BAYES_CASES)
+def test_gibbs_half_sweep(ctx, name):
+    g = load_golden(name)
+    n, d = g['users'].shape
+    m = g['items'].shape[0]
+    sub = float(g['mean_rating']) if int(g['subtract_mean']) else 0.
+    rt = ctx.ratings(g['ratings'], n, m)
+    rs = np.random.RandomState(1)
+    for side, rows, oth in ((0, n, g['items']), (1, m, g['users'])):
+        z = rs.normal(size=(rows, d))
+        out = ctx.empty((rows, d))
+        ctx.gibbs_half_sweep(rt, side, ctx.array(oth), d, ctx.array(g['sf_alpha']),
+                             ctx.array(g['sf_mu']), 2.0, sub, ctx.array(z), out)
+        ptr, idx, rat = orc.csr_by_row(g['ratings'], side, rows)
+        ref = orc.gibbs_half_sweep(ptr, idx, rat, oth, g['sf_alpha'], g['sf_mu'], 2.0, sub, z)
+        # Cholesky-based inverse here vs LU in numpy/the oracle: rounding only
+        np.testing.assert_allclose(out.to_host(), ref, rtol=1e-9, atol=1e-11)
+    # the recorded sample_feature call of the reference (bayes_pmf.py:189-216), user 0
+    z = np.zeros((n, d))
+    z[0] = g['sf_z']
+    out = ctx.empty((n, d))
+    ctx.gibbs_half_sweep(rt, 0, ctx.array(g['items']), d, ctx.array(g['sf_alpha']), ctx.array(g['sf_mu']),
+                         2.0, sub, ctx.array(z), out)
+    np.testing.assert_allclose(out.to_host()[0], g['sf_out'], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize('d', [1, 3, 10, 11, 22, 23, 32, 33, 46, 47, 64])
+def test_gibbs_all_d(ctx, d):
+    rs = np.random.RandomState(d)
+    n, m, N = 9, 12, 150
+    ii = np.concatenate([np.arange(n), rs.randint(0, n, N)])   # every user has >= 1 rating
+    jj = rs.randint(0, m, ii.size)
+    ratings = np.column_stack([ii, jj, rs.normal(size=ii.size)]).astype(float)
+    items = rs.normal(size=(m, d))
+    a = rs.normal(size=(d, d))
+    alpha, mu, z = a @ a.T / d + np.eye(d), rs.normal(size=d), rs.normal(size=(n, d))
+    rt = ctx.ratings(ratings, n, m)
+    out = ctx.empty((n, d))
+    ctx.gibbs_half_sweep(rt, 0, ctx.array(items), d, ctx.array(alpha), ctx.array(mu), 2.0, 0.1,
+                         ctx.array(z), out)
+    ptr, idx, rat = orc.csr_by_row(ratings, 0, n)
+    ref = orc.gibbs_half_sweep(ptr, idx, rat, items, alpha, mu, 2.0, 0.1, z)
+    np.testing.assert_allclose(out.to_host(), ref, rtol=1e-8, atol=1e-10)
+
+
+def test_gibbs_errors(ctx):
+    ratings = np.array([[0, 0, 1.], [1, 0, 2.]])
+    rt = ctx.ratings(ratings, 3, 1)       # user 2 has no rating: KeyError in bayes_pmf.py:287
+    d = 2
+    args = (ctx.array(np.ones((1, d))), d, ctx.array(np.eye(d)), ctx.array(np.zeros(d)), 2.0, 0.,
+            ctx.array(np.zeros((3, d))), ctx.empty((3, d)))
+    with pytest.raises(ValueError):
+        ctx.gibbs_half_sweep(rt, 0, *args)
+    rt2 = ctx.ratings(ratings, 2, 1)
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.gibbs_half_sweep(rt2, 0, ctx.array(np.ones((1, d))), d, ctx.array(-5 * np.eye(d)),
+                             ctx.array(np.zeros(d)), 2.0, 0., ctx.array(np.zeros((2, d))),
+                             ctx.empty((2, d)))
+
+
+@pytest.mark.parametrize('name', BAYES_CASES)
+def test_sample_stats_golden(ctx, name):
+    g = load_golden(name)
+    S, n, d = g['chain_U'].shape
+    m = g['chain_V'].shape[1]
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld = grid_ld(m)
+    add = float(g['mean_rating']) if int(g['subtract_mean']) else 0.
+    mean, var, prob = ctx.empty((n, ld)), ctx.empty((n, ld)), ctx.empty((n, ld))
+    dU, dV = ctx.array(g['chain_U']), ctx.array(g['chain_V'])
+    ctx.sample_stats(S, n, m, d, ld, dU, dV, add, 3.5, mean=mean, var=var, prob=prob)
+    mu, v, p = (ctx.download_grid(x, m) for x in (mean, var, prob))
+    np.testing.assert_allclose(mu, g['predict_full'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(v, g['pred_variance_full'], rtol=1e-9, atol=1e-12)
+    which = tuple(g['which'])
+    np.testing.assert_array_equal(p[which], g['prob_ge'])
+    # selection as bayes_pmf.full_test does it: np.argmax over the unrated list (bayes_pmf.py:702-712)
+    assert tuple(g['which'][:, np.argmax(v[which])]) == tuple(g['pick_argmax'])
+    ctx.sample_stats(S, n, m, d, ld, dU, dV, add, 0.5, prob=prob)
+    np.testing.assert_array_equal(ctx.download_grid(prob, m), g['prob_ge_full'])
