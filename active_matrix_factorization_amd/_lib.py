@@ -43,6 +43,8 @@ _SIGS = {
     'apmf_ctx_set_stream': (_i, [_vp, _vp]),
     'apmf_ctx_sync': (_i, [_vp]),
     'apmf_grid_ld': (_i, [_i]),
+    'apmf_profile_begin': (_i, [_vp, _i]),
+    'apmf_profile_end': (_i, [_vp, _vp, _i, C.POINTER(_i)]),
     'apmf_malloc': (_i, [_vp, _sz, C.POINTER(_vp)]),
     'apmf_free': (_i, [_vp, _vp]),
     'apmf_memset': (_i, [_vp, _vp, _i, _sz]),
@@ -239,6 +241,15 @@ class Context(object):
 
     def set_stream(self, hip_stream):
         _check(self._lib.apmf_ctx_set_stream(self._h, hip_stream))
+
+    def profile_begin(self, max_records=256):
+        _check(self._lib.apmf_profile_begin(self._h, max_records))
+
+    def profile_end(self, cap=4096):
+        ms = np.zeros(cap, np.float32)
+        cnt = _i(0)
+        _check(self._lib.apmf_profile_end(self._h, ms.ctypes.data, cap, C.byref(cnt)))
+        return ms[:min(cnt.value, cap)].astype(np.float64)
 
     def empty(self, shape, dtype=np.float64):
         return DeviceArray(self, shape, dtype)

@@ -21,6 +21,26 @@ struct apmf_ctx {
     void *pinned;
     size_t pinned_bytes;
     int num_cu;
+    // optional event pairs around the dominant kernels (apmf_profile_begin/end)
+    hipEvent_t *prof_ev;   // 2 * prof_cap events
+    int prof_cap, prof_n;
+};
+
+// bracket a kernel launch with events when profiling is on
+struct ProfScope {
+    apmf_ctx *c;
+    int slot;
+    explicit ProfScope(apmf_ctx *ctx) : c(ctx), slot(-1)
+    {
+        if (c->prof_ev && c->prof_n < c->prof_cap) {
+            slot = c->prof_n++;
+            (void)hipEventRecord(c->prof_ev[2 * slot], c->stream);
+        }
+    }
+    ~ProfScope()
+    {
+        if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], c->stream);
+    }
 };
 
 // device-resident ratings: CSR by user (index 0) and by item (index 1), stable order

@@ -1,5 +1,6 @@
 // ctx.hip - context, memory and stream plumbing of the C-ABI (include/apmf.h).
 #include <stdarg.h>
+#include <new>
 
 #include "common.h"
 
@@ -79,6 +80,10 @@ int apmf_ctx_destroy(apmf_ctx *ctx)
     for (int i = 0; i < 4; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->prof_ev) {
+        for (int i = 0; i < 2 * ctx->prof_cap; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
+        delete[] ctx->prof_ev;
+    }
     (void)hipStreamDestroy(ctx->own);
     delete ctx;
     return APMF_OK;
@@ -95,6 +100,42 @@ int apmf_ctx_sync(apmf_ctx *ctx)
 {
     APMF_REQUIRE(ctx, "ctx is NULL");
     APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return APMF_OK;
+}
+
+int apmf_profile_begin(apmf_ctx *ctx, int max_records)
+{
+    APMF_REQUIRE(ctx && max_records >= 1 && max_records <= 4096, "bad profile request");
+    if (ctx->prof_ev) {
+        for (int i = 0; i < 2 * ctx->prof_cap; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
+        delete[] ctx->prof_ev;
+        ctx->prof_ev = nullptr;
+    }
+    ctx->prof_ev = new (std::nothrow) hipEvent_t[2 * (size_t)max_records];
+    if (!ctx->prof_ev) { apmf_set_error("out of host memory"); return APMF_ENOMEM; }
+    for (int i = 0; i < 2 * max_records; i++) APMF_CHECK_HIP(hipEventCreate(&ctx->prof_ev[i]));
+    ctx->prof_cap = max_records;
+    ctx->prof_n = 0;
+    return APMF_OK;
+}
+
+int apmf_profile_end(apmf_ctx *ctx, float *h_ms, int cap, int *h_count)
+{
+    APMF_REQUIRE(ctx && h_count, "NULL operand");
+    *h_count = 0;
+    if (!ctx->prof_ev) return APMF_OK;
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    const int n = ctx->prof_n;
+    for (int i = 0; i < n && i < cap; i++) {
+        float ms = 0.f;
+        APMF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        if (h_ms) h_ms[i] = ms;
+    }
+    *h_count = n;
+    for (int i = 0; i < 2 * ctx->prof_cap; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
+    delete[] ctx->prof_ev;
+    ctx->prof_ev = nullptr;
+    ctx->prof_cap = ctx->prof_n = 0;
     return APMF_OK;
 }
 

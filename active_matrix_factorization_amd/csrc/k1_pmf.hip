@@ -324,6 +324,7 @@ int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const 
 {
     const int rows = r->n + r->m;
     const int blocks = (rows + 3) / 4;
+    ProfScope prof(ctx);
     DISPATCH_DP(dp_for(p.d),
                 hipLaunchKernelGGL((k_pmf_grad<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p, r->order,
                                    r->ptr[0], r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1],

@@ -444,7 +444,11 @@ int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_
 
     a.cross = d_cross; a.rowpack = rowpack; a.colpack = colpack; a.state = state;
     a.mask = d_mask; a.var = d_var; a.pmean = d_pmean; a.g.want = want; a.g.want_sum = d_sum != nullptr;
-    int rc = dispatch_grid<T>(a, D, ctx->stream);
+    int rc;
+    {
+        ProfScope prof(ctx);
+        rc = dispatch_grid<T>(a, D, ctx->stream);
+    }
     if (rc != APMF_OK) { apmf_set_error("no kernel for padded latent_d=%d", D); return rc; }
     APMF_CHECK_LAUNCH();
     if (want != 0 || d_sum) {

@@ -60,6 +60,13 @@ int apmf_ctx_set_stream(apmf_ctx *ctx, void *hip_stream);
 int apmf_ctx_sync(apmf_ctx *ctx);
 int apmf_grid_ld(int m); /* m rounded up to APMF_GRID_ALIGN */
 
+/* In-library timing of the dominant kernel of each instrumented entry point (the sweep
+ * kernel of apmf_mn_score_grid_*, the gradient kernel of apmf_pmf_gradient/fit_lls): between
+ * begin and end every such launch is bracketed by a pair of HIP events on the ctx stream,
+ * up to max_records launches.  end() synchronises and returns the durations in ms. */
+int apmf_profile_begin(apmf_ctx *ctx, int max_records);
+int apmf_profile_end(apmf_ctx *ctx, float *h_ms, int cap, int *h_count);
+
 int apmf_malloc(apmf_ctx *ctx, size_t bytes, void **d_out);
 int apmf_free(apmf_ctx *ctx, void *d_ptr);
 int apmf_memset(apmf_ctx *ctx, void *d_ptr, int value, size_t bytes);
