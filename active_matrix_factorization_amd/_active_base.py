@@ -1,0 +1,542 @@
+"""Machinery shared by the two variational active-PMF classes (MNActivePMF: matrix-normal
+posterior, ActivePMF: full-covariance Gaussian).
+
+The reference keeps two near-identical 1 100-line modules (mn_active_pmf.py, active_pmf.py).
+Here everything that does not depend on the shape of the posterior lives once in
+`_ActiveBase`: the criterion decorators, the selection surface (pick_query_point,
+_get_key_vals, get_key_evals), the one-step lookahead integrator and the experiment loop.
+What differs - how a pool of candidates is scored on the GPU and how the approximation is
+fitted - is supplied by the subclass.
+
+GPU note ("fork + HIP"): criteria are evaluated in the calling process.
+A `worker_pool` / `procs` argument is accepted for signature compatibility and ignored -
+a HIP context does not survive fork(), and one batched kernel launch replaces the whole
+map over the pool anyway.
+"""
+import itertools
+import math
+import operator
+import random
+import warnings
+from copy import deepcopy
+
+import numpy as np
+import scipy.linalg
+from scipy import stats
+
+from .pmf_cy import ProbabilisticMatrixFactorization
+
+
+# ---------------------------------------------------------------------------- helpers
+def project_psd(mat, min_eig=0, destroy=False):
+    '''Symmetrise, then clip the spectrum at min_eig (mn_active_pmf.py:42-67,
+    active_pmf.py:36-50).  `destroy` allows working in place.'''
+    if not destroy:
+        mat = mat.copy()
+    mat += mat.T
+    mat /= 2
+    vals, vecs = scipy.linalg.eigh(mat)
+    if vals.min() < min_eig:
+        mat = np.dot(vecs, np.dot(np.diag(np.maximum(vals, min_eig)), vecs.T))
+        mat += mat.T
+        mat /= 2
+    return mat
+
+
+def strictmap(*args, **kwargs):
+    return list(map(*args, **kwargs))
+
+
+class _Evaluator(object):
+    """Picklable `key(ij)` callable (the reference's *Evaluator classes)."""
+
+    def __init__(self, model, key):
+        self.model = model
+        self.key_name = key.__name__
+
+    def __call__(self, ij):
+        fn = getattr(self.model, self.key_name)
+        try:
+            return fn(ij)
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            raise
+
+
+# criterion metadata (mn_active_pmf.py:90-113)
+def do_normal_fit(val):
+    def decorator(f):
+        f.do_normal_fit = val
+        return f
+    return decorator
+
+
+def spawn_processes(val):
+    def decorator(f):
+        f.spawn_processes = val
+        return f
+    return decorator
+
+
+def nice_name(name):
+    def decorator(f):
+        f.nice_name = name
+        return f
+    return decorator
+
+
+def minimize(f):
+    f.chooser = min
+    return f
+
+
+def maximize(f):
+    f.chooser = max
+    return f
+
+
+def batched(method_name):
+    """Marks a criterion whose values for a whole pool come from one GPU launch:
+    `method_name(self, pi, pj) -> float64 array`."""
+    def decorator(f):
+        f.batched = method_name
+        return f
+    return decorator
+
+
+def _criterion(name, fit, spawn, chooser=maximize, batch=None):
+    def wrapper(f):
+        do_normal_fit(fit)(f)
+        spawn_processes(spawn)(f)
+        chooser(f)
+        nice_name(name)(f)
+        if batch:
+            batched(batch)(f)
+        return f
+    return wrapper
+
+
+def _pool_arrays(pool):
+    pool = pool if isinstance(pool, list) else list(pool)
+    if not pool:
+        return pool, np.zeros(0, np.int32), np.zeros(0, np.int32)
+    arr = np.asarray(pool)
+    return pool, np.ascontiguousarray(arr[:, 0], np.int32), np.ascontiguousarray(arr[:, 1], np.int32)
+
+
+# ---------------------------------------------------------------------------- the base class
+class _ActiveBase(ProbabilisticMatrixFactorization):
+    """Active-learning surface of the reference's (MN)ActivePMF, posterior-agnostic."""
+
+    def __init__(self, rating_tuples, latent_d=1, rating_values=None,
+                 discrete_expectations=False, refit_lookahead=False, knowable=None,
+                 fit_type=('batch',)):
+        super(_ActiveBase, self).__init__(rating_tuples, latent_d=latent_d, subtract_mean=False,
+                                          knowable=knowable, fit_type=fit_type)
+        self.ratings = np.asarray(self.ratings, dtype=float)
+        if rating_values is not None:
+            rating_values = set(map(float, rating_values))
+            if not rating_values.issuperset(self.ratings[:, 2]):
+                raise ValueError("got ratings not in rating_values")
+        self.rating_values = rating_values
+        self.discrete_expectations = discrete_expectations
+        self.refit_lookahead = refit_lookahead
+        self.approx_dim = (self.num_users + self.num_items) * self.latent_d
+        self.normal_learning_rate = 1e-4
+        self.min_eig = 1e-5
+
+    # -- copy / pickle: subclass attributes travel in state['__dict__'] like the reference
+    def __copy__(self):
+        res = type(self)(self.ratings, self.latent_d, self.rating_values,
+                         self.discrete_expectations)
+        res.__setstate__(self.__getstate__())
+        return res
+
+    def __deepcopy__(self, memodict):
+        res = type(self)(self.ratings, self.latent_d, self.rating_values,
+                         self.discrete_expectations)
+        res.__setstate__(deepcopy(self.__getstate__(), memodict))
+        return res
+
+    def __getstate__(self):
+        state = super(_ActiveBase, self).__getstate__()
+        state['__dict__'] = self._extra_dict()
+        return state
+
+    rating_values = property(lambda self: self._rating_values)
+    rating_bounds = property(lambda self: self._rating_bounds)
+
+    @rating_values.setter
+    def rating_values(self, vals):
+        if vals:
+            vals = tuple(sorted(vals))
+            self._rating_values = vals
+            edges = np.empty(len(vals) + 2)
+            edges[0], edges[1:-1], edges[-1] = -np.inf, vals, np.inf
+            self._rating_bounds = (edges[1:] + edges[:-1]) / 2
+        else:
+            self._rating_values = None
+            self._rating_bounds = None
+
+    # -- supplied by the subclass ---------------------------------------------------------
+    def _score_pool(self, pi, pj):
+        """(mean, var) float64 arrays of E / Var[U_i.V_j] for the pool, from the GPU."""
+        raise NotImplementedError
+
+    def fit_normal_kls(self):
+        raise NotImplementedError
+
+    def fit_normal(self):
+        '''Fit the approximation by projected gradient descent on the KL.'''
+        for kl in self.fit_normal_kls():
+            pass
+
+    def _descend(self, current, gradient, step, project, objective):
+        """The reference's learning-rate search for the variational fit
+        (mn_active_pmf.py:242-288 / active_pmf.py:250-288): x1.25 on an improving step,
+        x0.5 otherwise, converged when the KL improves by < .005 or lr < 1e-10."""
+        lr = self.normal_learning_rate
+        old_kl = objective(*current())
+        converged = False
+        while not converged:
+            grads = gradient()
+            while True:
+                cand = tuple(project(k, x - lr * g)
+                             for k, (x, g) in enumerate(zip(current(), grads)))
+                new_kl = objective(*cand)
+                if new_kl < old_kl:
+                    step(cand)
+                    lr *= 1.25
+                    if old_kl - new_kl < .005:
+                        converged = True
+                    yield new_kl
+                    old_kl = new_kl
+                    break
+                else:
+                    lr *= .5
+                    if lr < 1e-10:
+                        converged = True
+                        break
+
+    # -- one-candidate views -----------------------------------------------------------------
+    def approx_pred_mean_var(self, i, j):
+        mean, var = self._score_pool(np.array([i], np.int32), np.array([j], np.int32))
+        return float(mean[0]), float(var[0])
+
+    # -- criteria (mn_active_pmf.py:404-625) ------------------------------------------------
+    @_criterion("Random", False, False)
+    def random_weighting(self, ij):
+        return random.random()
+
+    def _pred_pool(self, pi, pj):
+        return self.predicted_matrix()[pi, pj]
+
+    @_criterion("Pred Mag", False, False, batch='_pred_pool')
+    def pred(self, ij):
+        '''The MAP estimate of R_ij.'''
+        i, j = ij
+        return np.dot(self.users[i, :], self.items[j, :])
+
+    def _prob_ge_pool(self, pi, pj, cutoff):
+        mean, var = self._score_pool(pi, pj)
+        # sic: the variance is passed as `scale` (mn_active_pmf.py:438)
+        return stats.norm.sf(cutoff, loc=mean, scale=var)
+
+    def _prob_ge_cutoff(self, ij, cutoff):
+        mean, var = self.approx_pred_mean_var(*ij)
+        return stats.norm.sf(cutoff, loc=mean, scale=var)
+
+    def _prob_ge_3_5_pool(self, pi, pj):
+        return self._prob_ge_pool(pi, pj, 3.5)
+
+    def _prob_ge_half_pool(self, pi, pj):
+        return self._prob_ge_pool(pi, pj, .5)
+
+    @_criterion("Prob >= 3.5", True, False, batch='_prob_ge_3_5_pool')
+    def prob_ge_3_5(self, ij):
+        return self._prob_ge_cutoff(ij, 3.5)
+
+    @_criterion("Prob >= .5", True, False, batch='_prob_ge_half_pool')
+    def prob_ge_half(self, ij):
+        return self._prob_ge_cutoff(ij, .5)
+
+    def _pred_variance_pool(self, pi, pj):
+        return self._score_pool(pi, pj)[1]
+
+    @_criterion("Pred Variance", True, False, batch='_pred_variance_pool')
+    def pred_variance(self, ij):
+        '''Variance of the prediction for R_ij under the current approximation.'''
+        return self.approx_pred_mean_var(*ij)[1]
+
+    def _onestep_ge_cutoff(self, ij, cutoff, use_map):
+        '''One-step lookahead utility (Garnett et al., KDD-MLG 2011) for the class
+        "value >= cutoff".'''
+        def fn(apmf, v):
+            return apmf._last_step_lookahead_helper(cutoff=cutoff, v=v)
+        fn.__name__ = '_1step_{}'.format(cutoff)
+        return self._exp_with_rij(ij, fn, use_map=use_map, discretize=True, pass_v=True)
+
+    @_criterion("1 step >= 3.5 (MAP)", True, True)
+    def onestep_ge_3_5(self, ij):
+        return self._onestep_ge_cutoff(ij, 3.5, True)
+
+    @_criterion("1 step >= 3.5 (Approx)", True, True)
+    def onestep_ge_3_5_approx(self, ij):
+        return self._onestep_ge_cutoff(ij, 3.5, False)
+
+    @_criterion("1 step >= .5 (MAP)", True, True)
+    def onestep_ge_half(self, ij):
+        return self._onestep_ge_cutoff(ij, .5, True)
+
+    @_criterion("1 step >= .5 (Approx)", True, True)
+    def onestep_ge_half_approx(self, ij):
+        return self._onestep_ge_cutoff(ij, .5, False)
+
+    def _last_step_lookahead_helper(self, cutoff, v):
+        utility = int(v >= cutoff)
+        pool, pi, pj = _pool_arrays(self.unrated)
+        return utility + max(self._prob_ge_pool(pi, pj, cutoff))
+
+    def _total_variance(self):
+        return self.approx_pred_means_vars()[1].sum()
+
+    @_criterion("E[U/V Entropy] (MAP)", True, True, chooser=minimize)
+    def exp_approx_entropy(self, ij):
+        return self._exp_with_rij(ij, type(self)._approx_entropy, use_map=True)
+
+    @_criterion("E[U/V Entropy] (Approx)", True, True, chooser=minimize)
+    def exp_approx_entropy_byapprox(self, ij):
+        return self._exp_with_rij(ij, type(self)._approx_entropy, use_map=False)
+
+    @_criterion("E[Pred Total Variance] (MAP)", True, True, chooser=minimize)
+    def exp_total_variance(self, ij):
+        return self._exp_with_rij(ij, type(self)._total_variance, use_map=True)
+
+    @_criterion("E[Pred Total Variance] (Approx)", True, True, chooser=minimize)
+    def exp_total_variance_byapprox(self, ij):
+        return self._exp_with_rij(ij, type(self)._total_variance, use_map=False)
+
+    def _exp_with_rij(self, ij, fn, use_map=True, discretize=None, pass_v=False):
+        '''E[fn(model with R_ij known)] over the predictive distribution of R_ij
+        (mn_active_pmf.py:627-696): MAP mean with variance sigma_sq if use_map, else the
+        approximation's mean/variance; summed over rating_values when discretising, else
+        integrated to +-2 sigma with scipy.'''
+        i, j = ij
+        if discretize is None:
+            discretize = self.discrete_expectations
+        if use_map:
+            mean = np.dot(self.users[i, :], self.items[j, :])
+            var = self.sigma_sq
+        else:
+            mean, var = self.approx_pred_mean_var(i, j)
+        std = math.sqrt(var)
+
+        def calculate_fn(v):
+            apmf = deepcopy(self)
+            apmf.add_rating(i, j, v)
+            if apmf.refit_lookahead:
+                apmf.do_fit()
+                apmf.initialize_approx()
+            apmf.fit_normal()
+            return fn(apmf, v=v) if pass_v else fn(apmf)
+
+        points = self.rating_values
+        if discretize and points:
+            evals = np.array([calculate_fn(v) for v in points])
+            if discretize == 'simps':
+                pdfs = stats.norm.pdf(points, loc=mean, scale=std)
+                import scipy.integrate
+                simpson = getattr(scipy.integrate, 'simpson', None) or scipy.integrate.simps
+                est = simpson(evals * pdfs, x=points)
+                s = "simps'ed"
+            else:
+                cdfs = stats.norm.cdf(self.rating_bounds, loc=mean, scale=std)
+                est = (evals * np.diff(cdfs)).sum()
+                s = "summed"
+        else:
+            if discretize and points is None:
+                warnings.warn("{} has no rating_values; doing integral".format(type(self).__name__))
+            left, right = mean - 2 * std, mean + 2 * std
+            est = stats.norm.expect(calculate_fn, loc=mean, scale=std, lb=left, ub=right,
+                                    epsrel=.02)
+            s = "from {:5.1f} to {:5.1f}".format(left, right)
+        name = getattr(fn, '__name__', '')
+        print("\t{:>20}({},{}) {}: {: 10.2f}".format(name, i, j, s, est))
+        return est
+
+    # -- selection surface (mn_active_pmf.py:701-779) ----------------------------------------
+    def _default_key(self):
+        return type(self).pred_variance
+
+    def pick_query_point(self, pool=None, key=None, procs=None, worker_pool=None):
+        '''Next (i, j) to query: the first extremum of `key` over `pool` (default
+        self.unrated) in the pool's iteration order, max or min per key.chooser.'''
+        if pool is None:
+            pool = self.unrated
+        if key is None:
+            key = self._default_key()
+        chooser = getattr(key, 'chooser', max)
+        if len(pool) == 0:
+            raise ValueError("can't pick a query point from an empty pool")
+        elif len(pool) == 1:
+            return next(iter(pool))
+        pool = list(pool)
+        vals = self._get_key_vals(pool, key, procs, worker_pool)
+        return chooser(zip(pool, vals), key=operator.itemgetter(1))[0]
+
+    def _get_key_vals(self, pool, key, procs=None, worker_pool=None):
+        '''Values of `key` for every (i, j) of `pool`, in pool order.  Batched criteria are
+        one GPU launch; the others (random, lookahead) are mapped in this process.'''
+        impl = getattr(key, 'batched', None)
+        if impl is not None:
+            pool, pi, pj = _pool_arrays(pool)
+            if not pool:
+                return []
+            return list(np.asarray(getattr(self, impl)(pi, pj), dtype=np.float64))
+        return [key(self, ij) for ij in pool]
+
+    def get_key_evals(self, pool=None, key=None, procs=None, worker_pool=None):
+        '''(n, m) matrix holding key's value at every element of pool, NaN elsewhere.'''
+        if pool is None:
+            pool = self.unrated
+        if key is None:
+            key = self._default_key()
+        pool = list(pool)
+        evals = np.empty((self.num_users, self.num_items))
+        evals.fill(np.nan)
+        if pool:
+            evals[tuple(zip(*pool))] = self._get_key_vals(pool, key, procs, worker_pool)
+        return evals
+
+
+# ---------------------------------------------------------------------------- experiment loop
+def make_key_funcs(cls, with_entropy_bound=False):
+    keys = {
+        "random": cls.random_weighting,
+        "pred-variance": cls.pred_variance,
+        "total-variance": cls.exp_total_variance,
+        "total-variance-approx": cls.exp_total_variance_byapprox,
+        "uv-entropy": cls.exp_approx_entropy,
+        "uv-entropy-approx": cls.exp_approx_entropy_byapprox,
+        "pred": cls.pred,
+        "prob-ge-3.5": cls.prob_ge_3_5,
+        "prob-ge-.5": cls.prob_ge_half,
+        "1step-ge-3.5": cls.onestep_ge_3_5,
+        "1step-ge-3.5-approx": cls.onestep_ge_3_5_approx,
+        "1step-ge-.5": cls.onestep_ge_half,
+        "1step-ge-.5-approx": cls.onestep_ge_half_approx,
+    }
+    if with_entropy_bound:
+        keys["pred-entropy-bound"] = cls.exp_pred_entropy_bound
+        keys["pred-entropy-bound-approx"] = cls.exp_pred_entropy_bound_byapprox
+    return keys
+
+
+def query_loop(apmf, real, picker_key, fit_normal, fit_sigmas, test_on=None, with_pred=True,
+               matrix_vals=False, initial_fit=False, refit_with_lls=False):
+    """select -> query -> refit generator behind full_test / _full_test_threaded
+    (mn_active_pmf.py:795-894): yields (n_rated, rmse, (i,j), vals[, predicted_matrix])."""
+    name = picker_key.nice_name
+    total = real.size
+
+    def result(*parts):
+        return parts + ((apmf.predicted_matrix(),) if with_pred and parts[2] is not None
+                        else ((None,) if with_pred else ()))
+
+    if initial_fit:
+        if fit_sigmas:
+            apmf.fit_with_sigmas()
+        else:
+            apmf.do_fit()
+        apmf.initialize_approx()
+        if fit_normal:
+            apmf.fit_normal()
+    rmse = apmf.rmse(real, test_on) if test_on is not None else apmf.rmse(real)
+    print("{:<40} Initial RMSE: {:.5}".format(name, rmse))
+    yield result(len(apmf.rated), rmse, None, None)
+
+    while apmf.unrated:
+        n = len(apmf.rated) + 1
+        print("{:<40} Picking query point {}...".format(name, n))
+        if len(apmf.unrated) == 1:
+            i, j = next(iter(apmf.unrated))
+            if matrix_vals:
+                vals = np.empty((apmf.num_users, apmf.num_items))
+                vals.fill(np.nan)
+            else:
+                vals = None
+        elif matrix_vals:
+            vals = apmf.get_key_evals(key=picker_key)
+            i, j = picker_key.chooser(apmf.unrated, key=vals.__getitem__)
+        else:
+            pool = list(apmf.unrated)
+            vals = apmf._get_key_vals(pool, picker_key, None, None)
+            i, j = picker_key.chooser(zip(pool, vals), key=operator.itemgetter(1))[0]
+
+        apmf.add_rating(i, j, real[i, j])
+        print("{:<40} Queried ({}, {}); {}/{} known".format(name, i, j, len(apmf.rated), total))
+        if refit_with_lls:
+            # full_test refits with plain fit_lls/fit_normal_kls, never re-initialising
+            for ll in apmf.fit_lls():
+                pass
+            if fit_normal:
+                for kl in apmf.fit_normal_kls():
+                    assert kl > -1e5
+        else:
+            if fit_sigmas:
+                apmf.fit_with_sigmas()
+            else:
+                apmf.do_fit()
+            if fit_normal:
+                if apmf.refit_lookahead:
+                    apmf.initialize_approx()
+                apmf.fit_normal()
+        rmse = apmf.rmse(real, test_on) if test_on is not None else apmf.rmse(real)
+        print("{:<40} RMSE {}: {:.5}".format(name, n, rmse))
+        yield result(len(apmf.rated), rmse, (i, j), vals)
+
+
+def run_compare(cls, key_funcs, key_names, real, ratings, rating_vals, latent_d, knowable,
+                test_on, steps, discrete_exp, refit_lookahead, fit_sigmas, apmf, sig_priors,
+                fit_type, do_threading, with_pred):
+    """Body of compare() (mn_active_pmf.py:922-1003 / active_pmf.py:1003-1092)."""
+    if apmf:
+        assert (apmf.num_users, apmf.num_items) == real.shape
+        assert np.all(apmf.ratings == ratings)
+        assert set(apmf.rating_values) == set(rating_vals)
+        apmf.discrete_expectations = discrete_exp
+    else:
+        apmf = cls(ratings, latent_d=latent_d, rating_values=rating_vals,
+                   discrete_expectations=discrete_exp, refit_lookahead=refit_lookahead,
+                   knowable=knowable, fit_type=fit_type)
+        apmf.sig_u_mean, apmf.sig_u_var, apmf.sig_v_mean, apmf.sig_v_var = sig_priors
+        print("Doing initial fit")
+        if fit_sigmas:
+            apmf.fit_with_sigmas()
+        else:
+            apmf.do_fit()
+        if any(key_funcs[name].do_normal_fit for name in key_names):
+            apmf.initialize_approx()
+            print("Initial approximation fit")
+            apmf.fit_normal()
+
+    results = {
+        '_real': real,
+        '_ratings': ratings,
+        '_rating_vals': rating_vals,
+        '_initial_apmf': deepcopy(apmf),
+    }
+    # The reference runs one thread per key over a forked process pool; with the criteria
+    # on the GPU the keys are simply run one after the other in this process.
+    for key_name in key_names:
+        key = key_funcs[key_name]
+        if do_threading:
+            res = query_loop(deepcopy(apmf), real, key, key.do_normal_fit, fit_sigmas,
+                             test_on=test_on, with_pred=with_pred, matrix_vals=True)
+        else:
+            res = query_loop(deepcopy(apmf), real, key, key.do_normal_fit, fit_sigmas,
+                             test_on=test_on, with_pred=with_pred, initial_fit=True,
+                             refit_with_lls=True)
+        results[key_name] = list(itertools.islice(res, steps))
+    return results

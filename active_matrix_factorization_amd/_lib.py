@@ -62,7 +62,8 @@ _SIGS = {
     'apmf_pmf_log_likelihood': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl,
                                      C.POINTER(_dbl), C.POINTER(_dbl)]),
     'apmf_pmf_fit_lls': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, C.POINTER(_dbl),
-                              _dbl, _dbl, _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
+                              C.POINTER(_dbl), _dbl, _dbl, _i64, _vp, _i64, C.POINTER(_i64),
+                              C.POINTER(_i)]),
     'apmf_pmf_minibatch_epoch': (_i, [_vp, _vp, _i64, _i, _i, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                       _i, _dbl, _dbl, _dbl, _i, _dbl]),
     'apmf_pmf_predicted_matrix': (_i, [_vp, _vp, _vp, _i, _i, _i, _dbl, _vp, _i]),
@@ -311,14 +312,16 @@ class Context(object):
         return ll.value, sq.value
 
     def pmf_fit_lls(self, rt, dU, dV, d, sig, sig_u, sig_v, subtract_mean, mean_rating, lr, min_lr,
-                    stop_thresh, max_steps=-1, max_trace=1 << 16):
+                    stop_thresh, max_steps=-1, max_trace=1 << 16, old_ll=None, return_ll=False):
         trace = np.empty(max(max_trace, 1), np.float64)
         lr_io, steps, conv = _dbl(lr), _i64(0), _i(0)
+        ll_io = _dbl(float('nan') if old_ll is None else old_ll)
         _check(self._lib.apmf_pmf_fit_lls(self._h, rt._h, _ptr(dU), _ptr(dV), d, sig, sig_u, sig_v,
                                           int(bool(subtract_mean)), mean_rating, C.byref(lr_io),
-                                          min_lr, stop_thresh, max_steps, trace.ctypes.data, max_trace,
-                                          C.byref(steps), C.byref(conv)))
-        return trace[:min(steps.value, max_trace)].copy(), steps.value, lr_io.value, bool(conv.value)
+                                          C.byref(ll_io), min_lr, stop_thresh, max_steps,
+                                          trace.ctypes.data, max_trace, C.byref(steps), C.byref(conv)))
+        res = (trace[:min(steps.value, max_trace)].copy(), steps.value, lr_io.value, bool(conv.value))
+        return res + (ll_io.value,) if return_ll else res
 
     def pmf_minibatch_epoch(self, shuffled, n, m, batch_size, lr, momentum, dU, dV, duinc, dvinc, d,
                             sig, sig_u, sig_v, subtract_mean, mean_rating):

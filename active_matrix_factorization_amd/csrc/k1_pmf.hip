@@ -483,9 +483,9 @@ int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *
 
 int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *d_V, int d,
                      double sigma_sq, double sigma_u_sq, double sigma_v_sq, int subtract_mean,
-                     double mean_rating, double *h_lr, double min_learning_rate,
-                     double stop_thresh, int64_t max_steps, double *h_ll_trace,
-                     int64_t max_trace, int64_t *h_steps, int *h_converged)
+                     double mean_rating, double *h_lr, double *h_old_ll,
+                     double min_learning_rate, double stop_thresh, int64_t max_steps,
+                     double *h_ll_trace, int64_t max_trace, int64_t *h_steps, int *h_converged)
 {
     APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
     APMF_REQUIRE(d_U && d_V && h_lr && h_steps, "NULL operand");
@@ -515,7 +515,8 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     // step swaps the roles instead of copying (the reference rebinds self.users / self.items)
     double *cU = d_U, *cV = d_V, *oU = tU, *oV = tV;
     double lr = *h_lr, old_ll;
-    APMF_TRY(eval_ll(cU, cV, &old_ll));
+    if (h_old_ll && *h_old_ll == *h_old_ll) old_ll = *h_old_ll;
+    else APMF_TRY(eval_ll(cU, cV, &old_ll));
     int64_t steps = 0;
     bool converged = false;
     const int ax_blocks = (int)std::min<size_t>((nu + nv + 255) / 256, 2048);
@@ -548,6 +549,7 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     }
     APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     *h_lr = lr;
+    if (h_old_ll) *h_old_ll = old_ll;
     *h_steps = steps;
     if (h_converged) *h_converged = converged ? 1 : 0;
     return APMF_OK;

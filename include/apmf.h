@@ -109,12 +109,16 @@ int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *
  * or until max_steps accepted steps (max_steps < 0: no limit).  h_ll_trace[0..min(steps,
  * max_trace)) receives the LL the reference's generator would yield.  *h_lr: in = starting
  * learning rate, out = learning rate after the last step (so a caller can resume);
- * *h_converged: the reference's `converged` flag. */
+ * *h_old_ll (may be NULL): in = the LL the search compares against (NaN: evaluate it at
+ * entry, as fit_lls does before its loop), out = LL of the last accepted step - carrying it
+ * across calls reproduces the generator exactly even when a caller changes the sigmas
+ * between steps (fit_with_sigmas_lls, pmf_cy.pyx:385-403); *h_converged: the reference's
+ * `converged` flag. */
 int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *d_V, int d,
                      double sigma_sq, double sigma_u_sq, double sigma_v_sq, int subtract_mean,
-                     double mean_rating, double *h_lr, double min_learning_rate,
-                     double stop_thresh, int64_t max_steps, double *h_ll_trace,
-                     int64_t max_trace, int64_t *h_steps, int *h_converged);
+                     double mean_rating, double *h_lr, double *h_old_ll,
+                     double min_learning_rate, double stop_thresh, int64_t max_steps,
+                     double *h_ll_trace, int64_t max_trace, int64_t *h_steps, int *h_converged);
 /* One epoch of fit_minibatches(), pmf_cy.pyx:324-344, on ALREADY SHUFFLED ratings
  * (the host keeps np.random.shuffle so the RNG stream matches): for each consecutive
  * batch  inc = momentum*inc + grad*(lr/len(batch)); params += inc.  d_U, d_V, d_uinc,

@@ -1,0 +1,391 @@
+"""The drop-in Python classes (ProbabilisticMatrixFactorization, MNActivePMF, ActivePMF,
+BayesianPMF) against golden vectors recorded from the real reference classes: same
+constructor calls, same seeds, same method names.  Needs an MI355X: run with -m gpu."""
+import copy
+import pickle
+import random
+from itertools import islice
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+
+
+def seed(s):
+    np.random.seed(s)
+    random.seed(s)
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    import active_matrix_factorization_amd.pmf_cy as pmf_cy
+    import active_matrix_factorization_amd.mn_active_pmf as mn
+    import active_matrix_factorization_amd.active_pmf as full
+    import active_matrix_factorization_amd.bayes_pmf as bayes
+
+    class P(object):
+        pass
+    p = P()
+    p.pmf_cy, p.mn, p.full, p.bayes = pmf_cy, mn, full, bayes
+    return p
+
+
+# ------------------------------------------------------------------ ProbabilisticMatrixFactorization
+PMF_CASES = [('pmf_c1_10x10_d2', 2), ('pmf_50x40_d3', 4), ('pmf_50x40_d3_submean', 5),
+             ('pmf_30x70_d16', 7)]
+
+
+def _make_pmf(pkg, g, s):
+    seed(s)   # the generator seeded, then constructed: np.random.random gives the same U0, V0
+    p = pkg.pmf_cy.ProbabilisticMatrixFactorization(g['ratings'].copy(), latent_d=int(g['d']),
+                                                    subtract_mean=bool(g['subtract_mean']))
+    p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq = (float(x) for x in g['sigma'])
+    return p
+
+
+@pytest.mark.parametrize('name,s', PMF_CASES)
+def test_pmf_class_golden(pkg, name, s):
+    g = load_golden(name)
+    p = _make_pmf(pkg, g, s)
+    np.testing.assert_array_equal(p.users, g['U0'])      # same RNG consumption as the reference
+    np.testing.assert_array_equal(p.items, g['V0'])
+    assert p.mean_rating == float(g['mean_rating'])
+    gU, gV = p.gradient()
+    np.testing.assert_allclose(gU, g['gU'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(gV, g['gV'], rtol=1e-12, atol=1e-12)
+    assert abs(p.log_likelihood() - g['ll']) <= 1e-12 * abs(g['ll'])
+    assert abs(p.full_ll() - g['full_ll']) <= 1e-12 * abs(g['full_ll'])
+    lo, hi = int(g['batch_lo']), int(g['batch_hi'])
+    gUb, gVb = p.gradient(p.ratings[lo:hi])
+    np.testing.assert_allclose(gUb, g['gU_batch'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(p.predicted_matrix(), g['pred0'], rtol=1e-13, atol=1e-13)
+    # fit_lls generator: same yields, state visible between yields
+    trace = list(p.fit_lls())
+    assert len(trace) == g['ll_trace'].size
+    np.testing.assert_allclose(trace, g['ll_trace'], rtol=1e-10)
+    np.testing.assert_allclose(p.users, g['U_fit'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(p.items, g['V_fit'], rtol=1e-8, atol=1e-10)
+    # rmse() returns a C float in the reference (pmf_cy.pyx:25-29, 422-426)
+    r = p.rmse(g['rmse_target'])
+    assert r == float(np.float32(r)) and abs(r - float(g['rmse'])) <= 2e-7 * float(g['rmse'])
+    r_on = p.rmse(g['rmse_target'], g['rmse_on_mask'])
+    assert abs(r_on - float(g['rmse_on'])) <= 2e-7 * float(g['rmse_on'])
+    p.update_sigma()
+    p.update_sigma_uv()
+    np.testing.assert_allclose([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq], g['sigma_after'], rtol=1e-9)
+
+
+@pytest.mark.parametrize('name,s', PMF_CASES[:2])
+def test_pmf_fit_equals_generator(pkg, name, s):
+    g = load_golden(name)
+    p = _make_pmf(pkg, g, s)
+    p.do_fit()      # one device call for the whole search
+    np.testing.assert_allclose(p.users, g['U_fit'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(p.items, g['V_fit'], rtol=1e-8, atol=1e-10)
+
+
+def test_pmf_errors_and_state(pkg):
+    PMF = pkg.pmf_cy.ProbabilisticMatrixFactorization
+    with pytest.raises(TypeError):
+        PMF(np.zeros((4, 2)))
+    g = load_golden('pmf_50x40_d3')
+    p = _make_pmf(pkg, g, 4)
+    with pytest.raises(ValueError):                      # pmf_cy.pyx:149-150
+        p.add_rating(int(g['ratings'][0, 0]), int(g['ratings'][0, 1]), 1.0)
+    with pytest.raises(TypeError):
+        p.add_ratings([[1, 2]])
+    i, j = next(iter(p.unrated))
+    p.add_rating(i, j, 2.5)
+    assert (i, j) in p.rated and (i, j) not in p.unrated and p.ratings.shape[0] == g['ratings'].shape[0] + 1
+    ll = p.log_likelihood()                              # the device CSR followed the new rating
+    from oracle import oracle as orc
+    assert abs(ll - orc.pmf_log_likelihood(p.ratings, p.users, p.items)) <= 1e-12 * abs(ll)
+    p.fit_type = ('nope',)
+    with pytest.raises(ValueError):
+        p.do_fit()
+    # device handles never enter pickles or deep copies
+    q = pickle.loads(pickle.dumps(p))
+    c = copy.deepcopy(p)
+    for o in (q, c):
+        assert '_dev' not in o.__getstate__() and o.__dict__.get('_dev') is None
+        np.testing.assert_array_equal(o.users, p.users)
+        assert o.unrated == p.unrated and o.rated == p.rated
+        assert o.log_likelihood() == ll
+    assert pkg.pmf_cy.parse_fit_type('mini-valid,100,2.5') == ('mini-valid', 100, 2.5)
+
+
+def test_pmf_minibatch_fit(pkg):
+    from oracle import oracle as orc
+    seed(3)
+    ratings, _, _ = pkg.pmf_cy.fake_ratings(num_users=30, num_items=25, num_ratings=8,
+                                            latent_dimension=4)
+    seed(9)
+    p = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=4)
+    U, V, r_host = p.users.copy(), p.items.copy(), ratings.copy()
+    ui, vi = np.zeros_like(U), np.zeros_like(V)
+    seed(11)
+    it = p.fit_minibatches(32)
+    errs = [next(it) for _ in range(3)]
+    # the reference recipe on the host: same shuffles (np.random.shuffle), pmf_cy.pyx:324-351
+    seed(11)
+    mom = float(np.float32(.8))
+    ref_errs = []
+    for _ in range(3):
+        np.random.shuffle(r_host)
+        for s in range(0, r_host.shape[0], 32):
+            b = r_host[s:s + 32]
+            gU, gV = orc.pmf_gradient(b, U, V)
+            sc = float(np.float32(1.) / np.float32(b.shape[0]))
+            ui = ui * mom + gU * sc
+            U = U + ui
+            vi = vi * mom + gV * sc
+            V = V + vi
+        pred = U @ V.T
+        ij = r_host[:, :2].astype(int)
+        ref_errs.append(float(np.float32(np.sqrt(np.mean((pred[ij[:, 0], ij[:, 1]) - r_host[:, 2]) ** 2)))))
+    np.testing.assert_allclose(p.users, U, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(errs, ref_errs, rtol=1e-6)
+    np.testing.assert_array_equal(p.ratings, r_host)     # shuffled in place, like the reference
+
+
+# ------------------------------------------------------------------ MNActivePMF
+MN_CASES = ['mn_c1_10x10_d2_eye', 'mn_c1_10x10_d2_rand', 'mn_24x17_d5_rand', 'mn_12x20_d10_rand']
+
+
+def _make_mn(pkg, g, rating_values=None):
+    a = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=int(g['d']), rating_values=rating_values)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = (g['mean'].copy(), g['cov_useritems'].copy(),
+                                              g['cov_latents'].copy())
+    return a
+
+
+@pytest.mark.parametrize('name', MN_CASES)
+def test_mn_class_scoring_and_selection(pkg, name):
+    g = load_golden(name)
+    a = _make_mn(pkg, g)
+    MN = pkg.mn.MNActivePMF
+    scale = np.abs(g['e2'])
+    # the unrated set iterates in the reference's order (same construction sequence)
+    pool = list(a.unrated)
+    np.testing.assert_array_equal(np.array(pool), g['pool'])
+    pm, pv = a.approx_pred_means_vars()
+    assert np.all(np.abs(pv - g['p_var']) <= 64 * EPS * scale)
+    assert np.all(np.abs(pm - g['p_mean']) <= 64 * EPS * (np.abs(g['p_mean']) + np.sqrt(scale)))
+    vals = a._get_key_vals(pool, MN.pred_variance, 1, None)
+    assert isinstance(vals, list) and len(vals) == len(pool)
+    assert np.all(np.abs(np.array(vals) - g['pool_vals']) <= 64 * EPS * scale.max())
+    # selected index identical to the reference's
+    assert tuple(a.pick_query_point(key=MN.pred_variance)) == tuple(g['pick_max'])
+    assert tuple(a.pick_query_point()) == tuple(g['pick_max'])
+    ev = a.get_key_evals(key=MN.pred_variance)
+    assert np.array_equal(np.isnan(ev), np.isnan(g['key_evals']))
+    ok = ~np.isnan(ev)
+    assert np.all(np.abs(ev[ok] - g['key_evals'][ok]) <= 64 * EPS * scale.max())
+    i, j = pool[3]
+    mn_, var_ = a.approx_pred_mean_var(i, j)
+    assert abs(var_ - g['p_var'][i, j]) <= 64 * EPS * scale[i, j]
+    assert abs(a.pred_variance((i, j)) - g['p_var'][i, j]) <= 64 * EPS * scale[i, j]
+    assert abs(a._total_variance() - g['total_variance']) <= 1e-12 * abs(g['total_variance'])
+    assert abs(a.kl_divergence() - g['kl']) <= 1e-10 * abs(g['kl'])
+    # small pool -> the pool kernel path; other criteria
+    few = pool[:5]
+    v5 = a._get_key_vals(few, MN.pred_variance, None, None)
+    assert np.all(np.abs(np.array(v5) - g['pool_vals'][:5]) <= 64 * EPS * scale.max())
+    pr = a._get_key_vals(few, MN.pred, None, None)
+    np.testing.assert_allclose(pr, [np.dot(a.users[i], a.items[j]) for i, j in few], rtol=1e-13)
+    from scipy import stats
+    pg = a._get_key_vals(few, MN.prob_ge_3_5, None, None)
+    ref = [stats.norm.sf(3.5, loc=g['p_mean'][i, j], scale=g['p_var'][i, j]) for i, j in few]
+    np.testing.assert_allclose(pg, ref, rtol=1e-9, atol=1e-300)
+    with pytest.raises(ValueError):
+        a.pick_query_point(pool=[])
+    assert a.pick_query_point(pool=[(1, 2)]) == (1, 2)
+
+
+def test_mn_requires_approx(pkg):
+    g = load_golden('mn_24x17_d5_rand')
+    a = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=5)
+    with pytest.raises(ValueError):
+        a.kl_divergence()
+    with pytest.raises(TypeError):
+        pkg.mn.matrixnormal_gradient(a)
+    with pytest.raises(ValueError):
+        pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=5, rating_values=(1, 2))
+
+
+@pytest.mark.parametrize('name', MN_CASES[:3])
+def test_mn_variational_fit(pkg, name):
+    """KL gradient and the first accepted steps of fit_normal_kls vs the reference
+    (matrix_normal_exps_cy.pyx:395-485, mn_active_pmf.py:242-288)."""
+    g = load_golden(name)
+    a = _make_mn(pkg, g)
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    gm, gcu, gcl = pkg.mn.matrixnormal_gradient(a)
+    np.testing.assert_allclose(gm, g['g_mean'], rtol=1e-9, atol=1e-9 * np.abs(g['g_mean']).max())
+    np.testing.assert_allclose(gcu, g['g_cov_useritems'], rtol=1e-9,
+                               atol=1e-9 * np.abs(g['g_cov_useritems']).max())
+    np.testing.assert_allclose(gcl, g['g_cov_latents'], rtol=1e-9,
+                               atol=1e-9 * np.abs(g['g_cov_latents']).max())
+    kls = list(islice(a.fit_normal_kls(), g['kl_trace'].size))
+    np.testing.assert_allclose(kls, g['kl_trace'], rtol=1e-8)
+    np.testing.assert_allclose(a.mean, g['mean_fit'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(a.cov_useritems, g['cov_useritems_fit'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(a.cov_latents, g['cov_latents_fit'], rtol=1e-6, atol=1e-8)
+    pm, pv = a.approx_pred_means_vars()
+    np.testing.assert_allclose(pv, g['p_var_fit'], rtol=1e-6, atol=1e-8 * np.abs(g['p_var_fit']).max())
+
+
+def test_mn_copy_and_pickle(pkg):
+    g = load_golden('mn_c1_10x10_d2_rand')
+    a = _make_mn(pkg, g, rating_values=(1, 2, 3, 4, 5))
+    a.approx_pred_means_vars()                    # creates the device cache
+    for b in (copy.deepcopy(a), pickle.loads(pickle.dumps(a)), copy.copy(a)):
+        assert b.__dict__.get('_dev') is None
+        assert b.rating_values == (1., 2., 3., 4., 5.)
+        np.testing.assert_array_equal(b.cov_useritems, a.cov_useritems)
+        assert tuple(b.pick_query_point()) == tuple(g['pick_max'])
+        assert list(b.unrated) == list(a.unrated)
+    st = a.__getstate__()
+    assert 'mean' in st['__dict__'] and '_dev' not in st['__dict__'] and 'users' not in st['__dict__']
+
+
+def test_config1_selection_trace(pkg):
+    """BASELINE.json configs[0]: 10x10 rank-2 discrete, pmf fit + random / pred-variance
+    selection, 5 steps of mn_active_pmf.compare(..., do_threading=False) under seed 40 -
+    the same (i, j) sequence and RMSEs as the reference run recorded in the fixture."""
+    g = load_golden('trace_c1_mn')
+    seed(int(g['seed']))
+    res = pkg.mn.compare(['random', 'pred-variance'], g['real'], g['ratings'],
+                         rating_vals=(1, 2, 3, 4, 5), latent_d=2, do_threading=False, steps=5)
+    init = res['_initial_apmf']
+    np.testing.assert_allclose(init.users, g['init_users'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(init.mean, g['init_mean'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(init.cov_useritems, g['init_cov_useritems'], rtol=1e-5, atol=1e-7)
+    for key in ('random', 'pred-variance'):
+        steps = res[key]
+        assert [s[0] for s in steps] == list(g[key + '_n_rated'])
+        picks = np.array([s[2] for s in steps[1:]])
+        np.testing.assert_array_equal(picks, g[key + '_picks'])       # selected indices: exact
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=2e-6)
+        for k, s in enumerate(steps[1:]):
+            np.testing.assert_allclose(s[3], g['%s_vals_%d' % (key, k)], rtol=1e-5, atol=1e-9)
+            assert s[4].shape == g['real'].shape
+    assert set(res) == {'_real', '_ratings', '_rating_vals', '_initial_apmf', 'random', 'pred-variance'}
+
+
+def test_mn_lookahead_total_variance(pkg):
+    """exp_total_variance: deepcopy + add_rating + fit_normal + grid sum per rating value
+    (mn_active_pmf.py:600-696); evaluated here against a by-hand composition."""
+    g = load_golden('mn_c1_10x10_d2_eye')
+    a = _make_mn(pkg, g, rating_values=(1, 2, 3, 4, 5))
+    a.discrete_expectations = True
+    ij = tuple(g['pool'][0])
+    est = a.exp_total_variance(ij)
+    from scipy import stats
+    evals = []
+    for v in a.rating_values:
+        b = copy.deepcopy(a)
+        b.add_rating(ij[0], ij[1], v)
+        b.fit_normal()
+        evals.append(b.approx_pred_means_vars()[1].sum())
+    mean = np.dot(a.users[ij[0]], a.items[ij[1]])
+    cdfs = stats.norm.cdf(a.rating_bounds, loc=mean, scale=np.sqrt(a.sigma_sq))
+    assert abs(est - (np.array(evals) * np.diff(cdfs)).sum()) <= 1e-9 * abs(est)
+    assert pkg.mn.KEY_FUNCS['total-variance'].chooser is min
+    assert pkg.mn.KEY_FUNCS['pred-variance'].nice_name == "Pred Variance"
+    assert pkg.mn.KEY_FUNCS['pred-variance'].do_normal_fit and not pkg.mn.KEY_FUNCS['random'].do_normal_fit
+
+
+# ------------------------------------------------------------------ ActivePMF (full covariance)
+@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
+def test_full_class(pkg, name):
+    g = load_golden(name)
+    a = pkg.full.ActivePMF(g['ratings'].copy(), latent_d=int(g['d']))
+    np.testing.assert_array_equal(a.u, g['u_idx'])
+    np.testing.assert_array_equal(a.v, g['v_idx'])
+    a.users, a.items, a.mean, a.cov = g['users'].copy(), g['items'].copy(), g['mean'].copy(), g['cov'].copy()
+    pool = list(a.unrated)
+    np.testing.assert_array_equal(np.array(pool), g['pool'])
+    from oracle import oracle as orc
+    n, m = g['p_mean'].shape
+    _, _, e2 = orc.full_pred_means_vars(n, m, int(g['d']), g['mean'], g['cov'], want_e2=True)
+    pm, pv = a.approx_pred_means_vars()
+    assert np.all(np.abs(pv - g['p_var']) <= 256 * EPS * np.abs(e2))
+    vals = a._get_key_vals(pool, pkg.full.ActivePMF.pred_variance, 1, None)
+    assert np.all(np.abs(np.array(vals) - g['pool_vals']) <= 256 * EPS * np.abs(e2).max())
+    assert tuple(a.pick_query_point()) == tuple(g['pick_max'])
+    assert abs(a.kl_divergence() - g['kl']) <= 1e-10 * abs(g['kl'])
+    assert abs(a._total_variance() - pv.sum()) <= 1e-12 * abs(pv.sum())
+    assert 'pred-entropy-bound' in pkg.full.KEY_FUNCS
+
+
+# ------------------------------------------------------------------ BayesianPMF
+BAYES_CASES = ['bayes_20x15_d4', 'bayes_c1_10x10_d2', 'bayes_100x90_d15']
+
+
+def _make_bayes(pkg, g):
+    b = pkg.bayes.BayesianPMF(g['ratings'].copy(), latent_d=int(g['d']),
+                              subtract_mean=bool(g['subtract_mean']))
+    b.users, b.items = g['users'].copy(), g['items'].copy()
+    return b
+
+
+@pytest.mark.parametrize('name', BAYES_CASES)
+def test_bayes_class_golden(pkg, name):
+    g = load_golden(name)
+    b = _make_bayes(pkg, g)
+    # one sample_feature call, same seed -> same N(0,1)^d draw (bayes_pmf.py:189-216)
+    seed(101)
+    out = b.sample_feature(0, True, g['sf_mu'], g['sf_alpha'], g['items'], g['sf_rated'], g['sf_ratings'])
+    np.testing.assert_allclose(out, g['sf_out'], rtol=1e-9, atol=1e-11)
+    # hyper-parameters (host): identical arithmetic and RNG stream
+    seed(int(g['hp_seed']))
+    mu, alpha = b.sample_hyperparam(g['users'], True)
+    np.testing.assert_allclose(mu, g['hp_mu'], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(alpha, g['hp_alpha'], rtol=1e-12, atol=1e-13)
+    # the chain prefix under the reference's seed
+    S = g['chain_U'].shape[0]
+    seed(int(g['chain_seed']))
+    samps = list(islice(b.samples(), S))
+    np.testing.assert_allclose([u for u, v in samps], g['chain_U'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose([v for u, v in samps], g['chain_V'], rtol=1e-6, atol=1e-8)
+    # criteria over the reference's own samples
+    ref = list(zip(g['chain_U'], g['chain_V']))
+    which = tuple(g['which'])
+    np.testing.assert_allclose(b.pred_variance(ref, which=which), g['pred_variance'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(b.pred_variance(ref), g['pred_variance_full'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(b.pred_variance(iter(ref), which=None), g['pred_variance_full'],
+                               rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(b.predict(ref), g['predict_full'], rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(b.prob_ge_cutoff(ref, 3.5, which=which), g['prob_ge'])
+    np.testing.assert_array_equal(b.prob_ge_cutoff(ref, 0.5), g['prob_ge_full'])
+    assert abs(b.total_variance(ref, which=which) - g['total_variance']) <= 1e-9 * abs(g['total_variance'])
+    ev = b.pred_variance(ref, which=which)
+    assert tuple(g['which'][:, np.argmax(ev)]) == tuple(g['pick_argmax'])
+    mr = b.matrix_results(ev, which)
+    assert np.isnan(mr).sum() == mr.size - ev.size
+
+
+def test_bayes_loop_and_state(pkg):
+    g = load_golden('bayes_c1_10x10_d2')
+    real = np.round(g['users'] @ g['items'].T + 3).clip(1, 5)
+    seed(5)
+    b = _make_bayes(pkg, g)
+    samples = list(islice(b.samples(), 6))
+    res = list(islice(pkg.bayes.full_test(copy.deepcopy(b), samples, real, 'pred-variance', num_samps=6), 3))
+    assert res[0][2] is None and len(res) == 3
+    for n_rated, err, ij, vals in res[1:]:
+        assert vals.shape == real.shape and np.isnan(vals[g['ratings'][0, 0].astype(int),
+                                                         g['ratings'][0, 1].astype(int)])
+        assert err == float(np.float32(err))
+    c = pickle.loads(pickle.dumps(b))
+    assert c.beta == 2 and c.__dict__.get('_dev') is None
+    assert c.u_hyperparams[2] == 2
+    assert set(pkg.bayes.KEYS) == {'random', 'pred-variance', 'exp-variance', 'pred', 'prob-ge-3.5',
+                                   'prob-ge-.5', 'prob-ge-0'}
