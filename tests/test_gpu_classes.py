@@ -147,7 +147,7 @@ def test_pmf_minibatch_fit(pkg):
             V = V + vi
         pred = U @ V.T
         ij = r_host[:, :2].astype(int)
-        ref_errs.append(float(np.float32(np.sqrt(np.mean((pred[ij[:, 0], ij[:, 1]) - r_host[:, 2]) ** 2)))))
+        ref_errs.append(float(np.float32(np.sqrt(np.mean((pred[ij[:, 0], ij[:, 1]] - r_host[:, 2]) ** 2)))))
     np.testing.assert_allclose(p.users, U, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(errs, ref_errs, rtol=1e-6)
     np.testing.assert_array_equal(p.ratings, r_host)     # shuffled in place, like the reference
