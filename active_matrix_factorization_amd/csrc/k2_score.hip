@@ -71,7 +71,7 @@ struct GridArgs {
     const T *rowpack;  // (B, n, rs): [Oa (D) | a (D) | a'Oa | s_ii]
     const T *colpack;  // (B, D+2, ld): b_k rows, then b'Ob, then s_jj
     const T *state;    // (B, 2): tr(O^2), tr(O)
-    const uint8_t *mask;  // (n, ld) or NULL
+    const uint16_t *maskT;  // (ceil(n/16), ld) bit r of word [g][j] = mask[16 g + r][j], or NULL
     T *var;            // (B, n, ld) or NULL
     T *pmean;          // (B, n, ld) or NULL
     double *part_sum;     // (B, nblk)
@@ -80,6 +80,9 @@ struct GridArgs {
 };
 
 // ---- per-state operand packs ------------------------------------------------------
+// One thread per row of M (users -> rowpack, items -> colpack).  The block's rows of M are
+// staged in LDS (coalesced fetch, conflict-free per-row reads); Omega entries are
+// wave-uniform operands (scalar loads); padding columns of colpack are zeroed.
 template <typename T>
 __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int D, int ld, int rs,
                                                  const T *__restrict__ mean,
@@ -88,9 +91,23 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
                                                  T *__restrict__ rowpack, T *__restrict__ colpack,
                                                  T *__restrict__ state)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *sA = reinterpret_cast<T *>(smem_raw);   // blockDim.x x st
+    const int st = d | 1;                      // odd stride: conflict-free row reads
+    const int R = blockDim.x;
     const int b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;  // 0..n+ld
-    const T *O = omega + (size_t)b * d * d;
+    const int t0 = blockIdx.x * R;             // first row (of the n + ld row space) of this block
+    const int t = t0 + threadIdx.x;
+    const T *__restrict__ O = omega + (size_t)b * d * d;
+    {
+        const int nreal = max(0, min(R, n + m - t0));
+        const T *src = mean + ((size_t)b * (n + m) + t0) * d;
+        for (int e = threadIdx.x; e < nreal * d; e += R) {
+            const int r = e / d, k = e - r * d;
+            sA[r * st + k] = src[e];
+        }
+    }
+    __syncthreads();
     if (t == 0) {
         T t2 = 0, tr = 0;
         for (int k = 0; k < d; k++) {
@@ -104,21 +121,22 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
     if (t >= n + ld) return;
     const bool is_user = t < n;
     const int j = t - n;  // column when !is_user (may be padding >= m)
+    T *cp = colpack + (size_t)b * (D + 2) * ld;
     if (!is_user && j >= m) {
-        T *cp = colpack + (size_t)b * (D + 2) * ld;
         for (int k = 0; k < D + 2; k++) cp[(size_t)k * ld + j] = 0;
         return;
     }
-    const T *a = mean + ((size_t)b * (n + m) + t) * d;
+    const T *a = sA + threadIdx.x * st;
     const T sd = diag[(size_t)b * (n + m) + t];
     T quad = 0;
     T *rp = rowpack + ((size_t)b * n + t) * rs;
-    T *cp = colpack + (size_t)b * (D + 2) * ld;
     for (int k = 0; k < D; k++) {
         T w = 0, ak = 0;
         if (k < d) {
             ak = a[k];
-            for (int l = 0; l < d; l++) w += O[k <= l ? k * d + l : l * d + k] * a[l];
+            // the reference only reads Omega[k, l] with k <= l: mirror the upper triangle
+            for (int l = 0; l < k; l++) w += O[l * d + k] * a[l];
+            for (int l = k; l < d; l++) w += O[k * d + l] * a[l];
             quad += ak * w;
         }
         if (is_user) {
@@ -137,28 +155,105 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
     }
 }
 
+// (n, ld) uint8 mask -> (ceil(n/16), ld) uint16 words, bit r = row 16 g + r: a lane fetches
+// the candidate bits of its columns for all 16 rows of its wave with ONE small load
+__global__ __launch_bounds__(256) void k_mask_pack(int n, int ld, const uint8_t *__restrict__ mask,
+                                                   uint16_t *__restrict__ maskT)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (j >= ld) return;
+    unsigned w = 0;
+    for (int r = 0; r < 16; r++) {
+        const int i = g * 16 + r;
+        if (i < n && mask[(size_t)i * ld + j]) w |= 1u << r;
+    }
+    maskT[(size_t)g * ld + j] = (uint16_t)w;
+}
+
 // ---- the sweep ----------------------------------------------------------------------
+#ifndef APMF_K2_NT
+#define APMF_K2_NT 1   // streamed-once operands use nontemporal loads/stores
+#endif
+
+template <typename T, int N> struct NVec { typedef T type __attribute__((ext_vector_type(N))); };
+template <typename T> struct NVec<T, 1> { typedef T type; };
+
+template <typename T, int V>
+__device__ __forceinline__ void vload_stream(T (&dst)[V], const T *p)
+{
+    using VT = typename NVec<T, V>::type;
+#if APMF_K2_NT
+    VT v = __builtin_nontemporal_load(reinterpret_cast<const VT *>(p));
+#else
+    VT v = *reinterpret_cast<const VT *>(p);
+#endif
+    const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+    for (int i = 0; i < V; i++) dst[i] = e[i];
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void vstore_stream(T *p, const T (&src)[V])
+{
+    using VT = typename NVec<T, V>::type;
+    VT v;
+    T *e = reinterpret_cast<T *>(&v);
+#pragma unroll
+    for (int i = 0; i < V; i++) e[i] = src[i];
+#if APMF_K2_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<VT *>(p));
+#else
+    *reinterpret_cast<VT *>(p) = v;
+#endif
+}
+
+// Element `lane_idx` of a wave-resident register as a wave-uniform value (v_readlane): the
+// per-row operands of a wave's 16 rows are fetched once with coalesced vector loads and then
+// broadcast from registers, instead of 16 x dependent scalar-cache round trips.
+__device__ __forceinline__ float bcast_lane(float v, int lane_idx)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_idx));
+}
+__device__ __forceinline__ double bcast_lane(double v, int lane_idx)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane_idx);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane_idx);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <typename T, int D, int VEC>
 __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__restrict__ p_cross,
                                                  const T *__restrict__ p_rowpack,
                                                  const T *__restrict__ p_colpack,
                                                  const T *__restrict__ p_state,
-                                                 const uint8_t *__restrict__ p_mask,
+                                                 const uint16_t *__restrict__ p_maskT,
                                                  T *__restrict__ p_var, T *__restrict__ p_pmean,
                                                  double *__restrict__ part_sum,
                                                  T *__restrict__ part_val,
                                                  long long *__restrict__ part_idx)
 {
+    static_assert(ROWS_PER_WAVE == 16, "mask words hold 16 rows");
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
-    const int b = blockIdx.z;
-    const int j0 = (blockIdx.x * 64 + lane) * VEC;
+    // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so
+    // all tiles of one posterior state go to the same XCD and its packs stay in ONE L2.
+    // (Placement is a speed matter only: any mapping covers every (state, tile) exactly once.)
+    const int per_state = a.nblk_x * a.nblk_y;
+    const int L = blockIdx.x;
+    const int xcd = L & 7, q = L >> 3;
+    const int b = (q / per_state) * 8 + xcd;
+    if (b >= a.B) return;   // block-uniform
+    const int tile = q % per_state;
+    const int bx = tile % a.nblk_x, by = tile / a.nblk_x;
+    const int j0 = (bx * 64 + lane) * VEC;
     const bool colok = j0 < a.ld;
     const int ld = a.ld, n = a.n, m = a.m;
-    const int rbeg = blockIdx.y * ROWS_PER_BLOCK + wave * ROWS_PER_WAVE;
+    const int rbeg = by * ROWS_PER_BLOCK + wave * ROWS_PER_WAVE;
     const int rend = min(rbeg + ROWS_PER_WAVE, n);
 
-    T bt[D][VEC], q[VEC], sjj[VEC];
+    T bt[D][VEC], qq[VEC], sjj[VEC];
     {
         const T *cp = p_colpack + (size_t)b * (D + 2) * ld + j0;
 #pragma unroll
@@ -169,11 +264,11 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
                 for (int v = 0; v < VEC; v++) bt[k][v] = 0;
         }
         if (colok) {
-            vload<T, VEC>(q, cp + (size_t)D * ld);
+            vload<T, VEC>(qq, cp + (size_t)D * ld);
             vload<T, VEC>(sjj, cp + (size_t)(D + 1) * ld);
         } else {
 #pragma unroll
-            for (int v = 0; v < VEC; v++) q[v] = sjj[v] = 0;
+            for (int v = 0; v < VEC; v++) qq[v] = sjj[v] = 0;
         }
     }
     const T t2 = p_state[2 * b], trO = p_state[2 * b + 1];
@@ -181,92 +276,125 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
     const bool do_var = p_var != nullptr;
     const bool do_red = a.want != 0 || a.want_sum;
 
+    // the wave's 16 rows of rowpack (contiguous: RS elements per row), element e in
+    // register e / 64, lane e % 64
+    constexpr int RS = (2 * D + 2 + 3) / 4 * 4;
+    constexpr int NRP = (ROWS_PER_WAVE * RS + 63) / 64;
+    T rpk[NRP];
+    {
+        const T *rp0 = p_rowpack + ((size_t)b * n + rbeg) * RS;
+        const int nel = (rend - rbeg) * RS;
+#pragma unroll
+        for (int c = 0; c < NRP; c++) rpk[c] = (c * 64 + lane < nel) ? rp0[c * 64 + lane] : (T)0;
+    }
+#define ROWOP(r, k) bcast_lane(rpk[((r) * RS + (k)) / 64], ((r) * RS + (k)) % 64)
+
+    // candidate bits of this lane's columns for the wave's 16 rows
+    unsigned mbits[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) mbits[v] = (colok && j0 + v < m) ? 0xFFFFu : 0u;
+    if (p_maskT && colok && do_red && rbeg < n) {
+        const uint16_t *mp = p_maskT + (size_t)(rbeg >> 4) * ld + j0;
+        uint16_t w[VEC];
+        __builtin_memcpy(w, __builtin_assume_aligned(mp, 2 * VEC), sizeof(w));
+#pragma unroll
+        for (int v = 0; v < VEC; v++) mbits[v] &= w[v];
+    }
+
     double sum = 0.;
     T bestv = 0;
-    long long besti = -1;
+    int bestrow = -1, bestcol = 0;
 
-    for (int i0 = rbeg; i0 < rend; i0 += UNR) {
-        T s[UNR][VEC];
-        unsigned char mk[UNR][VEC];
+    T s_cur[UNR][VEC];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+        if (rbeg + u < rend && colok) vload_stream<T, VEC>(s_cur[u], p_cross + ((size_t)b * n + rbeg + u) * ld + j0);
+        else
+#pragma unroll
+            for (int v = 0; v < VEC; v++) s_cur[u][v] = 0;
+    }
+
+#pragma unroll
+    for (int g = 0; g < ROWS_PER_WAVE / UNR; g++) {
+        const int i0 = rbeg + g * UNR;
+        if (i0 >= rend) break;  // wave-uniform
+        // prefetch the next UNR rows while this group is computed
+        T s_nxt[UNR][VEC];
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
-            const int i = i0 + u;
-            if (i < rend && colok) {
-                vload<T, VEC>(s[u], p_cross + ((size_t)b * n + i) * ld + j0);
-                if (p_mask) {
-                    const uint8_t *mp = p_mask + (size_t)i * ld + j0;
+            const int i = i0 + UNR + u;
+            if (i < rend && colok) vload_stream<T, VEC>(s_nxt[u], p_cross + ((size_t)b * n + i) * ld + j0);
+            else
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) mk[u][v] = mp[v];
-                } else {
-#pragma unroll
-                    for (int v = 0; v < VEC; v++) mk[u][v] = 1;
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < VEC; v++) { s[u][v] = 0; mk[u][v] = 0; }
-            }
+                for (int v = 0; v < VEC; v++) s_nxt[u][v] = 0;
         }
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
+            const int r = g * UNR + u;   // compile-time row slot of this wave
             const int i = i0 + u;
             if (i >= rend) break;  // wave-uniform
-            const T *rp = p_rowpack + ((size_t)b * n + i) * a.rs;  // wave-uniform address
-            const T p = rp[2 * D], sii = rp[2 * D + 1];
+            const T p = ROWOP(r, 2 * D), sii = ROWOP(r, 2 * D + 1);
             T dot[VEC], var[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; v++) dot[v] = 0;
 #pragma unroll
             for (int k = 0; k < D; k++) {
-                const T wk = rp[k];
+                const T wk = ROWOP(r, k);
 #pragma unroll
                 for (int v = 0; v < VEC; v++) dot[v] += wk * bt[k][v];
             }
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
-                const T sv = s[u][v];
-                var[v] = (sii * sjj[v] + sv * sv) * t2 + sjj[v] * p + sii * q[v] + 2 * sv * dot[v];
+                const T sv = s_cur[u][v];
+                var[v] = (sii * sjj[v] + sv * sv) * t2 + sjj[v] * p + sii * qq[v] + 2 * sv * dot[v];
             }
             if (colok) {
-                if (do_var) vstore<T, VEC>(p_var + ((size_t)b * n + i) * ld + j0, var);
+                if (do_var) vstore_stream<T, VEC>(p_var + ((size_t)b * n + i) * ld + j0, var);
                 if (do_mean) {
                     T mn[VEC];
 #pragma unroll
                     for (int v = 0; v < VEC; v++) mn[v] = 0;
 #pragma unroll
                     for (int k = 0; k < D; k++) {
-                        const T ak = rp[D + k];
+                        const T ak = ROWOP(r, D + k);
 #pragma unroll
                         for (int v = 0; v < VEC; v++) mn[v] += ak * bt[k][v];
                     }
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) mn[v] += s[u][v] * trO;
-                    vstore<T, VEC>(p_pmean + ((size_t)b * n + i) * ld + j0, mn);
+                    for (int v = 0; v < VEC; v++) mn[v] += s_cur[u][v] * trO;
+                    vstore_stream<T, VEC>(p_pmean + ((size_t)b * n + i) * ld + j0, mn);
                 }
             }
             if (do_red) {
+                T rowsum = 0;
 #pragma unroll
                 for (int v = 0; v < VEC; v++) {
-                    if (mk[u][v] && j0 + v < m) {
-                        sum += (double)var[v];
-                        const long long idx = (long long)i * m + (j0 + v);
-                        if (a.want) {
-                            // scan order is increasing idx within a thread: strict compare
-                            // keeps the first occurrence
-                            if (besti < 0 || (a.want > 0 ? var[v] > bestv : var[v] < bestv)) {
-                                bestv = var[v];
-                                besti = idx;
-                            }
-                        }
+                    const bool cand = (mbits[v] >> r) & 1u;
+                    rowsum += cand ? var[v] : (T)0;
+                    if (a.want) {
+                        // rows then columns ascend within a lane: a strict compare keeps the
+                        // first occurrence
+                        const bool better = cand && (bestrow < 0 || (a.want > 0 ? var[v] > bestv : var[v] < bestv));
+                        bestv = better ? var[v] : bestv;
+                        bestrow = better ? i : bestrow;
+                        bestcol = better ? v : bestcol;
                     }
                 }
+                sum += (double)rowsum;
             }
         }
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) s_cur[u][v] = s_nxt[u][v];
     }
+#undef ROWOP
 
     if (do_red) {
         __shared__ double sh_sum[WAVES];
         __shared__ T sh_val[WAVES];
         __shared__ long long sh_idx[WAVES];
+        long long besti = bestrow < 0 ? -1 : (long long)bestrow * m + (j0 + bestcol);
         sum = wave_sum(sum);
         if (a.want) wave_argext(bestv, besti, a.want);
         if (lane == 0) { sh_sum[wave] = sum; sh_val[wave] = bestv; sh_idx[wave] = besti; }
@@ -279,7 +407,7 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
                 ts += sh_sum[w];
                 if (a.want) argext_merge(bv, bi, sh_val[w], sh_idx[w], a.want);
             }
-            const size_t slot = (size_t)b * a.nblk_x * a.nblk_y + (size_t)blockIdx.y * a.nblk_x + blockIdx.x;
+            const size_t slot = (size_t)b * per_state + tile;
             part_sum[slot] = ts;
             part_val[slot] = bv;
             part_idx[slot] = bi;
@@ -330,9 +458,11 @@ __global__ __launch_bounds__(256) void k_grid_finish(int nblk, int want, const d
 template <typename T, int D, int VEC>
 void launch_grid(const GridArgs<T> &a, hipStream_t st)
 {
-    dim3 grid(a.g.nblk_x, a.g.nblk_y, a.g.B);
+    const int per_state = a.g.nblk_x * a.g.nblk_y;
+    const long long groups = (a.g.B + 7) / 8;   // states are dealt to the 8 XCDs in groups of 8
+    dim3 grid((unsigned)(groups * per_state * 8));
     hipLaunchKernelGGL((k_mn_grid<T, D, VEC>), grid, dim3(256), 0, st, a.g, a.cross, a.rowpack,
-                       a.colpack, a.state, a.mask, a.var, a.pmean, a.part_sum, a.part_val,
+                       a.colpack, a.state, a.maskT, a.var, a.pmean, a.part_sum, a.part_val,
                        a.part_idx);
 }
 
@@ -438,12 +568,25 @@ int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_
     a.part_idx = (long long *)(a.part_sum + (size_t)B * nblk);
     a.part_val = (T *)(a.part_idx + (size_t)B * nblk);
 
-    hipLaunchKernelGGL((k_mn_prep<T>), dim3((n + ld + 255) / 256, B), dim3(256), 0, ctx->stream, B,
-                       n, m, d, D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+    const int prep_rows = d <= 16 ? 256 : 64;
+    const size_t prep_smem = (size_t)prep_rows * (size_t)(d | 1) * sizeof(T);
+    hipLaunchKernelGGL((k_mn_prep<T>), dim3((n + ld + prep_rows - 1) / prep_rows, B), dim3(prep_rows),
+                       prep_smem, ctx->stream, B, n, m, d, D, ld, rs, d_mean, d_diag, d_omega, rowpack,
+                       colpack, state);
     APMF_CHECK_LAUNCH();
+    const uint16_t *maskT = nullptr;
+    if (d_mask && (want != 0 || d_sum)) {
+        const int ngrp = (n + 15) / 16;
+        void *w2;
+        APMF_TRY(apmf_ws(ctx, 2, (size_t)ngrp * ld * sizeof(uint16_t) + 64, &w2));
+        hipLaunchKernelGGL(k_mask_pack, dim3((ld + 255) / 256, ngrp), dim3(256), 0, ctx->stream, n, ld,
+                           d_mask, (uint16_t *)w2);
+        APMF_CHECK_LAUNCH();
+        maskT = (const uint16_t *)w2;
+    }
 
     a.cross = d_cross; a.rowpack = rowpack; a.colpack = colpack; a.state = state;
-    a.mask = d_mask; a.var = d_var; a.pmean = d_pmean; a.g.want = want; a.g.want_sum = d_sum != nullptr;
+    a.maskT = maskT; a.var = d_var; a.pmean = d_pmean; a.g.want = want; a.g.want_sum = d_sum != nullptr;
     int rc;
     {
         ProfScope prof(ctx);
