@@ -59,6 +59,8 @@ _SIGS = {
     'apmf_ratings_destroy': (_i, [_vp, _vp]),
     'apmf_ratings_count': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
     'apmf_pmf_gradient': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, _vp, _vp]),
+    'apmf_pmf_gradient_rows': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, _vp]),
+    'apmf_pmf_ll_terms': (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _i, _i, _i, _i, C.POINTER(_dbl)]),
     'apmf_pmf_log_likelihood': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl,
                                      C.POINTER(_dbl), C.POINTER(_dbl)]),
     'apmf_pmf_fit_lls': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, C.POINTER(_dbl),
@@ -76,6 +78,7 @@ _SIGS = {
                                         _i, C.POINTER(_i)]),
     'apmf_full_score_grid_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'apmf_gibbs_half_sweep': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
+    'apmf_gibbs_half_sweep_rows': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     'apmf_sample_stats_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
     'apmf_grid_gather_f64': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _vp]),
     'apmf_pool_argext_f64': (_i, [_vp, _vp, _i64, _i, C.POINTER(_i64), C.POINTER(_dbl)]),
@@ -304,6 +307,19 @@ class Context(object):
         _check(self._lib.apmf_pmf_gradient(self._h, rt._h, _ptr(dU), _ptr(dV), d, sig, sig_u, sig_v,
                                            int(bool(subtract_mean)), mean_rating, _ptr(dgU), _ptr(dgV)))
 
+    def pmf_gradient_rows(self, rt, side, lo, hi, dU, dV, d, sig, sig_u, sig_v, subtract_mean,
+                          mean_rating, dg):
+        _check(self._lib.apmf_pmf_gradient_rows(self._h, rt._h, side, lo, hi, _ptr(dU), _ptr(dV), d, sig,
+                                                sig_u, sig_v, int(bool(subtract_mean)), mean_rating,
+                                                _ptr(dg)))
+
+    def pmf_ll_terms(self, rt, dU, dV, d, subtract_mean, mean_rating, u_lo, u_hi, v_lo, v_hi):
+        t = (_dbl * 3)()
+        _check(self._lib.apmf_pmf_ll_terms(self._h, rt._h, _ptr(dU), _ptr(dV), d,
+                                           int(bool(subtract_mean)), mean_rating, u_lo, u_hi, v_lo, v_hi,
+                                           t))
+        return np.array(t[:], np.float64)
+
     def pmf_log_likelihood(self, rt, dU, dV, d, sig, sig_u, sig_v, subtract_mean, mean_rating):
         ll, sq = _dbl(), _dbl()
         _check(self._lib.apmf_pmf_log_likelihood(self._h, rt._h, _ptr(dU), _ptr(dV), d, sig, sig_u,
@@ -366,6 +382,11 @@ class Context(object):
     def gibbs_half_sweep(self, rt, side, oth, d, alpha, mu, beta, mean_sub, z, out):
         _check(self._lib.apmf_gibbs_half_sweep(self._h, rt._h, side, _ptr(oth), d, _ptr(alpha),
                                                _ptr(mu), beta, mean_sub, _ptr(z), _ptr(out)))
+
+    def gibbs_half_sweep_rows(self, rt, side, lo, hi, oth, d, alpha, mu, beta, mean_sub, z, out):
+        _check(self._lib.apmf_gibbs_half_sweep_rows(self._h, rt._h, side, lo, hi, _ptr(oth), d,
+                                                    _ptr(alpha), _ptr(mu), beta, mean_sub, _ptr(z),
+                                                    _ptr(out)))
 
     def sample_stats(self, S, n, m, d, ld, Us, Vs, add, cutoff, mean=None, var=None, prob=None):
         _check(self._lib.apmf_sample_stats_f64(self._h, S, n, m, d, ld, _ptr(Us), _ptr(Vs), add,

@@ -49,7 +49,8 @@ struct PmfParams {
 
 // gradient(): one wave per output row (users and items in one launch)
 template <int DP>
-__global__ __launch_bounds__(256) void k_pmf_grad(const PmfParams p, const int32_t *__restrict__ order,
+__global__ __launch_bounds__(256) void k_pmf_grad(const PmfParams p, int first_row, int nrows_launch,
+                                                  const int32_t *__restrict__ order,
                                                   const int64_t *__restrict__ ptr_u,
                                                   const int32_t *__restrict__ idx_u,
                                                   const double *__restrict__ val_u,
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void k_pmf_grad(const PmfParams p, const int32
     constexpr int G = 64 / DP;
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + wave_id_uniform();
-    if (slot >= p.n + p.m) return;
-    const int row_all = order[slot];  // wave-uniform
+    if (slot >= nrows_launch) return;
+    // whole model: rows in descending-nnz order (heaviest first); a shard: rows first_row..
+    const int row_all = order ? order[slot] : first_row + slot;  // wave-uniform
     const bool is_user = row_all < p.n;
     const int row = is_user ? row_all : row_all - p.n;
     const int64_t *ptr = is_user ? ptr_u : ptr_v;
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(256) void k_pmf_grad(const PmfParams p, const int32
 // sum of squared errors over the user-CSR (each rating once) + ||X||^2 of the rows this
 // wave owns; per-wave partials, combined later in a fixed order
 template <int DP>
-__global__ __launch_bounds__(256) void k_pmf_sqerr(const PmfParams p, const int64_t *__restrict__ ptr_u,
+__global__ __launch_bounds__(256) void k_pmf_sqerr(const PmfParams p, int u_lo, int u_hi, int v_lo, int v_hi,
+                                                   const int64_t *__restrict__ ptr_u,
                                                    const int32_t *__restrict__ idx_u,
                                                    const double *__restrict__ val_u,
                                                    const double *__restrict__ U,
@@ -115,16 +118,17 @@ __global__ __launch_bounds__(256) void k_pmf_sqerr(const PmfParams p, const int6
     constexpr int G = 64 / DP;
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + wave_id_uniform();
-    const int nrows = max(p.n, p.m);
+    const int nrows = max(u_hi - u_lo, v_hi - v_lo);
     if (slot >= nrows) return;
     const int d = p.d;
     const int k = lane % DP, g = lane / DP;
     const bool kok = k < d;
     double sq = 0., un = 0., vn = 0.;
-    if (slot < p.n) {
-        const double xk = kok ? U[(size_t)slot * d + k] : 0.;
+    if (u_lo + slot < u_hi) {
+        const int urow = u_lo + slot;
+        const double xk = kok ? U[(size_t)urow * d + k] : 0.;
         if (g == 0) un = xk * xk;
-        const int64_t beg = ptr_u[slot], end = ptr_u[slot + 1];
+        const int64_t beg = ptr_u[urow], end = ptr_u[urow + 1];
         for (int64_t t0 = beg + g; t0 < end; t0 += (int64_t)G * UN) {
             int32_t c[UN];
             double r[UN], y[UN];
@@ -146,8 +150,8 @@ __global__ __launch_bounds__(256) void k_pmf_sqerr(const PmfParams p, const int6
             }
         }
     }
-    if (slot < p.m && g == 0 && kok) {
-        const double vk = V[(size_t)slot * d + k];
+    if (v_lo + slot < v_hi && g == 0 && kok) {
+        const double vk = V[(size_t)(v_lo + slot) * d + k];
         vn = vk * vk;
     }
     sq = wave_sum(sq);
@@ -160,7 +164,8 @@ __global__ __launch_bounds__(256) void k_pmf_sqerr(const PmfParams p, const int6
     }
 }
 
-// fixed-order combine of the per-row partials -> out[0] = LL, out[1] = sq_error
+// fixed-order combine of the per-row partials -> out[0] = LL, out[1] = sq_error,
+// out[2] = ||U||^2, out[3] = ||V||^2 (over the launched ranges)
 __global__ __launch_bounds__(256) void k_pmf_ll_finish(int nslots, const double *__restrict__ part,
                                                        double sig, double sig_u, double sig_v,
                                                        double *__restrict__ out)
@@ -182,6 +187,8 @@ __global__ __launch_bounds__(256) void k_pmf_ll_finish(int nslots, const double 
     if (threadIdx.x == 0) {
         out[0] = -sh[0][0] / (2. * sig) - sh[1][0] / (2. * sig_u) - sh[2][0] / (2. * sig_v);
         out[1] = sh[0][0];
+        out[2] = sh[1][0];
+        out[3] = sh[2][0];
     }
 }
 
@@ -320,13 +327,16 @@ int check_common(apmf_ctx *ctx, const apmf_ratings *r, int d, double sigma_sq, d
 }
 
 int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const double *U,
-                const double *V, double *gU, double *gV)
+                const double *V, double *gU, double *gV, int first_row = 0, int nrows = -1)
 {
-    const int rows = r->n + r->m;
+    const bool whole = nrows < 0;
+    const int rows = whole ? r->n + r->m : nrows;
+    if (rows == 0) return APMF_OK;
     const int blocks = (rows + 3) / 4;
     ProfScope prof(ctx);
     DISPATCH_DP(dp_for(p.d),
-                hipLaunchKernelGGL((k_pmf_grad<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p, r->order,
+                hipLaunchKernelGGL((k_pmf_grad<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p, first_row,
+                                   rows, whole ? r->order : (const int32_t *)nullptr,
                                    r->ptr[0], r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1],
                                    U, V, gU, gV));
     APMF_CHECK_LAUNCH();
@@ -335,13 +345,17 @@ int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const 
 
 // LL of (U, V) -> d_out2[0] = ll, d_out2[1] = sq_error (device), no sync
 int launch_ll(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, double sigma_sq,
-              const double *U, const double *V, double *d_part, double *d_out2)
+              const double *U, const double *V, double *d_part, double *d_out2, int u_lo = 0,
+              int u_hi = -1, int v_lo = 0, int v_hi = -1)
 {
-    const int nslots = std::max(r->n, r->m);
+    if (u_hi < 0) u_hi = r->n;
+    if (v_hi < 0) v_hi = r->m;
+    const int nslots = std::max(std::max(u_hi - u_lo, v_hi - v_lo), 1);
     const int blocks = (nslots + 3) / 4;
+    APMF_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nslots * 24, ctx->stream));
     DISPATCH_DP(dp_for(p.d),
-                hipLaunchKernelGGL((k_pmf_sqerr<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p,
-                                   r->ptr[0], r->idx[0], r->val[0], U, V, d_part));
+                hipLaunchKernelGGL((k_pmf_sqerr<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p, u_lo,
+                                   u_hi, v_lo, v_hi, r->ptr[0], r->idx[0], r->val[0], U, V, d_part));
     APMF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_pmf_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nslots, d_part, sigma_sq,
                        p.sig_u, p.sig_v, d_out2);
@@ -470,7 +484,7 @@ int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *
     const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
     const int nslots = std::max(r->n, r->m);
     void *w;
-    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 64, &w));
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 128, &w));
     double *d_part = (double *)w;
     double *d_out2 = d_part + (size_t)nslots * 3;
     APMF_TRY(launch_ll(ctx, r, p, sigma_sq, d_U, d_V, d_part, d_out2));
@@ -478,6 +492,46 @@ int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *
     APMF_TRY(apmf_d2h(ctx, h, d_out2, sizeof(h)));
     if (h_ll) *h_ll = h[0];
     if (h_sq_error) *h_sq_error = h[1];
+    return APMF_OK;
+}
+
+int apmf_pmf_gradient_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo, int row_hi,
+                           const double *d_U, const double *d_V, int d, double sigma_sq,
+                           double sigma_u_sq, double sigma_v_sq, int subtract_mean,
+                           double mean_rating, double *d_g)
+{
+    APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
+    APMF_REQUIRE(d_U && d_V && d_g, "NULL operand");
+    APMF_REQUIRE(side == 0 || side == 1, "side must be 0 (users) or 1 (items)");
+    const int rows = side == 0 ? r->n : r->m;
+    APMF_REQUIRE(0 <= row_lo && row_lo <= row_hi && row_hi <= rows, "row range [%d,%d) outside [0,%d)",
+                 row_lo, row_hi, rows);
+    const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
+    return launch_grad(ctx, r, p, d_U, d_V, side == 0 ? d_g : (double *)nullptr,
+                       side == 1 ? d_g : (double *)nullptr, side == 0 ? row_lo : r->n + row_lo,
+                       row_hi - row_lo);
+}
+
+int apmf_pmf_ll_terms(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V, int d,
+                      int subtract_mean, double mean_rating, int user_lo, int user_hi, int item_lo,
+                      int item_hi, double *h_terms3)
+{
+    APMF_TRY(check_common(ctx, r, d, 1., 1., 1.));
+    APMF_REQUIRE(d_U && d_V && h_terms3, "NULL operand");
+    APMF_REQUIRE(0 <= user_lo && user_lo <= user_hi && user_hi <= r->n && 0 <= item_lo &&
+                     item_lo <= item_hi && item_hi <= r->m, "bad row ranges");
+    const PmfParams p = make_params(r, d, 1., 1., 1., subtract_mean, mean_rating);
+    const int nslots = std::max(std::max(user_hi - user_lo, item_hi - item_lo), 1);
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 128, &w));
+    double *d_part = (double *)w;
+    double *d_out = d_part + (size_t)nslots * 3;
+    APMF_TRY(launch_ll(ctx, r, p, 1., d_U, d_V, d_part, d_out, user_lo, user_hi, item_lo, item_hi));
+    double h[4];
+    APMF_TRY(apmf_d2h(ctx, h, d_out, sizeof(h)));
+    h_terms3[0] = h[1];
+    h_terms3[1] = h[2];
+    h_terms3[2] = h[3];
     return APMF_OK;
 }
 
@@ -496,7 +550,7 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     // workspace 0: gU gV | trial U V ; workspace 1: partials + 2 outputs
     void *w0, *w1;
     APMF_TRY(apmf_ws(ctx, 0, (2 * (nu + nv)) * 8 + 64, &w0));
-    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 64, &w1));
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 128, &w1));
     double *gU = (double *)w0, *gV = gU + nu, *tU = gV + nv, *tV = tU + nu;
     double *d_part = (double *)w1, *d_out2 = d_part + (size_t)nslots * 3;
     void *pin;

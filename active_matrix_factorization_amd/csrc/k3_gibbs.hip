@@ -42,7 +42,7 @@ __device__ __forceinline__ bool chol_lds(double *A, int d, int lda, int lane)
 }
 
 template <int NSLOT>
-__global__ __launch_bounds__(64) void k_gibbs_rows(int rows, int d, const int64_t *__restrict__ ptr,
+__global__ __launch_bounds__(64) void k_gibbs_rows(int row_lo, int rows, int d, const int64_t *__restrict__ ptr,
                                                    const int32_t *__restrict__ idx,
                                                    const double *__restrict__ val,
                                                    const double *__restrict__ oth,
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void k_gibbs_rows(int rows, int d, const int64_
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
-    const int row = blockIdx.x;
+    const int row = row_lo + blockIdx.x;
     if (row >= rows) return;
     const int lda = d + 1;
     double *Fs = smem;                    // CH x d
@@ -168,9 +168,36 @@ size_t gibbs_smem(int d)
 
 } // namespace
 
+static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo, int row_hi,
+                      const double *d_oth, int d, const double *d_alpha, const double *d_mu, double beta,
+                      double mean_sub, const double *d_z, double *d_out);
+
 extern "C" int apmf_gibbs_half_sweep(apmf_ctx *ctx, const apmf_ratings *r, int side, const double *d_oth,
                                      int d, const double *d_alpha, const double *d_mu, double beta,
                                      double mean_sub, const double *d_z, double *d_out)
+{
+    APMF_REQUIRE(ctx && r, "ctx/ratings is NULL");
+    APMF_REQUIRE(side == 0 || side == 1, "side must be 0 (users) or 1 (items)");
+    return gibbs_rows(ctx, r, side, 0, side == 0 ? r->n : r->m, d_oth, d, d_alpha, d_mu, beta, mean_sub,
+                      d_z, d_out);
+}
+
+extern "C" int apmf_gibbs_half_sweep_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo,
+                                          int row_hi, const double *d_oth, int d, const double *d_alpha,
+                                          const double *d_mu, double beta, double mean_sub,
+                                          const double *d_z, double *d_out)
+{
+    APMF_REQUIRE(ctx && r, "ctx/ratings is NULL");
+    APMF_REQUIRE(side == 0 || side == 1, "side must be 0 (users) or 1 (items)");
+    const int rows = side == 0 ? r->n : r->m;
+    APMF_REQUIRE(0 <= row_lo && row_lo <= row_hi && row_hi <= rows, "row range [%d,%d) outside [0,%d)",
+                 row_lo, row_hi, rows);
+    return gibbs_rows(ctx, r, side, row_lo, row_hi, d_oth, d, d_alpha, d_mu, beta, mean_sub, d_z, d_out);
+}
+
+static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo, int row_hi,
+                      const double *d_oth, int d, const double *d_alpha, const double *d_mu, double beta,
+                      double mean_sub, const double *d_z, double *d_out)
 {
     APMF_REQUIRE(ctx && r, "ctx/ratings is NULL");
     APMF_REQUIRE(side == 0 || side == 1, "side must be 0 (users) or 1 (items)");
@@ -179,7 +206,7 @@ extern "C" int apmf_gibbs_half_sweep(apmf_ctx *ctx, const apmf_ratings *r, int s
     // bayes_pmf.py:287,296: items_by_user[user_id] raises KeyError for a row without ratings
     APMF_REQUIRE(!r->has_empty[side], "a %s has no rating: the Gibbs sweep needs >= 1 per row",
                  side == 0 ? "user" : "item");
-    const int rows = side == 0 ? r->n : r->m;
+    if (row_hi == row_lo) return APMF_OK;
     void *w;
     APMF_TRY(apmf_ws(ctx, 2, 64, &w));
     int *d_status = (int *)w;
@@ -188,7 +215,8 @@ extern "C" int apmf_gibbs_half_sweep(apmf_ctx *ctx, const apmf_ratings *r, int s
     const int nslot = (npairs + 63) / 64;
     const size_t smem = gibbs_smem(d);
 #define LAUNCH_GIBBS(NS)                                                                          \
-    hipLaunchKernelGGL((k_gibbs_rows<NS>), dim3(rows), dim3(64), smem, ctx->stream, rows, d,      \
+    hipLaunchKernelGGL((k_gibbs_rows<NS>), dim3(row_hi - row_lo), dim3(64), smem, ctx->stream,    \
+                       row_lo, row_hi, d,                                                         \
                        r->ptr[side], r->idx[side], r->val[side], d_oth, d_alpha, d_mu, beta,      \
                        mean_sub, d_z, d_out, d_status)
     if (smem > 64 * 1024)

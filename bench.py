@@ -106,7 +106,10 @@ def main():
         return float(t[0])
 
     from active_matrix_factorization_amd import _lib
-    ctx = _lib.Context(local_rank)
+    dev = local_rank
+    if os.environ.get('APMF_BENCH_SHARE_GPU'):   # rehearsal of N > 1 on a one-GPU box only
+        dev = local_rank % max(_lib.device_count(), 1)
+    ctx = _lib.Context(dev)
     n, m, d, B = N_USERS, N_ITEMS, LATENT_D, args.states
     ld = _lib.grid_ld(m)
     K, W = args.steps, args.warmup

@@ -98,6 +98,19 @@ int apmf_ratings_count(const apmf_ratings *r, int64_t *N, int *n, int *m);
 int apmf_pmf_gradient(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V,
                       int d, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
                       int subtract_mean, double mean_rating, double *d_gU, double *d_gV);
+/* Row-sharded gradient (multi-GPU): only rows [row_lo, row_hi) of one side
+ * (0 = users -> rows of grad_u, 1 = items -> rows of grad_v) are computed and written into
+ * the full-size d_g; every rank holds the whole ratings container and the whole U, V. */
+int apmf_pmf_gradient_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo, int row_hi,
+                           const double *d_U, const double *d_V, int d, double sigma_sq,
+                           double sigma_u_sq, double sigma_v_sq, int subtract_mean,
+                           double mean_rating, double *d_g);
+/* The three sums log_likelihood() is made of, restricted to a shard: h_terms3[0] = squared
+ * error over the ratings of users [user_lo, user_hi), [1] = ||U[user_lo:user_hi]||^2,
+ * [2] = ||V[item_lo:item_hi]||^2.  Summed over the shards they give pmf_cy.pyx:191-193. */
+int apmf_pmf_ll_terms(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V, int d,
+                      int subtract_mean, double mean_rating, int user_lo, int user_hi, int item_lo,
+                      int item_hi, double *h_terms3);
 /* log_likelihood(), pmf_cy.pyx:170-193 (h_ll) and the bare sum of squared errors that
  * update_sigma() needs, pmf_cy.pyx:225-234 (h_sq_error; either may be NULL). */
 int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U,
@@ -195,6 +208,13 @@ int apmf_full_score_grid_f64(apmf_ctx *ctx, int n, int m, int d, int ld, const d
 int apmf_gibbs_half_sweep(apmf_ctx *ctx, const apmf_ratings *r, int side, const double *d_oth,
                           int d, const double *d_alpha, const double *d_mu, double beta,
                           double mean_sub, const double *d_z, double *d_out);
+
+/* Row-sharded half-sweep: only rows [row_lo, row_hi) of `side` are resampled (d_z and d_out
+ * are indexed by the global row). */
+int apmf_gibbs_half_sweep_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo,
+                               int row_hi, const double *d_oth, int d, const double *d_alpha,
+                               const double *d_mu, double beta, double mean_sub,
+                               const double *d_z, double *d_out);
 
 /* ---- K4: statistics over S posterior samples (bayes_pmf.py:433-448, 528-538) -----------
  * predict / pred_variance / prob_ge_cutoff: per (i, j) the mean, the variance (ddof 0) and

@@ -1,0 +1,47 @@
+"""Test-only row-block engine over the CPU oracle, with the interface of
+active_matrix_factorization_amd.sharding.HipEngine.  It lets the world_size-2 gloo tests
+exercise the sharding / exchange logic on a machine without a GPU.  Never used by the product."""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+class OracleEngine(object):
+    def __init__(self, ratings, n, m, d, sigma_sq=1., sigma_u_sq=10., sigma_v_sq=10.,
+                 subtract_mean=False, mean_rating=0.):
+        self.ratings, self.n, self.m, self.d = np.asarray(ratings, float), n, m, d
+        self.kw = dict(sig=sigma_sq, sig_u=sigma_u_sq, sig_v=sigma_v_sq, subtract_mean=subtract_mean,
+                       mean_rating=mean_rating)
+
+    def grad_rows(self, side, lo, hi, U, V):
+        gU, gV = orc.pmf_gradient(self.ratings, U, V, **self.kw)
+        return (gU if side == 0 else gV)[lo:hi]
+
+    def ll_terms(self, U, V, u_lo, u_hi, v_lo, v_hi):
+        r = self.ratings
+        sel = r[(r[:, 0] >= u_lo) & (r[:, 0] < u_hi)]
+        sq = orc.pmf_sq_error(sel, U, V, self.kw['subtract_mean'], self.kw['mean_rating']) if len(sel) else 0.
+        return np.array([sq, (U[u_lo:u_hi] ** 2).sum(), (V[v_lo:v_hi] ** 2).sum()])
+
+    def gibbs_rows(self, side, lo, hi, oth, alpha, mu, beta, mean_sub, z):
+        rows = self.n if side == 0 else self.m
+        ptr, idx, rat = orc.csr_by_row(self.ratings, side, rows)
+        out = np.empty((hi - lo, self.d))
+        for t in range(lo, hi):
+            out[t - lo] = orc.sample_feature(oth, idx[ptr[t]:ptr[t + 1]], rat[ptr[t]:ptr[t + 1]], alpha,
+                                             mu, beta, mean_sub, z[t])
+        return out
+
+    def score_rows(self, mean_users, mean_items, cross_rows, diag_users, diag_items, omega, mask_rows,
+                   want):
+        nl, m = cross_rows.shape
+        if nl == 0:
+            return 0., 0., -1
+        _, pv = orc.mn_pred_means_vars_compact(nl, m, np.vstack([mean_users, mean_items]), cross_rows,
+                                               np.concatenate([diag_users, diag_items]), omega)
+        mask = np.ones((nl, m), bool) if mask_rows is None else mask_rows.astype(bool)
+        if not mask.any():
+            return 0., 0., -1
+        cand = np.where(mask, pv, -np.inf if want > 0 else np.inf)
+        k = int(np.argmax(cand)) if want > 0 else int(np.argmin(cand))
+        return float(pv[mask].sum()), float(cand.ravel()[k]), k
