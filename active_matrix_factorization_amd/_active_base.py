@@ -24,7 +24,10 @@ import numpy as np
 import scipy.linalg
 from scipy import stats
 
-from .pmf_cy import ProbabilisticMatrixFactorization
+try:
+    from .pmf_cy import ProbabilisticMatrixFactorization
+except ImportError:      # top-level import, like the reference's sibling modules
+    from pmf_cy import ProbabilisticMatrixFactorization
 
 
 # ---------------------------------------------------------------------------- helpers

@@ -8,7 +8,10 @@ import sys
 
 import numpy as np
 
-from .pmf_cy import parse_fit_type
+try:
+    from .pmf_cy import parse_fit_type
+except ImportError:
+    from pmf_cy import parse_fit_type
 
 
 def _bool_opt(parser, name, default=False):

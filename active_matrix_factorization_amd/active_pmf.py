@@ -15,11 +15,18 @@ import warnings
 
 import numpy as np
 
-from . import _lib
-from ._active_base import (_ActiveBase, _Evaluator, _criterion, minimize, make_key_funcs,
-                           query_loop, run_compare, strictmap)
-from .normal_exps_cy import quadexpect, exp_a2bc, exp_dotprod_sq, normal_gradient
-from .pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
+try:
+    from . import _lib
+    from ._active_base import (_ActiveBase, _Evaluator, _criterion, minimize, make_key_funcs,
+                               query_loop, run_compare, strictmap)
+    from .normal_exps_cy import quadexpect, exp_a2bc, exp_dotprod_sq, normal_gradient
+    from .pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
+except ImportError:      # top-level import (package directory on sys.path, like python-pmf/)
+    import _lib
+    from _active_base import (_ActiveBase, _Evaluator, _criterion, minimize, make_key_funcs,
+                              query_loop, run_compare, strictmap)
+    from normal_exps_cy import quadexpect, exp_a2bc, exp_dotprod_sq, normal_gradient
+    from pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
 
 ActivePMFEvaluator = _Evaluator
 
@@ -263,7 +270,10 @@ def compare(key_names, latent_d=5, processes=None, do_threading=True, steps=None
 
 
 def main():
-    from ._cli import run_cli
+    try:
+        from ._cli import run_cli
+    except ImportError:
+        from _cli import run_cli
     run_cli(KEY_FUNCS, compare, kind='full')
 
 

@@ -23,8 +23,12 @@ import warnings
 import numpy as np
 from scipy import stats, integrate
 
-from . import _lib
-from .pmf_cy import ProbabilisticMatrixFactorization, rmse, parse_fit_type  # noqa: F401
+try:
+    from . import _lib
+    from .pmf_cy import ProbabilisticMatrixFactorization, rmse, parse_fit_type  # noqa: F401
+except ImportError:      # top-level import (package directory on sys.path, like python-pmf/)
+    import _lib
+    from pmf_cy import ProbabilisticMatrixFactorization, rmse, parse_fit_type  # noqa: F401
 
 
 def sample_wishart(sigma, dof):
@@ -401,7 +405,10 @@ def compare_active(key_names, latent_d, real, ratings, rating_vals=None, discret
 
 
 def main():
-    from ._cli import run_bayes_cli
+    try:
+        from ._cli import run_bayes_cli
+    except ImportError:
+        from _cli import run_bayes_cli
     run_bayes_cli(KEYS, compare_active)
 
 

@@ -11,13 +11,22 @@ csrc/k2_score.hip), in float64 so that the selected indices match the reference.
 """
 import numpy as np
 
-from . import _lib
-from ._active_base import (_ActiveBase, _Evaluator, project_psd, strictmap, do_normal_fit,
-                           spawn_processes, nice_name, minimize, maximize, make_key_funcs,
-                           query_loop, run_compare)
-from .matrix_normal_exps_cy import (quadexpect, exp_a2bc, exp_dotprod_sq, mn_kl_divergence,
-                                    matrixnormal_gradient)
-from .pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
+try:
+    from . import _lib
+    from ._active_base import (_ActiveBase, _Evaluator, project_psd, strictmap, do_normal_fit,
+                               spawn_processes, nice_name, minimize, maximize, make_key_funcs,
+                               query_loop, run_compare)
+    from .matrix_normal_exps_cy import (quadexpect, exp_a2bc, exp_dotprod_sq, mn_kl_divergence,
+                                        matrixnormal_gradient)
+    from .pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
+except ImportError:      # top-level import (package directory on sys.path, like python-pmf/)
+    import _lib
+    from _active_base import (_ActiveBase, _Evaluator, project_psd, strictmap, do_normal_fit,
+                              spawn_processes, nice_name, minimize, maximize, make_key_funcs,
+                              query_loop, run_compare)
+    from matrix_normal_exps_cy import (quadexpect, exp_a2bc, exp_dotprod_sq, mn_kl_divergence,
+                                       matrixnormal_gradient)
+    from pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
 
 MNActivePMFEvaluator = _Evaluator
 
@@ -179,7 +188,10 @@ def compare(key_names, real, ratings, rating_vals=None, latent_d=5, knowable=Non
 
 
 def main():
-    from ._cli import run_cli
+    try:
+        from ._cli import run_cli
+    except ImportError:
+        from _cli import run_cli
     run_cli(KEY_FUNCS, compare, kind='mn')
 
 

@@ -15,7 +15,10 @@ from copy import deepcopy
 
 import numpy as np
 
-from . import _lib
+try:
+    from . import _lib
+except ImportError:      # imported as a top-level module (package dir on sys.path)
+    import _lib
 
 DTYPE = float
 

@@ -54,3 +54,19 @@ def test_product_never_imports_oracle():
                 assert 'oracle' not in src.replace('oracle/', '').lower() or fn == '__init__.py' or \
                     'import oracle' not in src and 'from oracle' not in src
                 assert 'from oracle' not in src and 'import oracle' not in src
+
+
+def test_modules_import_like_the_reference():
+    """The reference's scripts import their siblings by bare module name (python-pmf/ on
+    sys.path); the drop-in modules support that, and classes then pickle under the same
+    module.Class names as the reference's."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import pmf_cy, mn_active_pmf, active_pmf, bayes_pmf, "
+            "matrix_normal_exps_cy, normal_exps_cy; "
+            "assert mn_active_pmf.MNActivePMF.__module__ == 'mn_active_pmf'; "
+            "assert issubclass(bayes_pmf.BayesianPMF, pmf_cy.ProbabilisticMatrixFactorization); "
+            "assert mn_active_pmf.KEY_FUNCS['pred-variance'].chooser is max; print('ok')"
+            % os.path.join(ROOT, 'active_matrix_factorization_amd'))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr
