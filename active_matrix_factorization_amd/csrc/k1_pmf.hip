@@ -22,13 +22,33 @@
 
 namespace {
 
-constexpr int UN = 4;
+#ifndef APMF_K1_UN
+#define APMF_K1_UN 4
+#endif
+constexpr int UN = APMF_K1_UN;
 
+// DPP lane exchange inside a 16-lane row (VALU rate; no LDS crossbar round trip like
+// ds_bpermute).  CTRL: 0xB1 = quad_perm[1,0,3,2] (xor 1), 0x4E = quad_perm[2,3,0,1] (xor 2),
+// 0x141 = row_half_mirror (i <-> 7-i), 0x140 = row_mirror (i <-> 15-i).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// all-reduce (sum) over the DP lanes of a group; every lane of the group gets the total
 template <int DP>
 __device__ __forceinline__ double group_sum(double v)
 {
-#pragma unroll
-    for (int o = DP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (DP >= 2) v += dpp_move<0xB1>(v);
+    if (DP >= 4) v += dpp_move<0x4E>(v);
+    if (DP >= 8) v += dpp_move<0x141>(v);
+    if (DP >= 16) v += dpp_move<0x140>(v);
+    if (DP >= 32) v += __shfl_xor(v, 16, 64);
+    if (DP >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 
@@ -47,132 +67,201 @@ struct PmfParams {
     double mean_add;     // mean_rating if subtract_mean else 0
 };
 
-// gradient(): one wave per output row (users and items in one launch)
-template <int DP>
-__global__ __launch_bounds__(256) void k_pmf_grad(const PmfParams p, int first_row, int nrows_launch,
-                                                  const int32_t *__restrict__ order,
-                                                  const int64_t *__restrict__ ptr_u,
-                                                  const int32_t *__restrict__ idx_u,
-                                                  const double *__restrict__ val_u,
-                                                  const int64_t *__restrict__ ptr_v,
-                                                  const int32_t *__restrict__ idx_v,
-                                                  const double *__restrict__ val_v,
-                                                  const double *__restrict__ U,
-                                                  const double *__restrict__ V,
-                                                  double *__restrict__ gU, double *__restrict__ gV)
+// ---- fit_lls state kept on the device (apmf_pmf_fit_lls) -----------------------------------
+// The host enqueues iterations {gradient (if needed) -> trial point + its LL sums -> decide}
+// back to back and only reads this 64-byte state every few iterations: no round trip per trial.
+struct FitState {
+    double lr, old_ll, min_lr, stop_thresh;
+    long long steps, max_steps, max_trace;
+    int cur;        // which factor buffer pair holds the current point (0: caller's arrays)
+    int need_grad;  // the point moved: recompute the gradient before the next trial
+    int converged;
+    int pad;
+};
+
+__device__ __forceinline__ bool fit_done(const FitState *s)
+{
+    return s->converged || (s->max_steps >= 0 && s->steps >= s->max_steps);
+}
+
+// One pass over (a share of) one CSR row.  The row's own vector is xk (lane k of every
+// group); for each rating the other side's row y is gathered - at the trial point
+// fl(Y + fl(lr * gY)) when TRIAL - and the prediction formed with a DP-lane reduce.
+//   GRAD : returns this wave's share of  sum_t y_t * (r_t - pred_t) / sigma^2   (lane k)
+//   !GRAD: returns this wave's share of  sum_t (r_t - pred_t)^2                 (lanes k == 0)
+// WPR waves share a row: wave `sub` takes ratings sub*G + g, + WPR*G, ...
+template <int DP, int WPR, bool TRIAL, bool GRAD>
+__device__ __forceinline__ double row_pass(const PmfParams &p, int lane, int sub, int64_t beg, int64_t end,
+                                           const int32_t *__restrict__ idx,
+                                           const double *__restrict__ val, double xk,
+                                           const double *Y, const double *gY, double lr)
 {
     constexpr int G = 64 / DP;
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + wave_id_uniform();
-    if (slot >= nrows_launch) return;
-    // whole model: rows in descending-nnz order (heaviest first); a shard: rows first_row..
-    const int row_all = order ? order[slot] : first_row + slot;  // wave-uniform
-    const bool is_user = row_all < p.n;
-    const int row = is_user ? row_all : row_all - p.n;
-    const int64_t *ptr = is_user ? ptr_u : ptr_v;
-    const int32_t *idx = is_user ? idx_u : idx_v;
-    const double *val = is_user ? val_u : val_v;
-    const double *X = is_user ? U : V, *Y = is_user ? V : U;
-    double *gout = is_user ? gU : gV;
+    constexpr int STRIDE = WPR * G;
     const int d = p.d;
     const int k = lane % DP, g = lane / DP;
     const bool kok = k < d;
-    const double xk = kok ? X[(size_t)row * d + k] : 0.;
-    const int64_t beg = ptr[row], end = ptr[row + 1];
     double acc = 0.;
-    for (int64_t t0 = beg + g; t0 < end; t0 += (int64_t)G * UN) {
+    for (int64_t t0 = beg + sub * G + g; t0 < end; t0 += (int64_t)STRIDE * UN) {
         int32_t c[UN];
         double r[UN], y[UN];
         bool ok[UN];
 #pragma unroll
         for (int u = 0; u < UN; u++) {
-            const int64_t t = t0 + (int64_t)u * G;
+            const int64_t t = t0 + (int64_t)u * STRIDE;
             ok[u] = t < end;
             c[u] = ok[u] ? idx[t] : 0;
             r[u] = ok[u] ? val[t] : 0.;
         }
 #pragma unroll
-        for (int u = 0; u < UN; u++) y[u] = (ok[u] && kok) ? Y[(size_t)c[u] * d + k] : 0.;
+        for (int u = 0; u < UN; u++) {
+            const size_t oy = (size_t)c[u] * d + k;
+            if (TRIAL) y[u] = (ok[u] && kok) ? __dadd_rn(Y[oy], __dmul_rn(lr, gY[oy])) : 0.;
+            else y[u] = (ok[u] && kok) ? Y[oy] : 0.;
+        }
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             const double pred = group_sum<DP>(xk * y[u]) + p.mean_add;
-            const double w = ok[u] ? (r[u] - pred) / p.sig : 0.;
-            acc += y[u] * w;
+            if (GRAD) {
+                const double w = ok[u] ? (r[u] - pred) / p.sig : 0.;
+                acc += y[u] * w;
+            } else {
+                const double e = ok[u] ? (r[u] - pred) : 0.;
+                if (k == 0) acc += e * e;
+            }
         }
     }
-    acc = cross_group_sum<DP>(acc);
-    if (g == 0 && kok) gout[(size_t)row * d + k] = -xk / (is_user ? p.sig_u : p.sig_v) + acc;
+    return acc;
 }
 
-// sum of squared errors over the user-CSR (each rating once) + ||X||^2 of the rows this
-// wave owns; per-wave partials, combined later in a fixed order
-template <int DP>
-__global__ __launch_bounds__(256) void k_pmf_sqerr(const PmfParams p, int u_lo, int u_hi, int v_lo, int v_hi,
-                                                   const int64_t *__restrict__ ptr_u,
-                                                   const int32_t *__restrict__ idx_u,
-                                                   const double *__restrict__ val_u,
-                                                   const double *__restrict__ U,
-                                                   const double *__restrict__ V,
-                                                   double *__restrict__ part /* (nslots, 3) */)
+// gradient(), pmf_cy.pyx:204-223.  A block is 4 waves = 4/WPR output rows (users and items in
+// one launch); WPR waves split a long row and are combined through LDS in a fixed order.
+// st == nullptr: plain call on (U0, V0).  st != nullptr: fit_lls mode, the current point is
+// buffer pair st->cur and the launch is a no-op unless the point moved.
+template <int DP, int WPR>
+__global__ __launch_bounds__(256) void k_grad(const PmfParams p, const FitState *__restrict__ st,
+                                              int first_row, int nrows_launch,
+                                              const int32_t *__restrict__ order,
+                                              const int64_t *__restrict__ ptr_u,
+                                              const int32_t *__restrict__ idx_u,
+                                              const double *__restrict__ val_u,
+                                              const int64_t *__restrict__ ptr_v,
+                                              const int32_t *__restrict__ idx_v,
+                                              const double *__restrict__ val_v, const double *U0,
+                                              const double *V0, const double *U1, const double *V1,
+                                              double *__restrict__ gU, double *__restrict__ gV)
 {
-    constexpr int G = 64 / DP;
+    if (st && (fit_done(st) || !st->need_grad)) return;   // grid-uniform
+    constexpr int RPB = 4 / WPR;
+    __shared__ double sh[4][64];
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + wave_id_uniform();
+    const int wave = wave_id_uniform();
+    const int slot = blockIdx.x * RPB + wave / WPR;
+    const int sub = wave % WPR;
+    const bool valid = slot < nrows_launch;
+    const double *U = (st && st->cur) ? U1 : U0, *V = (st && st->cur) ? V1 : V0;
+    const int d = p.d;
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    int row = 0;
+    bool is_user = true;
+    double xk = 0., acc = 0.;
+    if (valid) {
+        // whole model: rows in descending-nnz order (heaviest first); a shard: rows first_row..
+        const int row_all = order ? order[slot] : first_row + slot;  // wave-uniform
+        is_user = row_all < p.n;
+        row = is_user ? row_all : row_all - p.n;
+        const int64_t *ptr = is_user ? ptr_u : ptr_v;
+        const double *X = is_user ? U : V;
+        xk = kok ? X[(size_t)row * d + k] : 0.;
+        acc = row_pass<DP, WPR, false, true>(p, lane, sub, ptr[row], ptr[row + 1],
+                                             is_user ? idx_u : idx_v, is_user ? val_u : val_v, xk,
+                                             is_user ? V : U, nullptr, 0.);
+        acc = cross_group_sum<DP>(acc);
+    }
+    if (WPR > 1) {
+        sh[wave][lane] = acc;
+        __syncthreads();
+        if (valid && sub == 0)
+#pragma unroll
+            for (int w = 1; w < WPR; w++) acc += sh[wave + w][lane];
+    }
+    if (valid && sub == 0 && g == 0 && kok)
+        (is_user ? gU : gV)[(size_t)row * d + k] = -xk / (is_user ? p.sig_u : p.sig_v) + acc;
+}
+
+// The three sums of log_likelihood() (pmf_cy.pyx:170-193) as per-wave partials: squared error
+// over the ratings of users [u_lo, u_hi) (each rating once) and the squared norms of the user
+// and item rows of the launched ranges.  TRIAL (fit_lls): the point is
+// fl(cur + fl(lr * grad)) (two roundings, like numpy's `users + lr * grad_u`,
+// pmf_cy.pyx:271-272), evaluated on the fly and written to the other buffer pair.
+template <int DP, int WPR, bool TRIAL>
+__global__ __launch_bounds__(256) void k_sqerr(const PmfParams p, const FitState *__restrict__ st, int u_lo,
+                                               int u_hi, int v_lo, int v_hi,
+                                               const int64_t *__restrict__ ptr_u,
+                                               const int32_t *__restrict__ idx_u,
+                                               const double *__restrict__ val_u, double *U0, double *V0,
+                                               double *U1, double *V1, const double *__restrict__ gU,
+                                               const double *__restrict__ gV,
+                                               double *__restrict__ part /* (nslots * WPR, 3) */)
+{
+    if (TRIAL && fit_done(st)) return;
+    constexpr int RPB = 4 / WPR;
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const int slot = blockIdx.x * RPB + wave / WPR;
+    const int sub = wave % WPR;
     const int nrows = max(u_hi - u_lo, v_hi - v_lo);
     if (slot >= nrows) return;
+    const double lr = TRIAL ? st->lr : 0.;
+    const bool cur1 = TRIAL && st->cur;
+    const double *U = cur1 ? U1 : U0, *V = cur1 ? V1 : V0;
+    double *tU = cur1 ? U0 : U1, *tV = cur1 ? V0 : V1;
     const int d = p.d;
     const int k = lane % DP, g = lane / DP;
     const bool kok = k < d;
     double sq = 0., un = 0., vn = 0.;
     if (u_lo + slot < u_hi) {
         const int urow = u_lo + slot;
-        const double xk = kok ? U[(size_t)urow * d + k] : 0.;
-        if (g == 0) un = xk * xk;
-        const int64_t beg = ptr_u[urow], end = ptr_u[urow + 1];
-        for (int64_t t0 = beg + g; t0 < end; t0 += (int64_t)G * UN) {
-            int32_t c[UN];
-            double r[UN], y[UN];
-            bool ok[UN];
-#pragma unroll
-            for (int u = 0; u < UN; u++) {
-                const int64_t t = t0 + (int64_t)u * G;
-                ok[u] = t < end;
-                c[u] = ok[u] ? idx_u[t] : 0;
-                r[u] = ok[u] ? val_u[t] : 0.;
-            }
-#pragma unroll
-            for (int u = 0; u < UN; u++) y[u] = (ok[u] && kok) ? V[(size_t)c[u] * d + k] : 0.;
-#pragma unroll
-            for (int u = 0; u < UN; u++) {
-                const double pred = group_sum<DP>(xk * y[u]) + p.mean_add;
-                const double e = ok[u] ? (r[u] - pred) : 0.;
-                if (k == 0) sq += e * e;
-            }
+        const size_t o = (size_t)urow * d + k;
+        double xk = 0.;
+        if (kok) xk = TRIAL ? __dadd_rn(U[o], __dmul_rn(lr, gU[o])) : U[o];
+        if (sub == 0 && g == 0 && kok) {
+            if (TRIAL) tU[o] = xk;
+            un = xk * xk;
         }
+        sq = row_pass<DP, WPR, TRIAL, false>(p, lane, sub, ptr_u[urow], ptr_u[urow + 1], idx_u, val_u, xk,
+                                             V, gV, lr);
     }
-    if (v_lo + slot < v_hi && g == 0 && kok) {
-        const double vk = V[(size_t)(v_lo + slot) * d + k];
+    if (sub == 0 && v_lo + slot < v_hi && g == 0 && kok) {
+        const size_t o = (size_t)(v_lo + slot) * d + k;
+        const double vk = TRIAL ? __dadd_rn(V[o], __dmul_rn(lr, gV[o])) : V[o];
+        if (TRIAL) tV[o] = vk;
         vn = vk * vk;
     }
     sq = wave_sum(sq);
     un = wave_sum(un);
     vn = wave_sum(vn);
     if (lane == 0) {
-        part[(size_t)slot * 3 + 0] = sq;
-        part[(size_t)slot * 3 + 1] = un;
-        part[(size_t)slot * 3 + 2] = vn;
+        const size_t e = ((size_t)slot * WPR + sub) * 3;
+        part[e + 0] = sq;
+        part[e + 1] = un;
+        part[e + 2] = vn;
     }
 }
 
-// fixed-order combine of the per-row partials -> out[0] = LL, out[1] = sq_error,
-// out[2] = ||U||^2, out[3] = ||V||^2 (over the launched ranges)
-__global__ __launch_bounds__(256) void k_pmf_ll_finish(int nslots, const double *__restrict__ part,
-                                                       double sig, double sig_u, double sig_v,
-                                                       double *__restrict__ out)
+// fixed-order combine of the partials.  st == nullptr: out[0] = LL, out[1] = sq_error,
+// out[2] = ||U||^2, out[3] = ||V||^2.  st != nullptr: LL of the trial point, then accept / reject
+// exactly as pmf_cy.pyx:275-291.
+__global__ __launch_bounds__(256) void k_ll_finish(int nparts, FitState *__restrict__ st,
+                                                   const double *__restrict__ part, double sig,
+                                                   double sig_u, double sig_v, double *__restrict__ out,
+                                                   double *__restrict__ trace)
 {
+    if (st && fit_done(st)) return;
     __shared__ double sh[3][256];
     double a = 0, b = 0, c = 0;
-    for (int t = threadIdx.x; t < nslots; t += 256) {
+    for (int t = threadIdx.x; t < nparts; t += 256) {
         a += part[(size_t)t * 3];
         b += part[(size_t)t * 3 + 1];
         c += part[(size_t)t * 3 + 2];
@@ -184,26 +273,27 @@ __global__ __launch_bounds__(256) void k_pmf_ll_finish(int nslots, const double 
             for (int q = 0; q < 3; q++) sh[q][threadIdx.x] += sh[q][threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        out[0] = -sh[0][0] / (2. * sig) - sh[1][0] / (2. * sig_u) - sh[2][0] / (2. * sig_v);
+    if (threadIdx.x != 0) return;
+    const double ll = -sh[0][0] / (2. * sig) - sh[1][0] / (2. * sig_u) - sh[2][0] / (2. * sig_v);
+    if (!st) {
+        out[0] = ll;
         out[1] = sh[0][0];
         out[2] = sh[1][0];
         out[3] = sh[2][0];
+        return;
     }
-}
-
-// trial point of the learning-rate search: new = old + lr * grad (two roundings, like
-// numpy's `users + lr * grad_u`, pmf_cy.pyx:271-272)
-__global__ __launch_bounds__(256) void k_axpy2(size_t nu, size_t nv, double lr,
-                                               const double *__restrict__ U, const double *__restrict__ gU,
-                                               double *__restrict__ nU, const double *__restrict__ V,
-                                               const double *__restrict__ gV, double *__restrict__ nV)
-{
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; t < nu + nv; t += stride) {
-        if (t < nu) nU[t] = __dadd_rn(U[t], __dmul_rn(lr, gU[t]));
-        else nV[t - nu] = __dadd_rn(V[t - nu], __dmul_rn(lr, gV[t - nu]));
+    if (ll > st->old_ll) {
+        st->cur ^= 1;
+        st->lr *= 1.25;
+        if (ll - st->old_ll < st->stop_thresh) st->converged = 1;
+        if (st->steps < st->max_trace) trace[st->steps] = ll;
+        st->steps += 1;
+        st->old_ll = ll;
+        st->need_grad = 1;
+    } else {
+        st->lr *= .5;
+        st->need_grad = 0;
+        if (st->lr < st->min_lr) st->converged = 1;
     }
 }
 
@@ -296,14 +386,14 @@ int dp_for(int d)
     return dp;
 }
 
-#define DISPATCH_DP(dp, CALL)                 \
-    switch (dp) {                             \
-    case 4: { constexpr int DP = 4; CALL; } break;   \
-    case 8: { constexpr int DP = 8; CALL; } break;   \
-    case 16: { constexpr int DP = 16; CALL; } break; \
-    case 32: { constexpr int DP = 32; CALL; } break; \
-    case 64: { constexpr int DP = 64; CALL; } break; \
-    default: apmf_set_error("latent_d too large"); return APMF_EINVAL; \
+#define DISPATCH_DP(dp, ...)                                                   \
+    switch (dp) {                                                              \
+    case 4: { constexpr int DP = 4; __VA_ARGS__; } break;                      \
+    case 8: { constexpr int DP = 8; __VA_ARGS__; } break;                      \
+    case 16: { constexpr int DP = 16; __VA_ARGS__; } break;                    \
+    case 32: { constexpr int DP = 32; __VA_ARGS__; } break;                    \
+    case 64: { constexpr int DP = 64; __VA_ARGS__; } break;                    \
+    default: apmf_set_error("latent_d too large"); return APMF_EINVAL;         \
     }
 
 PmfParams make_params(const apmf_ratings *r, int d, double sigma_sq, double sigma_u_sq,
@@ -326,39 +416,61 @@ int check_common(apmf_ctx *ctx, const apmf_ratings *r, int d, double sigma_sq, d
     return APMF_OK;
 }
 
-int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const double *U,
-                const double *V, double *gU, double *gV, int first_row = 0, int nrows = -1)
+// waves per row: long rows (MovieLens-like: ~100 ratings per user) are split over 4 waves
+int wpr_for(const apmf_ratings *r)
+{
+    const int64_t rows = std::max(1, std::min(r->n, r->m));
+    return (r->N / rows) >= 48 ? 4 : 1;
+}
+
+#define DISPATCH_DP_WPR(dp, wpr, ...)                                           \
+    if ((wpr) == 4) { constexpr int WPR = 4; DISPATCH_DP(dp, __VA_ARGS__); }        \
+    else { constexpr int WPR = 1; DISPATCH_DP(dp, __VA_ARGS__); }
+
+int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const FitState *st,
+                const double *U0, const double *V0, const double *U1, const double *V1, double *gU,
+                double *gV, int first_row = 0, int nrows = -1)
 {
     const bool whole = nrows < 0;
     const int rows = whole ? r->n + r->m : nrows;
     if (rows == 0) return APMF_OK;
-    const int blocks = (rows + 3) / 4;
+    const int wpr = wpr_for(r);
+    const int blocks = (rows + (4 / wpr) - 1) / (4 / wpr);
     ProfScope prof(ctx);
-    DISPATCH_DP(dp_for(p.d),
-                hipLaunchKernelGGL((k_pmf_grad<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p, first_row,
-                                   rows, whole ? r->order : (const int32_t *)nullptr,
-                                   r->ptr[0], r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1],
-                                   U, V, gU, gV));
+    DISPATCH_DP_WPR(dp_for(p.d), wpr,
+                    hipLaunchKernelGGL((k_grad<DP, WPR>), dim3(blocks), dim3(256), 0, ctx->stream, p, st,
+                                       first_row, rows, whole ? r->order : (const int32_t *)nullptr,
+                                       r->ptr[0], r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1],
+                                       U0, V0, U1, V1, gU, gV));
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
 
-// LL of (U, V) -> d_out2[0] = ll, d_out2[1] = sq_error (device), no sync
+int ll_parts(const apmf_ratings *r, int u_lo, int u_hi, int v_lo, int v_hi)
+{
+    return std::max(std::max(u_hi - u_lo, v_hi - v_lo), 1) * wpr_for(r);
+}
+
+// LL of (U, V) -> d_out4 = {ll, sq_error, ||U||^2, ||V||^2} (device), no sync
 int launch_ll(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, double sigma_sq,
-              const double *U, const double *V, double *d_part, double *d_out2, int u_lo = 0,
+              const double *U, const double *V, double *d_part, double *d_out4, int u_lo = 0,
               int u_hi = -1, int v_lo = 0, int v_hi = -1)
 {
     if (u_hi < 0) u_hi = r->n;
     if (v_hi < 0) v_hi = r->m;
+    const int wpr = wpr_for(r);
     const int nslots = std::max(std::max(u_hi - u_lo, v_hi - v_lo), 1);
-    const int blocks = (nslots + 3) / 4;
-    APMF_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nslots * 24, ctx->stream));
-    DISPATCH_DP(dp_for(p.d),
-                hipLaunchKernelGGL((k_pmf_sqerr<DP>), dim3(blocks), dim3(256), 0, ctx->stream, p, u_lo,
-                                   u_hi, v_lo, v_hi, r->ptr[0], r->idx[0], r->val[0], U, V, d_part));
+    const int blocks = (nslots + (4 / wpr) - 1) / (4 / wpr);
+    APMF_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nslots * wpr * 24, ctx->stream));
+    DISPATCH_DP_WPR(dp_for(p.d), wpr,
+                    hipLaunchKernelGGL((k_sqerr<DP, WPR, false>), dim3(blocks), dim3(256), 0, ctx->stream, p,
+                                       (const FitState *)nullptr, u_lo, u_hi, v_lo, v_hi, r->ptr[0],
+                                       r->idx[0], r->val[0], const_cast<double *>(U),
+                                       const_cast<double *>(V), (double *)nullptr, (double *)nullptr,
+                                       (const double *)nullptr, (const double *)nullptr, d_part));
     APMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_pmf_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nslots, d_part, sigma_sq,
-                       p.sig_u, p.sig_v, d_out2);
+    hipLaunchKernelGGL(k_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nslots * wpr, (FitState *)nullptr,
+                       d_part, sigma_sq, p.sig_u, p.sig_v, d_out4, (double *)nullptr);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -471,7 +583,7 @@ int apmf_pmf_gradient(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, c
     APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
     APMF_REQUIRE(d_U && d_V && d_gU && d_gV, "NULL operand");
     const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
-    return launch_grad(ctx, r, p, d_U, d_V, d_gU, d_gV);
+    return launch_grad(ctx, r, p, nullptr, d_U, d_V, nullptr, nullptr, d_gU, d_gV);
 }
 
 int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U,
@@ -482,11 +594,11 @@ int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *
     APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
     APMF_REQUIRE(d_U && d_V, "NULL operand");
     const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
-    const int nslots = std::max(r->n, r->m);
+    const int nparts = ll_parts(r, 0, r->n, 0, r->m);
     void *w;
-    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 128, &w));
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nparts * 24 + 128, &w));
     double *d_part = (double *)w;
-    double *d_out2 = d_part + (size_t)nslots * 3;
+    double *d_out2 = d_part + (size_t)nparts * 3;
     APMF_TRY(launch_ll(ctx, r, p, sigma_sq, d_U, d_V, d_part, d_out2));
     double h[2];
     APMF_TRY(apmf_d2h(ctx, h, d_out2, sizeof(h)));
@@ -507,9 +619,9 @@ int apmf_pmf_gradient_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int r
     APMF_REQUIRE(0 <= row_lo && row_lo <= row_hi && row_hi <= rows, "row range [%d,%d) outside [0,%d)",
                  row_lo, row_hi, rows);
     const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
-    return launch_grad(ctx, r, p, d_U, d_V, side == 0 ? d_g : (double *)nullptr,
-                       side == 1 ? d_g : (double *)nullptr, side == 0 ? row_lo : r->n + row_lo,
-                       row_hi - row_lo);
+    return launch_grad(ctx, r, p, nullptr, d_U, d_V, nullptr, nullptr,
+                       side == 0 ? d_g : (double *)nullptr, side == 1 ? d_g : (double *)nullptr,
+                       side == 0 ? row_lo : r->n + row_lo, row_hi - row_lo);
 }
 
 int apmf_pmf_ll_terms(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V, int d,
@@ -521,11 +633,11 @@ int apmf_pmf_ll_terms(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, c
     APMF_REQUIRE(0 <= user_lo && user_lo <= user_hi && user_hi <= r->n && 0 <= item_lo &&
                      item_lo <= item_hi && item_hi <= r->m, "bad row ranges");
     const PmfParams p = make_params(r, d, 1., 1., 1., subtract_mean, mean_rating);
-    const int nslots = std::max(std::max(user_hi - user_lo, item_hi - item_lo), 1);
+    const int nparts = ll_parts(r, user_lo, user_hi, item_lo, item_hi);
     void *w;
-    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 128, &w));
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nparts * 24 + 128, &w));
     double *d_part = (double *)w;
-    double *d_out = d_part + (size_t)nslots * 3;
+    double *d_out = d_part + (size_t)nparts * 3;
     APMF_TRY(launch_ll(ctx, r, p, 1., d_U, d_V, d_part, d_out, user_lo, user_hi, item_lo, item_hi));
     double h[4];
     APMF_TRY(apmf_d2h(ctx, h, d_out, sizeof(h)));
@@ -547,65 +659,72 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
     const size_t nu = (size_t)r->n * d, nv = (size_t)r->m * d;
     const int nslots = std::max(r->n, r->m);
-    // workspace 0: gU gV | trial U V ; workspace 1: partials + 2 outputs
+    const int wpr = wpr_for(r);
+    const int nparts = nslots * wpr;
+    const int64_t trace_cap = max_trace < 0 ? 0 : max_trace;
+    // workspace 0: gU gV | second factor buffer pair | trace ; workspace 1: partials, outputs, state
     void *w0, *w1;
-    APMF_TRY(apmf_ws(ctx, 0, (2 * (nu + nv)) * 8 + 64, &w0));
-    APMF_TRY(apmf_ws(ctx, 1, (size_t)nslots * 24 + 128, &w1));
-    double *gU = (double *)w0, *gV = gU + nu, *tU = gV + nv, *tV = tU + nu;
-    double *d_part = (double *)w1, *d_out2 = d_part + (size_t)nslots * 3;
+    APMF_TRY(apmf_ws(ctx, 0, (2 * (nu + nv) + (size_t)trace_cap) * 8 + 64, &w0));
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nparts * 24 + 128 + sizeof(FitState) + 64, &w1));
+    double *gU = (double *)w0, *gV = gU + nu, *tU = gV + nv, *tV = tU + nu, *d_trace = tV + nv;
+    double *d_part = (double *)w1, *d_out2 = d_part + (size_t)nparts * 3;
+    FitState *d_state = (FitState *)(d_out2 + 8);
     void *pin;
-    APMF_TRY(apmf_pinned(ctx, 64, &pin));
-    volatile double *h2 = (volatile double *)pin;
+    APMF_TRY(apmf_pinned(ctx, 256, &pin));
+    FitState *h_state = (FitState *)pin;
 
-    auto eval_ll = [&](const double *U, const double *V, double *out) -> int {
-        APMF_TRY(launch_ll(ctx, r, p, sigma_sq, U, V, d_part, d_out2));
-        APMF_CHECK_HIP(hipMemcpyAsync((void *)h2, d_out2, 16, hipMemcpyDeviceToHost, ctx->stream));
-        APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-        *out = h2[0];
-        return APMF_OK;
-    };
-
-    // the current point lives in (cU, cV); trial points are written to (oU, oV); an accepted
-    // step swaps the roles instead of copying (the reference rebinds self.users / self.items)
-    double *cU = d_U, *cV = d_V, *oU = tU, *oV = tV;
-    double lr = *h_lr, old_ll;
+    double old_ll;
     if (h_old_ll && *h_old_ll == *h_old_ll) old_ll = *h_old_ll;
-    else APMF_TRY(eval_ll(cU, cV, &old_ll));
-    int64_t steps = 0;
-    bool converged = false;
-    const int ax_blocks = (int)std::min<size_t>((nu + nv + 255) / 256, 2048);
-    while (!converged && (max_steps < 0 || steps < max_steps)) {
-        APMF_TRY(launch_grad(ctx, r, p, cU, cV, gU, gV));
-        for (;;) {
-            hipLaunchKernelGGL(k_axpy2, dim3(ax_blocks), dim3(256), 0, ctx->stream, nu, nv, lr, cU, gU, oU,
-                               cV, gV, oV);
-            APMF_CHECK_LAUNCH();
-            double new_ll;
-            APMF_TRY(eval_ll(oU, oV, &new_ll));
-            if (new_ll > old_ll) {
-                std::swap(cU, oU);
-                std::swap(cV, oV);
-                lr *= 1.25;
-                if (new_ll - old_ll < stop_thresh) converged = true;
-                if (steps < max_trace) h_ll_trace[steps] = new_ll;
-                steps++;
-                old_ll = new_ll;
-                break;
-            } else {
-                lr *= .5;
-                if (lr < min_learning_rate) { converged = true; break; }
-            }
+    else {
+        // LL of the starting point (fit_lls computes it once before its loop, pmf_cy.pyx:261)
+        APMF_TRY(launch_ll(ctx, r, p, sigma_sq, d_U, d_V, d_part, d_out2));
+        APMF_CHECK_HIP(hipMemcpyAsync(pin, d_out2, 16, hipMemcpyDeviceToHost, ctx->stream));
+        APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        old_ll = ((volatile double *)pin)[0];
+    }
+    memset(h_state, 0, sizeof(FitState));
+    h_state->lr = *h_lr;
+    h_state->old_ll = old_ll;
+    h_state->min_lr = min_learning_rate;
+    h_state->stop_thresh = stop_thresh;
+    h_state->max_steps = max_steps;
+    h_state->max_trace = trace_cap;
+    h_state->need_grad = 1;
+    APMF_CHECK_HIP(hipMemcpyAsync(d_state, h_state, sizeof(FitState), hipMemcpyHostToDevice, ctx->stream));
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the pinned block is reused for read-backs
+
+    const int t_blocks = (nslots + (4 / wpr) - 1) / (4 / wpr);
+    const int dp = dp_for(d);
+    for (;;) {
+        const long long remaining = max_steps < 0 ? 1 << 20 : max_steps - h_state->steps;
+        const int chunk = (int)std::min<long long>(std::max<long long>(remaining + 1, 2), 16);
+        for (int it = 0; it < chunk; it++) {
+            APMF_TRY(launch_grad(ctx, r, p, d_state, d_U, d_V, tU, tV, gU, gV));
+            DISPATCH_DP_WPR(dp, wpr,
+                            hipLaunchKernelGGL((k_sqerr<DP, WPR, true>), dim3(t_blocks), dim3(256), 0,
+                                               ctx->stream, p, d_state, 0, r->n, 0, r->m, r->ptr[0],
+                                               r->idx[0], r->val[0], d_U, d_V, tU, tV, gU, gV, d_part));
+            hipLaunchKernelGGL(k_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nparts, d_state, d_part,
+                               sigma_sq, sigma_u_sq, sigma_v_sq, (double *)nullptr, d_trace);
         }
+        APMF_CHECK_LAUNCH();
+        APMF_CHECK_HIP(hipMemcpyAsync(h_state, d_state, sizeof(FitState), hipMemcpyDeviceToHost, ctx->stream));
+        APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_state->converged || (max_steps >= 0 && h_state->steps >= max_steps)) break;
     }
-    if (cU != d_U) {
-        APMF_CHECK_HIP(hipMemcpyAsync(d_U, cU, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        APMF_CHECK_HIP(hipMemcpyAsync(d_V, cV, nv * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    const FitState fin = *h_state;
+    if (fin.cur) {
+        APMF_CHECK_HIP(hipMemcpyAsync(d_U, tU, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        APMF_CHECK_HIP(hipMemcpyAsync(d_V, tV, nv * 8, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    const int64_t ntr = std::min<int64_t>(fin.steps, trace_cap);
+    if (ntr > 0)
+        APMF_CHECK_HIP(hipMemcpyAsync(h_ll_trace, d_trace, (size_t)ntr * 8, hipMemcpyDeviceToHost, ctx->stream));
     APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    *h_lr = lr;
-    if (h_old_ll) *h_old_ll = old_ll;
-    *h_steps = steps;
-    if (h_converged) *h_converged = converged ? 1 : 0;
+    *h_lr = fin.lr;
+    if (h_old_ll) *h_old_ll = fin.old_ll;
+    *h_steps = fin.steps;
+    if (h_converged) *h_converged = fin.converged ? 1 : 0;
     return APMF_OK;
 }
 

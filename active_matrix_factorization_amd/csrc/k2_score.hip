@@ -81,9 +81,10 @@ struct GridArgs {
 
 // ---- per-state operand packs ------------------------------------------------------
 // One thread per row of M (users -> rowpack, items -> colpack).  The block's rows of M are
-// staged in LDS (coalesced fetch, conflict-free per-row reads); Omega entries are
+// staged in LDS (coalesced fetch, conflict-free per-row reads) and then held in registers
+// (DT = compile-time latent-dimension bound, 0 = generic loop over LDS); Omega entries are
 // wave-uniform operands (scalar loads); padding columns of colpack are zeroed.
-template <typename T>
+template <typename T, int DT>
 __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int D, int ld, int rs,
                                                  const T *__restrict__ mean,
                                                  const T *__restrict__ diag,
@@ -130,20 +131,45 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
     const T sd = diag[(size_t)b * (n + m) + t];
     T quad = 0;
     T *rp = rowpack + ((size_t)b * n + t) * rs;
-    for (int k = 0; k < D; k++) {
-        T w = 0, ak = 0;
-        if (k < d) {
-            ak = a[k];
-            // the reference only reads Omega[k, l] with k <= l: mirror the upper triangle
-            for (int l = 0; l < k; l++) w += O[l * d + k] * a[l];
-            for (int l = k; l < d; l++) w += O[k * d + l] * a[l];
-            quad += ak * w;
+    if (DT > 0) {
+        // the row in registers, loops fully unrolled; the reference only reads Omega[k, l]
+        // with k <= l, so the upper triangle is mirrored
+        T av[DT > 0 ? DT : 1];
+#pragma unroll
+        for (int k = 0; k < DT; k++) av[k] = k < d ? a[k] : (T)0;
+#pragma unroll
+        for (int k = 0; k < DT; k++) {
+            T w = 0;
+            if (k < d) {
+#pragma unroll
+                for (int l = 0; l < DT; l++)
+                    if (l < d) w += O[l < k ? l * d + k : k * d + l] * av[l];
+                quad += av[k] * w;
+            }
+            if (k < D) {
+                if (is_user) { rp[k] = w; rp[D + k] = av[k]; }
+                else cp[(size_t)k * ld + j] = av[k];
+            }
         }
-        if (is_user) {
-            rp[k] = w;
-            rp[D + k] = ak;
-        } else {
-            cp[(size_t)k * ld + j] = ak;
+        for (int k = DT; k < D; k++) {
+            if (is_user) { rp[k] = 0; rp[D + k] = 0; }
+            else cp[(size_t)k * ld + j] = 0;
+        }
+    } else {
+        for (int k = 0; k < D; k++) {
+            T w = 0, ak = 0;
+            if (k < d) {
+                ak = a[k];
+                for (int l = 0; l < k; l++) w += O[l * d + k] * a[l];
+                for (int l = k; l < d; l++) w += O[k * d + l] * a[l];
+                quad += ak * w;
+            }
+            if (is_user) {
+                rp[k] = w;
+                rp[D + k] = ak;
+            } else {
+                cp[(size_t)k * ld + j] = ak;
+            }
         }
     }
     if (is_user) {
@@ -570,9 +596,19 @@ int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_
 
     const int prep_rows = d <= 16 ? 256 : 64;
     const size_t prep_smem = (size_t)prep_rows * (size_t)(d | 1) * sizeof(T);
-    hipLaunchKernelGGL((k_mn_prep<T>), dim3((n + ld + prep_rows - 1) / prep_rows, B), dim3(prep_rows),
-                       prep_smem, ctx->stream, B, n, m, d, D, ld, rs, d_mean, d_diag, d_omega, rowpack,
-                       colpack, state);
+    const dim3 prep_grid((n + ld + prep_rows - 1) / prep_rows, B);
+    if (d <= 4)
+        hipLaunchKernelGGL((k_mn_prep<T, 4>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m, d,
+                           D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+    else if (d <= 10)
+        hipLaunchKernelGGL((k_mn_prep<T, 10>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m,
+                           d, D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+    else if (d <= 16)
+        hipLaunchKernelGGL((k_mn_prep<T, 16>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m,
+                           d, D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+    else
+        hipLaunchKernelGGL((k_mn_prep<T, 0>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m, d,
+                           D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
     APMF_CHECK_LAUNCH();
     const uint16_t *maskT = nullptr;
     if (d_mask && (want != 0 || d_sum)) {
