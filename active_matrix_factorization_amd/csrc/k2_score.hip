@@ -24,7 +24,10 @@ namespace {
 constexpr int ROWS_PER_WAVE = 16;
 constexpr int WAVES = 4;
 constexpr int ROWS_PER_BLOCK = ROWS_PER_WAVE * WAVES;
-constexpr int UNR = 4;
+#ifndef APMF_K2_UNR
+#define APMF_K2_UNR 4
+#endif
+constexpr int UNR = APMF_K2_UNR;
 
 template <typename T, int N> struct Vec;
 template <> struct Vec<float, 4> { using type = float4; };
@@ -198,6 +201,9 @@ __global__ __launch_bounds__(256) void k_mask_pack(int n, int ld, const uint8_t 
 }
 
 // ---- the sweep ----------------------------------------------------------------------
+#ifndef APMF_K2_PREFETCH
+#define APMF_K2_PREFETCH 1
+#endif
 #ifndef APMF_K2_NT
 #define APMF_K2_NT 1   // streamed-once operands use nontemporal loads/stores
 #endif
@@ -249,7 +255,7 @@ __device__ __forceinline__ double bcast_lane(double v, int lane_idx)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <typename T, int D, int VEC>
+template <typename T, int D, int VEC, bool RED, bool MEAN>
 __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__restrict__ p_cross,
                                                  const T *__restrict__ p_rowpack,
                                                  const T *__restrict__ p_colpack,
@@ -298,9 +304,11 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
         }
     }
     const T t2 = p_state[2 * b], trO = p_state[2 * b + 1];
-    const bool do_mean = p_pmean != nullptr;
+    // RED / MEAN are compile-time so that the plain "write the scores" sweep does not carry
+    // the registers of the reductions and of the second output
+    constexpr bool do_mean = MEAN;
     const bool do_var = p_var != nullptr;
-    const bool do_red = a.want != 0 || a.want_sum;
+    constexpr bool do_red = RED;
 
     // the wave's 16 rows of rowpack (contiguous: RS elements per row), element e in
     // register e / 64, lane e % 64
@@ -344,6 +352,7 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
     for (int g = 0; g < ROWS_PER_WAVE / UNR; g++) {
         const int i0 = rbeg + g * UNR;
         if (i0 >= rend) break;  // wave-uniform
+#if APMF_K2_PREFETCH
         // prefetch the next UNR rows while this group is computed
         T s_nxt[UNR][VEC];
 #pragma unroll
@@ -354,6 +363,15 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
 #pragma unroll
                 for (int v = 0; v < VEC; v++) s_nxt[u][v] = 0;
         }
+#else
+        if (g > 0) {
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const int i = i0 + u;
+                if (i < rend && colok) vload_stream<T, VEC>(s_cur[u], p_cross + ((size_t)b * n + i) * ld + j0);
+            }
+        }
+#endif
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const int r = g * UNR + u;   // compile-time row slot of this wave
@@ -409,10 +427,12 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
                 sum += (double)rowsum;
             }
         }
+#if APMF_K2_PREFETCH
 #pragma unroll
         for (int u = 0; u < UNR; u++)
 #pragma unroll
             for (int v = 0; v < VEC; v++) s_cur[u][v] = s_nxt[u][v];
+#endif
     }
 #undef ROWOP
 
@@ -481,13 +501,26 @@ __global__ __launch_bounds__(256) void k_grid_finish(int nblk, int want, const d
     }
 }
 
+template <typename T, int D, int VEC, bool RED, bool MEAN>
+void launch_grid_v(const GridArgs<T> &a, hipStream_t st);
+
 template <typename T, int D, int VEC>
 void launch_grid(const GridArgs<T> &a, hipStream_t st)
+{
+    const bool red = a.g.want != 0 || a.g.want_sum, mean = a.pmean != nullptr;
+    if (red && mean) launch_grid_v<T, D, VEC, true, true>(a, st);
+    else if (red) launch_grid_v<T, D, VEC, true, false>(a, st);
+    else if (mean) launch_grid_v<T, D, VEC, false, true>(a, st);
+    else launch_grid_v<T, D, VEC, false, false>(a, st);
+}
+
+template <typename T, int D, int VEC, bool RED, bool MEAN>
+void launch_grid_v(const GridArgs<T> &a, hipStream_t st)
 {
     const int per_state = a.g.nblk_x * a.g.nblk_y;
     const long long groups = (a.g.B + 7) / 8;   // states are dealt to the 8 XCDs in groups of 8
     dim3 grid((unsigned)(groups * per_state * 8));
-    hipLaunchKernelGGL((k_mn_grid<T, D, VEC>), grid, dim3(256), 0, st, a.g, a.cross, a.rowpack,
+    hipLaunchKernelGGL((k_mn_grid<T, D, VEC, RED, MEAN>), grid, dim3(256), 0, st, a.g, a.cross, a.rowpack,
                        a.colpack, a.state, a.maskT, a.var, a.pmean, a.part_sum, a.part_val,
                        a.part_idx);
 }
