@@ -68,13 +68,17 @@ struct PmfParams {
 };
 
 // ---- fit_lls state kept on the device (apmf_pmf_fit_lls) -----------------------------------
-// The host enqueues iterations {gradient (if needed) -> trial point + its LL sums -> decide}
-// back to back and only reads this 64-byte state every few iterations: no round trip per trial.
+// One iteration of the search is two launches, enqueued back to back without host round trips:
+//   A: trial point fl(cur + fl(lr * grad)) into the other factor pair + its three LL sums;
+//   B: accept / reject (one block)  ||  gradient AT THE TRIAL POINT into the other gradient
+//      pair (speculative: it is the next step's gradient whenever the trial is accepted).
+// The state is double-buffered (B reads st[it & 1], its decide block writes st[(it+1) & 1]), so
+// the gradient blocks of B never see the state change under them.
 struct FitState {
     double lr, old_ll, min_lr, stop_thresh;
     long long steps, max_steps, max_trace;
     int cur;        // which factor buffer pair holds the current point (0: caller's arrays)
-    int need_grad;  // the point moved: recompute the gradient before the next trial
+    int gsel;       // which gradient buffer pair holds the gradient at the current point
     int converged;
     int pad;
 };
@@ -136,30 +140,23 @@ __device__ __forceinline__ double row_pass(const PmfParams &p, int lane, int sub
 
 // gradient(), pmf_cy.pyx:204-223.  A block is 4 waves = 4/WPR output rows (users and items in
 // one launch); WPR waves split a long row and are combined through LDS in a fixed order.
-// st == nullptr: plain call on (U0, V0).  st != nullptr: fit_lls mode, the current point is
-// buffer pair st->cur and the launch is a no-op unless the point moved.
 template <int DP, int WPR>
-__global__ __launch_bounds__(256) void k_grad(const PmfParams p, const FitState *__restrict__ st,
-                                              int first_row, int nrows_launch,
-                                              const int32_t *__restrict__ order,
-                                              const int64_t *__restrict__ ptr_u,
-                                              const int32_t *__restrict__ idx_u,
-                                              const double *__restrict__ val_u,
-                                              const int64_t *__restrict__ ptr_v,
-                                              const int32_t *__restrict__ idx_v,
-                                              const double *__restrict__ val_v, const double *U0,
-                                              const double *V0, const double *U1, const double *V1,
-                                              double *__restrict__ gU, double *__restrict__ gV)
+__device__ __forceinline__ void grad_block(const PmfParams &p, int block, int first_row, int nrows_launch,
+                                           const int32_t *__restrict__ order,
+                                           const int64_t *__restrict__ ptr_u,
+                                           const int32_t *__restrict__ idx_u,
+                                           const double *__restrict__ val_u,
+                                           const int64_t *__restrict__ ptr_v,
+                                           const int32_t *__restrict__ idx_v,
+                                           const double *__restrict__ val_v, const double *U,
+                                           const double *V, double *gU, double *gV, double (*sh)[64])
 {
-    if (st && (fit_done(st) || !st->need_grad)) return;   // grid-uniform
     constexpr int RPB = 4 / WPR;
-    __shared__ double sh[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
-    const int slot = blockIdx.x * RPB + wave / WPR;
+    const int slot = block * RPB + wave / WPR;
     const int sub = wave % WPR;
     const bool valid = slot < nrows_launch;
-    const double *U = (st && st->cur) ? U1 : U0, *V = (st && st->cur) ? V1 : V0;
     const int d = p.d;
     const int k = lane % DP, g = lane / DP;
     const bool kok = k < d;
@@ -190,6 +187,23 @@ __global__ __launch_bounds__(256) void k_grad(const PmfParams p, const FitState 
         (is_user ? gU : gV)[(size_t)row * d + k] = -xk / (is_user ? p.sig_u : p.sig_v) + acc;
 }
 
+template <int DP, int WPR>
+__global__ __launch_bounds__(256) void k_grad(const PmfParams p, int first_row, int nrows_launch,
+                                              const int32_t *__restrict__ order,
+                                              const int64_t *__restrict__ ptr_u,
+                                              const int32_t *__restrict__ idx_u,
+                                              const double *__restrict__ val_u,
+                                              const int64_t *__restrict__ ptr_v,
+                                              const int32_t *__restrict__ idx_v,
+                                              const double *__restrict__ val_v,
+                                              const double *__restrict__ U, const double *__restrict__ V,
+                                              double *__restrict__ gU, double *__restrict__ gV)
+{
+    __shared__ double sh[4][64];
+    grad_block<DP, WPR>(p, blockIdx.x, first_row, nrows_launch, order, ptr_u, idx_u, val_u, ptr_v, idx_v,
+                        val_v, U, V, gU, gV, sh);
+}
+
 // The three sums of log_likelihood() (pmf_cy.pyx:170-193) as per-wave partials: squared error
 // over the ratings of users [u_lo, u_hi) (each rating once) and the squared norms of the user
 // and item rows of the launched ranges.  TRIAL (fit_lls): the point is
@@ -201,11 +215,12 @@ __global__ __launch_bounds__(256) void k_sqerr(const PmfParams p, const FitState
                                                const int64_t *__restrict__ ptr_u,
                                                const int32_t *__restrict__ idx_u,
                                                const double *__restrict__ val_u, double *U0, double *V0,
-                                               double *U1, double *V1, const double *__restrict__ gU,
-                                               const double *__restrict__ gV,
+                                               double *U1, double *V1, const double *gU0,
+                                               const double *gV0, const double *gU1, const double *gV1,
                                                double *__restrict__ part /* (nslots * WPR, 3) */)
 {
     if (TRIAL && fit_done(st)) return;
+    const double *gU = (TRIAL && st->gsel) ? gU1 : gU0, *gV = (TRIAL && st->gsel) ? gV1 : gV0;
     constexpr int RPB = 4 / WPR;
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
@@ -250,16 +265,10 @@ __global__ __launch_bounds__(256) void k_sqerr(const PmfParams p, const FitState
     }
 }
 
-// fixed-order combine of the partials.  st == nullptr: out[0] = LL, out[1] = sq_error,
-// out[2] = ||U||^2, out[3] = ||V||^2.  st != nullptr: LL of the trial point, then accept / reject
-// exactly as pmf_cy.pyx:275-291.
-__global__ __launch_bounds__(256) void k_ll_finish(int nparts, FitState *__restrict__ st,
-                                                   const double *__restrict__ part, double sig,
-                                                   double sig_u, double sig_v, double *__restrict__ out,
-                                                   double *__restrict__ trace)
+// fixed-order combine of the per-wave partials (one 256-thread block) -> sums[3]
+__device__ __forceinline__ void combine_parts(int nparts, const double *__restrict__ part, double (*sh)[256],
+                                              double (&sums)[3])
 {
-    if (st && fit_done(st)) return;
-    __shared__ double sh[3][256];
     double a = 0, b = 0, c = 0;
     for (int t = threadIdx.x; t < nparts; t += 256) {
         a += part[(size_t)t * 3];
@@ -273,28 +282,74 @@ __global__ __launch_bounds__(256) void k_ll_finish(int nparts, FitState *__restr
             for (int q = 0; q < 3; q++) sh[q][threadIdx.x] += sh[q][threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x != 0) return;
-    const double ll = -sh[0][0] / (2. * sig) - sh[1][0] / (2. * sig_u) - sh[2][0] / (2. * sig_v);
-    if (!st) {
-        out[0] = ll;
-        out[1] = sh[0][0];
-        out[2] = sh[1][0];
-        out[3] = sh[2][0];
+    sums[0] = sh[0][0]; sums[1] = sh[1][0]; sums[2] = sh[2][0];
+}
+
+// out[0] = LL, out[1] = sq_error, out[2] = ||U||^2, out[3] = ||V||^2
+__global__ __launch_bounds__(256) void k_ll_finish(int nparts, const double *__restrict__ part, double sig,
+                                                   double sig_u, double sig_v, double *__restrict__ out)
+{
+    __shared__ double sh[3][256];
+    double s[3];
+    combine_parts(nparts, part, sh, s);
+    if (threadIdx.x == 0) {
+        out[0] = -s[0] / (2. * sig) - s[1] / (2. * sig_u) - s[2] / (2. * sig_v);
+        out[1] = s[0];
+        out[2] = s[1];
+        out[3] = s[2];
+    }
+}
+
+// launch B of a search iteration (see FitState): blocks [0, g_blocks) = gradient at the trial
+// point (factor pair 1 - cur) into gradient pair 1 - gsel; block g_blocks = accept / reject
+// exactly as pmf_cy.pyx:275-291, reading st_in and writing st_out.
+template <int DP, int WPR>
+__global__ __launch_bounds__(256) void k_fit_step(const PmfParams p, const FitState *__restrict__ st_in,
+                                                  FitState *__restrict__ st_out, int g_blocks,
+                                                  const int32_t *__restrict__ order,
+                                                  const int64_t *__restrict__ ptr_u,
+                                                  const int32_t *__restrict__ idx_u,
+                                                  const double *__restrict__ val_u,
+                                                  const int64_t *__restrict__ ptr_v,
+                                                  const int32_t *__restrict__ idx_v,
+                                                  const double *__restrict__ val_v, const double *U0,
+                                                  const double *V0, const double *U1, const double *V1,
+                                                  double *gU0, double *gV0, double *gU1, double *gV1,
+                                                  int nparts, const double *__restrict__ part, double sig,
+                                                  double *__restrict__ trace)
+{
+    __shared__ double sh_g[4][64];
+    __shared__ double sh_d[3][256];
+    const FitState s = *st_in;
+    const bool done = s.converged || (s.max_steps >= 0 && s.steps >= s.max_steps);
+    if ((int)blockIdx.x < g_blocks) {
+        if (done) return;
+        grad_block<DP, WPR>(p, blockIdx.x, 0, p.n + p.m, order, ptr_u, idx_u, val_u, ptr_v, idx_v, val_v,
+                            s.cur ? U0 : U1, s.cur ? V0 : V1, s.gsel ? gU0 : gU1, s.gsel ? gV0 : gV1, sh_g);
         return;
     }
-    if (ll > st->old_ll) {
-        st->cur ^= 1;
-        st->lr *= 1.25;
-        if (ll - st->old_ll < st->stop_thresh) st->converged = 1;
-        if (st->steps < st->max_trace) trace[st->steps] = ll;
-        st->steps += 1;
-        st->old_ll = ll;
-        st->need_grad = 1;
-    } else {
-        st->lr *= .5;
-        st->need_grad = 0;
-        if (st->lr < st->min_lr) st->converged = 1;
+    if (done) {
+        if (threadIdx.x == 0) *st_out = s;
+        return;
     }
+    double sums[3];
+    combine_parts(nparts, part, sh_d, sums);
+    if (threadIdx.x != 0) return;
+    const double ll = -sums[0] / (2. * sig) - sums[1] / (2. * p.sig_u) - sums[2] / (2. * p.sig_v);
+    FitState o = s;
+    if (ll > s.old_ll) {
+        o.cur = s.cur ^ 1;
+        o.gsel = s.gsel ^ 1;
+        o.lr = s.lr * 1.25;
+        if (ll - s.old_ll < s.stop_thresh) o.converged = 1;
+        if (s.steps < s.max_trace) trace[s.steps] = ll;
+        o.steps = s.steps + 1;
+        o.old_ll = ll;
+    } else {
+        o.lr = s.lr * .5;
+        if (o.lr < s.min_lr) o.converged = 1;
+    }
+    *st_out = o;
 }
 
 // minibatch momentum update, pmf_cy.pyx:338-344:
@@ -427,9 +482,8 @@ int wpr_for(const apmf_ratings *r)
     if ((wpr) == 4) { constexpr int WPR = 4; DISPATCH_DP(dp, __VA_ARGS__); }        \
     else { constexpr int WPR = 1; DISPATCH_DP(dp, __VA_ARGS__); }
 
-int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const FitState *st,
-                const double *U0, const double *V0, const double *U1, const double *V1, double *gU,
-                double *gV, int first_row = 0, int nrows = -1)
+int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const double *U,
+                const double *V, double *gU, double *gV, int first_row = 0, int nrows = -1)
 {
     const bool whole = nrows < 0;
     const int rows = whole ? r->n + r->m : nrows;
@@ -438,10 +492,10 @@ int launch_grad(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, const 
     const int blocks = (rows + (4 / wpr) - 1) / (4 / wpr);
     ProfScope prof(ctx);
     DISPATCH_DP_WPR(dp_for(p.d), wpr,
-                    hipLaunchKernelGGL((k_grad<DP, WPR>), dim3(blocks), dim3(256), 0, ctx->stream, p, st,
+                    hipLaunchKernelGGL((k_grad<DP, WPR>), dim3(blocks), dim3(256), 0, ctx->stream, p,
                                        first_row, rows, whole ? r->order : (const int32_t *)nullptr,
                                        r->ptr[0], r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1],
-                                       U0, V0, U1, V1, gU, gV));
+                                       U, V, gU, gV));
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -467,10 +521,11 @@ int launch_ll(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, double s
                                        (const FitState *)nullptr, u_lo, u_hi, v_lo, v_hi, r->ptr[0],
                                        r->idx[0], r->val[0], const_cast<double *>(U),
                                        const_cast<double *>(V), (double *)nullptr, (double *)nullptr,
+                                       (const double *)nullptr, (const double *)nullptr,
                                        (const double *)nullptr, (const double *)nullptr, d_part));
     APMF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nslots * wpr, (FitState *)nullptr,
-                       d_part, sigma_sq, p.sig_u, p.sig_v, d_out4, (double *)nullptr);
+    hipLaunchKernelGGL(k_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nslots * wpr, d_part, sigma_sq,
+                       p.sig_u, p.sig_v, d_out4);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -583,7 +638,7 @@ int apmf_pmf_gradient(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, c
     APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
     APMF_REQUIRE(d_U && d_V && d_gU && d_gV, "NULL operand");
     const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
-    return launch_grad(ctx, r, p, nullptr, d_U, d_V, nullptr, nullptr, d_gU, d_gV);
+    return launch_grad(ctx, r, p, d_U, d_V, d_gU, d_gV);
 }
 
 int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U,
@@ -619,9 +674,9 @@ int apmf_pmf_gradient_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int r
     APMF_REQUIRE(0 <= row_lo && row_lo <= row_hi && row_hi <= rows, "row range [%d,%d) outside [0,%d)",
                  row_lo, row_hi, rows);
     const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, subtract_mean, mean_rating);
-    return launch_grad(ctx, r, p, nullptr, d_U, d_V, nullptr, nullptr,
-                       side == 0 ? d_g : (double *)nullptr, side == 1 ? d_g : (double *)nullptr,
-                       side == 0 ? row_lo : r->n + row_lo, row_hi - row_lo);
+    return launch_grad(ctx, r, p, d_U, d_V, side == 0 ? d_g : (double *)nullptr,
+                       side == 1 ? d_g : (double *)nullptr, side == 0 ? row_lo : r->n + row_lo,
+                       row_hi - row_lo);
 }
 
 int apmf_pmf_ll_terms(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V, int d,
@@ -662,13 +717,15 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     const int wpr = wpr_for(r);
     const int nparts = nslots * wpr;
     const int64_t trace_cap = max_trace < 0 ? 0 : max_trace;
-    // workspace 0: gU gV | second factor buffer pair | trace ; workspace 1: partials, outputs, state
+    // workspace 0: two gradient pairs | second factor pair | trace ; workspace 1: partials,
+    // outputs, the two states
     void *w0, *w1;
-    APMF_TRY(apmf_ws(ctx, 0, (2 * (nu + nv) + (size_t)trace_cap) * 8 + 64, &w0));
-    APMF_TRY(apmf_ws(ctx, 1, (size_t)nparts * 24 + 128 + sizeof(FitState) + 64, &w1));
-    double *gU = (double *)w0, *gV = gU + nu, *tU = gV + nv, *tV = tU + nu, *d_trace = tV + nv;
+    APMF_TRY(apmf_ws(ctx, 0, (3 * (nu + nv) + (size_t)trace_cap) * 8 + 64, &w0));
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nparts * 24 + 128 + 2 * sizeof(FitState) + 64, &w1));
+    double *gU0 = (double *)w0, *gV0 = gU0 + nu, *gU1 = gV0 + nv, *gV1 = gU1 + nu, *tU = gV1 + nv,
+           *tV = tU + nu, *d_trace = tV + nv;
     double *d_part = (double *)w1, *d_out2 = d_part + (size_t)nparts * 3;
-    FitState *d_state = (FitState *)(d_out2 + 8);
+    FitState *d_state = (FitState *)(d_out2 + 8);   // d_state[0], d_state[1]
     void *pin;
     APMF_TRY(apmf_pinned(ctx, 256, &pin));
     FitState *h_state = (FitState *)pin;
@@ -689,26 +746,35 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     h_state->stop_thresh = stop_thresh;
     h_state->max_steps = max_steps;
     h_state->max_trace = trace_cap;
-    h_state->need_grad = 1;
     APMF_CHECK_HIP(hipMemcpyAsync(d_state, h_state, sizeof(FitState), hipMemcpyHostToDevice, ctx->stream));
     APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the pinned block is reused for read-backs
 
+    if (max_steps != 0) APMF_TRY(launch_grad(ctx, r, p, d_U, d_V, gU0, gV0));   // gradient at the start
     const int t_blocks = (nslots + (4 / wpr) - 1) / (4 / wpr);
+    const int g_blocks = (r->n + r->m + (4 / wpr) - 1) / (4 / wpr);
     const int dp = dp_for(d);
+    long long it = 0;
     for (;;) {
+        if (max_steps == 0) break;
         const long long remaining = max_steps < 0 ? 1 << 20 : max_steps - h_state->steps;
         const int chunk = (int)std::min<long long>(std::max<long long>(remaining + 1, 2), 16);
-        for (int it = 0; it < chunk; it++) {
-            APMF_TRY(launch_grad(ctx, r, p, d_state, d_U, d_V, tU, tV, gU, gV));
+        for (int c = 0; c < chunk; c++, it++) {
+            FitState *s_in = d_state + (it & 1), *s_out = d_state + ((it + 1) & 1);
             DISPATCH_DP_WPR(dp, wpr,
                             hipLaunchKernelGGL((k_sqerr<DP, WPR, true>), dim3(t_blocks), dim3(256), 0,
-                                               ctx->stream, p, d_state, 0, r->n, 0, r->m, r->ptr[0],
-                                               r->idx[0], r->val[0], d_U, d_V, tU, tV, gU, gV, d_part));
-            hipLaunchKernelGGL(k_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nparts, d_state, d_part,
-                               sigma_sq, sigma_u_sq, sigma_v_sq, (double *)nullptr, d_trace);
+                                               ctx->stream, p, s_in, 0, r->n, 0, r->m, r->ptr[0], r->idx[0],
+                                               r->val[0], d_U, d_V, tU, tV, gU0, gV0, gU1, gV1, d_part));
+            ProfScope prof(ctx);
+            DISPATCH_DP_WPR(dp, wpr,
+                            hipLaunchKernelGGL((k_fit_step<DP, WPR>), dim3(g_blocks + 1), dim3(256), 0,
+                                               ctx->stream, p, s_in, s_out, g_blocks, r->order, r->ptr[0],
+                                               r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1], d_U,
+                                               d_V, tU, tV, gU0, gV0, gU1, gV1, nparts, d_part, sigma_sq,
+                                               d_trace));
         }
         APMF_CHECK_LAUNCH();
-        APMF_CHECK_HIP(hipMemcpyAsync(h_state, d_state, sizeof(FitState), hipMemcpyDeviceToHost, ctx->stream));
+        APMF_CHECK_HIP(hipMemcpyAsync(h_state, d_state + (it & 1), sizeof(FitState), hipMemcpyDeviceToHost,
+                                      ctx->stream));
         APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
         if (h_state->converged || (max_steps >= 0 && h_state->steps >= max_steps)) break;
     }

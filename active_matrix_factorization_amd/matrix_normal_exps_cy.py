@@ -88,6 +88,28 @@ def _upper_mirrored(cov_latents):
     return up + np.triu(cov_latents, 1).T
 
 
+def _e_dot_sq_on_device(num_users, ratings, mean, cov_useritems, cov_latents):
+    """E[(U_i.V_j)^2] of every rated entry = Var + E^2 from the K2 pool kernel (no host path)."""
+    try:
+        from . import _lib
+    except ImportError:
+        import _lib
+    ctx = _lib.default_context()
+    n = int(num_users)
+    m, d = mean.shape[0] - n, mean.shape[1]
+    cov_useritems = np.asarray(cov_useritems, np.float64)
+    cross = ctx.upload_grid(cov_useritems[:n, n:], np.float64)
+    P = ratings.shape[0]
+    pm, pv = ctx.empty(P), ctx.empty(P)
+    ctx.mn_score_pool(n, m, d, cross.shape[1], ctx.array(mean, np.float64), cross,
+                      ctx.array(np.ascontiguousarray(np.diagonal(cov_useritems)), np.float64),
+                      ctx.array(cov_latents, np.float64),
+                      ctx.array(np.ascontiguousarray(ratings[:, 0], np.int32), np.int32),
+                      ctx.array(np.ascontiguousarray(ratings[:, 1], np.int32), np.int32), P, pm, pv)
+    pm, pv = pm.to_host(), pv.to_host()
+    return pv + pm * pm
+
+
 def mn_kl_divergence(num_users, ratings, mean, cov_useritems, cov_latents,
                      sigma_sq, sigma_u_sq, sigma_v_sq, e_dot_sq=None):
     '''KL( MN(mean, cov_useritems, cov_latents) || PMF posterior ) up to a constant
@@ -110,11 +132,7 @@ def mn_kl_divergence(num_users, ratings, mean, cov_useritems, cov_latents,
     ii, jj, r, a, b, s, vi, vj = _rating_operands(num_users, ratings, mean, cov_useritems)
     pred = (a * b).sum(1) + s * tr_cov_latents
     if e_dot_sq is None:
-        om = _upper_mirrored(cov_latents)
-        t2 = (om * om).sum()
-        var = ((vi * vj + s * s) * t2 + vj * np.einsum('tk,kl,tl->t', a, om, a)
-               + vi * np.einsum('tk,kl,tl->t', b, om, b) + 2 * s * np.einsum('tk,kl,tl->t', a, om, b))
-        e_dot_sq = var + pred ** 2
+        e_dot_sq = _e_dot_sq_on_device(num_users, ratings, mean, cov_useritems, cov_latents)
     bit = (e_dot_sq - 2 * r * pred + r * r).sum()
     return kl + bit / (2 * sigma_sq)
 
