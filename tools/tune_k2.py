@@ -46,3 +46,16 @@ run('var+sum+argmax', var=var, dsum=dsum, want=1, best_val=bv, best_idx=bi)
 run('var+sum+argmax+mask (bench)', var=var, dsum=dsum, want=1, best_val=bv, best_idx=bi, mask=mask)
 run('sum+argmax+mask (no write)', dsum=dsum, want=1, best_val=bv, best_idx=bi, mask=mask)
 run('var+mean', var=var, pmean=pm)
+
+# calibration: device-to-device copy of the same 1.6 GB in / 1.6 GB out (hipMemcpyAsync)
+import time
+for _ in range(2):
+    ctx._lib.apmf_d2d(ctx._h, var.ptr, cross.ptr, cross.nbytes)
+ctx.sync()
+t0 = time.perf_counter()
+R = 10
+for _ in range(R):
+    ctx._lib.apmf_d2d(ctx._h, var.ptr, cross.ptr, cross.nbytes)
+ctx.sync()
+dt = (time.perf_counter() - t0) / R
+print('d2d copy of the same bytes: %.3f ms  %.0f GB/s (read+write)' % (dt * 1e3, 2 * cross.nbytes / dt / 1e9))
