@@ -69,8 +69,8 @@ def synth_states(rs, B, ld, rank_r=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--states', type=int, default=256, help='posterior states per sweep (B)')
     ap.add_argument('--grad-steps-per-call', type=int, default=25)
     ap.add_argument('--no-cpu-baseline', action='store_true')

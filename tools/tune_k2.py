@@ -35,9 +35,20 @@ def run(name, reps=10, **kw):
     for _ in range(reps):
         ctx.mn_score_grid(np.float32, B, n, m, d, ld, mean, cross, diag, om, **kw)
     ms = ctx.profile_end()
+    import time as _t
+    ctx.sync(); _t0 = _t.perf_counter()
+    for _ in range(reps):
+        ctx.mn_score_grid(np.float32, B, n, m, d, ld, mean, cross, diag, om, **kw)
+    ctx.sync(); wall = (_t.perf_counter() - _t0) / reps * 1e3
+    _t0 = _t.perf_counter()
+    for _ in range(reps):
+        ctx.mn_score_grid(np.float32, B, n, m, d, ld, mean, cross, diag, om, **kw)
+    enq = (_t.perf_counter() - _t0) / reps * 1e3
+    ctx.sync()
+    name = '%s [wall %.3f ms/call, enqueue %.3f ms/call]' % (name, wall, enq)
     cand = B * n * m
     byt = 4 * cand * (1 + ('var' in kw) + ('pmean' in kw))
-    print('%-34s min %.3f ms  med %.3f ms   %.0f GB/s (algorithmic, median)  %.3e cand/s' % (
+    print('%-80s min %.3f ms  med %.3f ms   %.0f GB/s (algorithmic, median)  %.3e cand/s' % (
         name, ms.min(), np.median(ms), byt / np.median(ms) / 1e6, cand / np.median(ms) * 1e3))
 
 run('var', var=var)
