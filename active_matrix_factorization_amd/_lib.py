@@ -84,13 +84,38 @@ _SIGS = {
     'apmf_pool_argext_f64': (_i, [_vp, _vp, _i64, _i, C.POINTER(_i64), C.POINTER(_dbl)]),
 }
 
+_DENSE_SIGS = {
+    'apmf_dense_project_psd': (_i, [_vp, _vp, _i, _dbl, C.POINTER(_i)]),
+    'apmf_dense_inv_logdet': (_i, [_vp, _vp, _i, _vp, C.POINTER(_dbl)]),
+}
+DENSE_LIB_PATH = os.path.join(_HERE, 'libapmf_dense.so')
+
 _lib = None
+_dense = None
 _lock = threading.Lock()
 
 
 def exported_symbols():
     """Names include/apmf.h declares (used by the CPU-side ABI test)."""
-    return sorted(_SIGS)
+    return sorted(_SIGS) + sorted(_DENSE_SIGS)
+
+
+def load_dense():
+    """dlopen libapmf_dense.so (rocSOLVER / rocBLAS underneath) on first use."""
+    global _dense
+    load()
+    with _lock:
+        if _dense is None:
+            if not os.path.exists(DENSE_LIB_PATH):
+                raise ApmfError(ENODEV, 'HIP extension %s is not built; there is no CPU fallback'
+                                % DENSE_LIB_PATH)
+            lib = C.CDLL(DENSE_LIB_PATH, mode=C.RTLD_GLOBAL)
+            for name, (res, args) in _DENSE_SIGS.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _dense = lib
+    return _dense
 
 
 def load():
@@ -102,7 +127,7 @@ def load():
                 raise ApmfError(ENODEV, 'HIP extension %s is not built (run `python -c "import '
                                 '__graft_entry__ as g; g.build()"` or `make -C %s/csrc`); there '
                                 'is no CPU fallback' % (LIB_PATH, _HERE))
-            lib = C.CDLL(LIB_PATH)
+            lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)   # libapmf_dense.so resolves apmf_ws etc. here
             for name, (res, args) in _SIGS.items():
                 fn = getattr(lib, name)
                 fn.restype = res
@@ -377,6 +402,18 @@ class Context(object):
         _check(self._lib.apmf_full_score_grid_f64(self._h, n, m, d, ld, _ptr(mean), _ptr(cov),
                                                   _ptr(mask), _ptr(var), _ptr(pmean), _ptr(dsum), want,
                                                   _ptr(best_val), _ptr(best_idx)))
+
+    # -- dense symmetric linear algebra of the variational fit ------------------------------
+    def dense_project_psd(self, dmat, N, min_eig):
+        flag = _i(0)
+        _check(load_dense().apmf_dense_project_psd(self._h, _ptr(dmat), N, float(min_eig), C.byref(flag)))
+        return bool(flag.value)
+
+    def dense_inv_logdet(self, dmat, N, dinv=None, want_logdet=True):
+        ld = _dbl(0.)
+        _check(load_dense().apmf_dense_inv_logdet(self._h, _ptr(dmat), N, _ptr(dinv),
+                                                  C.byref(ld) if want_logdet else None))
+        return ld.value
 
     # -- K3 / K4 -----------------------------------------------------------------------
     def gibbs_half_sweep(self, rt, side, oth, d, alpha, mu, beta, mean_sub, z, out):

@@ -18,13 +18,15 @@ import numpy as np
 try:
     from . import _lib
     from ._active_base import (_ActiveBase, _Evaluator, _criterion, minimize, make_key_funcs,
-                               query_loop, run_compare, strictmap)
+                               query_loop, run_compare, strictmap, project_psd as _project_psd)
+    from .matrix_normal_exps_cy import logabsdet, inverse
     from .normal_exps_cy import quadexpect, exp_a2bc, exp_dotprod_sq, normal_gradient
     from .pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
 except ImportError:      # top-level import (package directory on sys.path, like python-pmf/)
     import _lib
     from _active_base import (_ActiveBase, _Evaluator, _criterion, minimize, make_key_funcs,
-                              query_loop, run_compare, strictmap)
+                              query_loop, run_compare, strictmap, project_psd as _project_psd)
+    from matrix_normal_exps_cy import logabsdet, inverse
     from normal_exps_cy import quadexpect, exp_a2bc, exp_dotprod_sq, normal_gradient
     from pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
 
@@ -32,13 +34,8 @@ ActivePMFEvaluator = _Evaluator
 
 
 def project_psd(mat, min_eig=0):
-    '''Symmetrise and clip the spectrum at min_eig (active_pmf.py:36-50).'''
-    mat = (mat + mat.T) / 2
-    vals, vecs = np.linalg.eigh(mat)
-    if vals.min() < min_eig:
-        mat = np.dot(vecs, np.dot(np.diag(np.maximum(vals, min_eig)), vecs.T))
-        mat = (mat + mat.T) / 2
-    return mat
+    '''Symmetrise and clip the spectrum at min_eig (active_pmf.py:36-50), on the device.'''
+    return _project_psd(mat, min_eig=min_eig)
 
 
 class ActivePMF(_ActiveBase):
@@ -77,8 +74,7 @@ class ActivePMF(_ActiveBase):
         div = ((pv + pm * pm - 2 * r * pm).sum() + (r ** 2).sum()) / (2 * self.sigma_sq)
         div += ((mean[us] ** 2).sum() + cov[us, us].sum()) / (2 * self.sigma_u_sq)
         div += ((mean[vs] ** 2).sum() + cov[vs, vs].sum()) / (2 * self.sigma_v_sq)
-        det_sign, log_det = np.linalg.slogdet(cov)
-        return div - log_det / 2
+        return div - logabsdet(cov) / 2
 
     def fit_normal_kls(self):
         def step(cand):
@@ -95,9 +91,7 @@ class ActivePMF(_ActiveBase):
         return np.abs(self.mean - p).mean()
 
     def _approx_entropy(self):
-        sign, logdet = np.linalg.slogdet(self.cov)
-        assert sign == 1
-        return logdet
+        return logabsdet(self.cov)
 
     # ------------------------------------------------------------------ GPU scoring (K2-full)
     def _score_grid(self, state=None, total_only=False):

@@ -1,0 +1,158 @@
+// dense.hip - libapmf_dense.so: the (n+m) x (n+m) dense symmetric linear algebra of the
+// variational fit, on the device:
+//   project_psd  (mn_active_pmf.py:42-67: symmetrise, eigh, clip the spectrum, rebuild)
+//   inverse + log|det| of a covariance (matrix_normal_exps_cy.pyx:180-182,477-485:
+//   np.linalg.slogdet / np.linalg.inv, i.e. LAPACK getrf / getri)
+// These are plain LAPACK-shaped operations, so they go to rocSOLVER / rocBLAS (syevd, getrf,
+// getri, gemm); the element-wise glue (symmetrise, spectrum clip, mirror) is HIP.  Kept in a
+// library of its own so that libapmf_hip.so has no BLAS dependency; loaded lazily.
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include "common.h"
+
+namespace {
+
+rocblas_handle g_handle = nullptr;
+
+int handle_for(apmf_ctx *ctx, rocblas_handle *out)
+{
+    if (!g_handle) {
+        if (rocblas_create_handle(&g_handle) != rocblas_status_success) {
+            apmf_set_error("rocblas_create_handle failed");
+            return APMF_EHIP;
+        }
+    }
+    if (rocblas_set_stream(g_handle, ctx->stream) != rocblas_status_success) {
+        apmf_set_error("rocblas_set_stream failed");
+        return APMF_EHIP;
+    }
+    *out = g_handle;
+    return APMF_OK;
+}
+
+#define APMF_CHECK_ROC(expr)                                                                  \
+    do {                                                                                      \
+        rocblas_status _s = (expr);                                                           \
+        if (_s != rocblas_status_success) {                                                   \
+            apmf_set_error("%s failed: rocblas_status %d (%s:%d)", #expr, (int)_s, __FILE__,  \
+                           __LINE__);                                                         \
+            return APMF_EHIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+// A <- (A + A') / 2, done per (i, j > i) pair
+__global__ __launch_bounds__(256) void k_symmetrize(double *__restrict__ A, int N)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)N * N) return;
+    const int i = (int)(t / N), j = (int)(t % N);
+    if (j <= i) return;
+    const double v = (A[(size_t)i * N + j] + A[(size_t)j * N + i]) / 2;
+    A[(size_t)i * N + j] = v;
+    A[(size_t)j * N + i] = v;
+}
+
+// Vs[:, c] = V[:, c] * max(w[c], min_eig)   (column-major eigenvectors)
+__global__ __launch_bounds__(256) void k_scale_cols(const double *__restrict__ V, const double *__restrict__ w,
+                                                    double min_eig, double *__restrict__ Vs, int N)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)N * N) return;
+    const int c = (int)(t / N);
+    const double e = w[c];
+    Vs[t] = V[t] * (e > min_eig ? e : min_eig);
+}
+
+// log |det| from the diagonal of an LU factor (numpy.linalg.slogdet's second value)
+__global__ __launch_bounds__(256) void k_logabsdet_lu(const double *__restrict__ L, int N, double *__restrict__ out)
+{
+    __shared__ double sh[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < N; i += 256) s += log(fabs(L[(size_t)i * N + i]));
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+int grid_for(size_t count) { return (int)((count + 255) / 256); }
+
+} // namespace
+
+extern "C" {
+
+int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, int *h_projected)
+{
+    APMF_REQUIRE(ctx && d_mat, "NULL operand");
+    APMF_REQUIRE(N >= 1, "bad size");
+    rocblas_handle h;
+    APMF_TRY(handle_for(ctx, &h));
+    const size_t nn = (size_t)N * N;
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 3, (2 * nn + 2 * (size_t)N) * sizeof(double) + 64, &w));
+    double *V = (double *)w, *Vs = V + nn, *evals = Vs + nn, *E = evals + N;
+    int *info = (int *)(E + N);
+    hipLaunchKernelGGL(k_symmetrize, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_mat, N);
+    APMF_CHECK_LAUNCH();
+    APMF_CHECK_HIP(hipMemcpyAsync(V, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    APMF_CHECK_ROC(rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, N, V, N, evals, E, info));
+    double wmin;
+    int hinfo;
+    APMF_TRY(apmf_d2h(ctx, &wmin, evals, sizeof(double)));   // ascending: evals[0] is the minimum
+    APMF_TRY(apmf_d2h(ctx, &hinfo, info, sizeof(int)));
+    if (hinfo != 0) {
+        apmf_set_error("rocsolver_dsyevd did not converge (info=%d)", hinfo);
+        return APMF_EHIP;
+    }
+    const bool project = wmin < min_eig;
+    if (h_projected) *h_projected = project ? 1 : 0;
+    if (!project) return APMF_OK;   // the symmetrised input is returned unchanged
+    hipLaunchKernelGGL(k_scale_cols, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, V, evals, min_eig, Vs, N);
+    APMF_CHECK_LAUNCH();
+    const double one = 1., zero = 0.;
+    APMF_CHECK_ROC(rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_transpose, N, N, N, &one, Vs, N,
+                                 V, N, &zero, d_mat, N));
+    hipLaunchKernelGGL(k_symmetrize, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_mat, N);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_inv, double *h_logdet)
+{
+    APMF_REQUIRE(ctx && d_mat, "NULL operand");
+    APMF_REQUIRE(N >= 1, "bad size");
+    if (!d_inv && !h_logdet) return APMF_OK;
+    rocblas_handle h;
+    APMF_TRY(handle_for(ctx, &h));
+    const size_t nn = (size_t)N * N;
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 3, (nn + 8) * sizeof(double) + ((size_t)N + 16) * sizeof(int) + 64, &w));
+    double *LU = d_inv ? d_inv : (double *)w;
+    double *scal = (double *)w + nn;
+    int *info = (int *)(scal + 4);
+    int *ipiv = info + 8;
+    if (LU != d_mat)
+        APMF_CHECK_HIP(hipMemcpyAsync(LU, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    // LU of the transpose (row-major data seen column-major): same determinant, and the inverse
+    // of the transpose is the transpose of the inverse - exactly what row-major storage wants
+    APMF_CHECK_ROC(rocsolver_dgetrf(h, N, N, LU, N, ipiv, info));
+    int hinfo;
+    APMF_TRY(apmf_d2h(ctx, &hinfo, info, sizeof(int)));
+    if (hinfo != 0) {
+        apmf_set_error("Singular matrix (getrf info=%d)", hinfo);
+        return APMF_ENOTPD;
+    }
+    if (h_logdet) {
+        hipLaunchKernelGGL(k_logabsdet_lu, dim3(1), dim3(256), 0, ctx->stream, LU, N, scal);
+        APMF_CHECK_LAUNCH();
+        APMF_TRY(apmf_d2h(ctx, h_logdet, scal, sizeof(double)));
+    }
+    if (d_inv) APMF_CHECK_ROC(rocsolver_dgetri(h, N, LU, N, ipiv, info));
+    return APMF_OK;
+}
+
+} // extern "C"

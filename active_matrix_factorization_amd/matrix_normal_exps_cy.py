@@ -7,9 +7,10 @@ cov_cols) and the KL objective / gradient of the variational fit.
   entries.  The hot loop that called exp_dotprod_sq once per candidate in the reference is
   replaced by the batched HIP kernels behind MNActivePMF (K2, csrc/k2_score.hip).
 * mn_kl_divergence / matrixnormal_gradient are the variational-fit pair (SURVEY.md 8(f)
-  rank 1, "next").  This round they are vectorised over the ratings on the host (the
-  per-rating E[(U_i.V_j)^2] terms of the KL come from the K2 pool kernel); the reference's
-  quirks are reproduced on purpose (see the comments at each).
+  rank 1, "next").  This round the per-rating sums of the gradient are vectorised over the
+  ratings on the host; the per-rating E[(U_i.V_j)^2] terms of the KL come from the K2 pool
+  kernel and the (n+m) x (n+m) inverse / log-determinant run on the device (rocSOLVER behind
+  libapmf_dense.so).  The reference's quirks are reproduced on purpose (see each comment).
 """
 import numpy as np
 
@@ -88,13 +89,33 @@ def _upper_mirrored(cov_latents):
     return up + np.triu(cov_latents, 1).T
 
 
-def _e_dot_sq_on_device(num_users, ratings, mean, cov_useritems, cov_latents):
-    """E[(U_i.V_j)^2] of every rated entry = Var + E^2 from the K2 pool kernel (no host path)."""
+def _ctx():
     try:
         from . import _lib
     except ImportError:
         import _lib
-    ctx = _lib.default_context()
+    return _lib.default_context()
+
+
+def logabsdet(mat):
+    """np.linalg.slogdet(mat)[1] on the device (LU via rocSOLVER, libapmf_dense.so)."""
+    ctx = _ctx()
+    mat = np.ascontiguousarray(mat, np.float64)
+    return ctx.dense_inv_logdet(ctx.array(mat), mat.shape[0], None, want_logdet=True)
+
+
+def inverse(mat):
+    """np.linalg.inv(mat) on the device (getrf + getri via rocSOLVER)."""
+    ctx = _ctx()
+    mat = np.ascontiguousarray(mat, np.float64)
+    out = ctx.empty(mat.shape)
+    ctx.dense_inv_logdet(ctx.array(mat), mat.shape[0], out, want_logdet=False)
+    return out.to_host()
+
+
+def _e_dot_sq_on_device(num_users, ratings, mean, cov_useritems, cov_latents):
+    """E[(U_i.V_j)^2] of every rated entry = Var + E^2 from the K2 pool kernel (no host path)."""
+    ctx = _ctx()
     n = int(num_users)
     m, d = mean.shape[0] - n, mean.shape[1]
     cov_useritems = np.asarray(cov_useritems, np.float64)
@@ -119,8 +140,8 @@ def mn_kl_divergence(num_users, ratings, mean, cov_useritems, cov_latents,
       * the item prior uses sigma_u_sq, not sigma_v_sq (:196-197).
     e_dot_sq: optional precomputed E[(U_i.V_j)^2] for every rating (from the K2 pool kernel).'''
     num_useritems, latent_d = mean.shape
-    _, log_det_useritems = np.linalg.slogdet(cov_useritems)
-    _, log_det_latents = np.linalg.slogdet(cov_latents)
+    log_det_useritems = logabsdet(cov_useritems)
+    log_det_latents = logabsdet(cov_latents)
     kl = -(log_det_useritems * latent_d + log_det_latents * num_useritems) / 2.
 
     tr_cov_latents = cov_latents.trace()
@@ -224,8 +245,8 @@ def _mnormal_grad(mean, cov_useritems, cov_latents, ratings, num_users, latent_d
     g_cl[latent_idx, latent_idx] += cov_useritems[item_idx, item_idx].sum() / (2 * sig_v_sq)
 
     # entropy  d/2 ln det(Sigma) + (n+m)/2 ln det(Omega), w.r.t. a triangular half
-    inv_cu = np.linalg.inv(cov_useritems)
+    inv_cu = inverse(cov_useritems)
     g_cu -= d / 2. * (inv_cu + inv_cu.T * (1 - np.eye(num_useritems)))
-    inv_cl = np.linalg.inv(cov_latents)
+    inv_cl = inverse(cov_latents)
     g_cl -= num_useritems / 2. * (inv_cl + inv_cl.T * (1 - np.eye(d)))
     return g_mean, g_cu, g_cl

@@ -17,7 +17,7 @@ try:
                                spawn_processes, nice_name, minimize, maximize, make_key_funcs,
                                query_loop, run_compare)
     from .matrix_normal_exps_cy import (quadexpect, exp_a2bc, exp_dotprod_sq, mn_kl_divergence,
-                                        matrixnormal_gradient)
+                                        matrixnormal_gradient, logabsdet)
     from .pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
 except ImportError:      # top-level import (package directory on sys.path, like python-pmf/)
     import _lib
@@ -25,7 +25,7 @@ except ImportError:      # top-level import (package directory on sys.path, like
                               spawn_processes, nice_name, minimize, maximize, make_key_funcs,
                               query_loop, run_compare)
     from matrix_normal_exps_cy import (quadexpect, exp_a2bc, exp_dotprod_sq, mn_kl_divergence,
-                                       matrixnormal_gradient)
+                                       matrixnormal_gradient, logabsdet)
     from pmf_cy import ProbabilisticMatrixFactorization, parse_fit_type  # noqa: F401
 
 MNActivePMFEvaluator = _Evaluator
@@ -95,10 +95,8 @@ class MNActivePMF(_ActiveBase):
 
     def _approx_entropy(self):
         '''Entropy of the approximation, up to an additive constant.'''
-        ui_sign, ui_logdet = np.linalg.slogdet(self.cov_useritems)
-        l_sign, l_logdet = np.linalg.slogdet(self.cov_latents)
-        assert ui_sign == 1
-        assert l_sign == 1
+        ui_logdet = logabsdet(self.cov_useritems)
+        l_logdet = logabsdet(self.cov_latents)
         return 0.5 * (self.latent_d * ui_logdet
                       + (self.num_users + self.num_items) * l_logdet)
 

@@ -123,6 +123,10 @@ def _normal_grad(mean, cov, ratings, d, u, v, sig, sig_u, sig_v):
     grad_mean[vs] += mean[vs] / sig_v
     grad_cov[us, us] += 1 / (2 * sig_u)
     grad_cov[vs, vs] += 1 / (2 * sig_v)
-    inv = np.linalg.inv(cov)
+    try:
+        from .matrix_normal_exps_cy import inverse
+    except ImportError:
+        from matrix_normal_exps_cy import inverse
+    inv = inverse(cov)     # (n+m)d x (n+m)d, on the device
     grad_cov -= (inv + inv.T * (1 - np.eye(cov.shape[0]))) / 2
     return grad_mean, grad_cov

@@ -232,6 +232,19 @@ int apmf_grid_gather_f64(apmf_ctx *ctx, const double *d_grid, int ld, const int3
 int apmf_pool_argext_f64(apmf_ctx *ctx, const double *d_vals, int64_t P, int want,
                          int64_t *h_pos, double *h_val);
 
+/* ---- dense symmetric linear algebra of the variational fit (libapmf_dense.so) -----------
+ * Exported by a second shared library (rocSOLVER / rocBLAS underneath) that shares the
+ * apmf_ctx of libapmf_hip.so.  d_mat is an N x N float64 matrix, N = n + m (or d).
+ *
+ * project_psd(), mn_active_pmf.py:42-67 / active_pmf.py:36-50: symmetrise in place; if the
+ * smallest eigenvalue is < min_eig rebuild the matrix with its spectrum clipped at min_eig
+ * (then symmetrise again).  *h_projected tells which branch ran. */
+int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, int *h_projected);
+/* np.linalg.inv and the log|det| of np.linalg.slogdet (matrix_normal_exps_cy.pyx:180-182,
+ * 477-485) by LU (getrf / getri, like NumPy): d_inv (N x N, nullable) and *h_logdet
+ * (nullable).  Singular -> APMF_ENOTPD (NumPy raises LinAlgError("Singular matrix")). */
+int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_inv, double *h_logdet);
+
 #ifdef __cplusplus
 }
 #endif

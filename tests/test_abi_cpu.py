@@ -23,9 +23,9 @@ def test_header_and_binding_agree(lib):
     declared -= {'apmf_status'}
     bound = set(lib.exported_symbols())
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
-    so = lib.load()
+    so, dense = lib.load(), lib.load_dense()
     for name in declared:
-        assert getattr(so, name) is not None
+        assert getattr(dense if name.startswith('apmf_dense_') else so, name) is not None
 
 
 def test_no_gpu_fails_loudly(lib):

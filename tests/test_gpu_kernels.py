@@ -520,3 +520,38 @@ def test_sample_stats_golden(ctx, name):
     assert tuple(g['which'][:, np.argmax(v[which])]) == tuple(g['pick_argmax'])
     ctx.sample_stats(S, n, m, d, ld, dU, dV, add, 0.5, prob=prob)
     np.testing.assert_array_equal(ctx.download_grid(prob, m), g['prob_ge_full'])
+
+
+# ---------------------------------------------------------------------------- dense (rocSOLVER)
+@pytest.mark.parametrize('N', [3, 17, 64, 200])
+def test_dense_project_psd_and_inverse(ctx, N):
+    rs = np.random.RandomState(N)
+    a = rs.normal(size=(N, N))
+    # indefinite, asymmetric input: the projection branch (mn_active_pmf.py:61-66)
+    d = ctx.array(a)
+    assert ctx.dense_project_psd(d, N, 1e-5) is True
+    out = d.to_host()
+    sym = (a + a.T) / 2
+    w, v = np.linalg.eigh(sym)
+    ref = (v * np.maximum(w, 1e-5)) @ v.T
+    ref = (ref + ref.T) / 2
+    np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-10 * np.abs(ref).max())
+    assert np.array_equal(out, out.T)
+    # already PD: only symmetrised
+    spd = a @ a.T + N * np.eye(N)
+    skew = spd + 1e-3 * (a - a.T)
+    d2 = ctx.array(skew)
+    assert ctx.dense_project_psd(d2, N, 1e-5) is False
+    np.testing.assert_allclose(d2.to_host(), (skew + skew.T) / 2, rtol=1e-15)
+    # inverse + log|det| (np.linalg.inv / slogdet)
+    inv = ctx.empty((N, N))
+    ld = ctx.dense_inv_logdet(ctx.array(spd), N, inv)
+    np.testing.assert_allclose(inv.to_host(), np.linalg.inv(spd), rtol=1e-9, atol=1e-12)
+    assert abs(ld - np.linalg.slogdet(spd)[1]) <= 1e-11 * abs(ld) + 1e-12
+    gen = a + N * np.eye(N)                      # general (non-symmetric) matrix
+    inv2 = ctx.empty((N, N))
+    ld2 = ctx.dense_inv_logdet(ctx.array(gen), N, inv2)
+    np.testing.assert_allclose(inv2.to_host(), np.linalg.inv(gen), rtol=1e-9, atol=1e-12)
+    assert abs(ld2 - np.linalg.slogdet(gen)[1]) <= 1e-11 * abs(ld2) + 1e-12
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.dense_inv_logdet(ctx.array(np.zeros((N, N))), N, inv2)
