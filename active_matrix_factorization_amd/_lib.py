@@ -101,20 +101,11 @@ def exported_symbols():
 
 
 def load_dense():
-    """dlopen libapmf_dense.so (rocSOLVER / rocBLAS underneath) on first use."""
-    global _dense
+    """libapmf_dense.so (rocSOLVER / rocBLAS underneath); opened by load()."""
     load()
-    with _lock:
-        if _dense is None:
-            if not os.path.exists(DENSE_LIB_PATH):
-                raise ApmfError(ENODEV, 'HIP extension %s is not built; there is no CPU fallback'
-                                % DENSE_LIB_PATH)
-            lib = C.CDLL(DENSE_LIB_PATH, mode=C.RTLD_GLOBAL)
-            for name, (res, args) in _DENSE_SIGS.items():
-                fn = getattr(lib, name)
-                fn.restype = res
-                fn.argtypes = args
-            _dense = lib
+    if _dense is None:
+        raise ApmfError(ENODEV, 'HIP extension %s is not built; there is no CPU fallback'
+                        % DENSE_LIB_PATH)
     return _dense
 
 
@@ -133,7 +124,23 @@ def load():
                 fn.restype = res
                 fn.argtypes = args
             _lib = lib
+            # libapmf_dense.so pulls in rocSOLVER / rocBLAS, whose (very large) device-code
+            # bundles must be registered with the HIP runtime BEFORE the first kernel launch of
+            # the process: registered afterwards they are unpacked eagerly, which takes minutes.
+            # So it is opened here, together with the main library, never later.
+            _open_dense()
     return _lib
+
+
+def _open_dense():
+    global _dense
+    if _dense is None and os.path.exists(DENSE_LIB_PATH):
+        lib = C.CDLL(DENSE_LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _DENSE_SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _dense = lib
 
 
 def _check(status):
