@@ -97,17 +97,26 @@ def _ctx():
     return _lib.default_context()
 
 
+HOST_DENSE_MAX = 16   # d x d matrices up to this size stay host LAPACK work (like the
+                      # hyper-parameter draws); the (n+m) x (n+m) ones go to the device
+
+
 def logabsdet(mat):
-    """np.linalg.slogdet(mat)[1] on the device (LU via rocSOLVER, libapmf_dense.so)."""
-    ctx = _ctx()
+    """np.linalg.slogdet(mat)[1]; on the device (LU via rocSOLVER, libapmf_dense.so) beyond
+    HOST_DENSE_MAX."""
     mat = np.ascontiguousarray(mat, np.float64)
+    if mat.shape[0] <= HOST_DENSE_MAX:
+        return float(np.linalg.slogdet(mat)[1])
+    ctx = _ctx()
     return ctx.dense_inv_logdet(ctx.array(mat), mat.shape[0], None, want_logdet=True)
 
 
 def inverse(mat):
-    """np.linalg.inv(mat) on the device (getrf + getri via rocSOLVER)."""
-    ctx = _ctx()
+    """np.linalg.inv(mat); on the device (getrf + getri via rocSOLVER) beyond HOST_DENSE_MAX."""
     mat = np.ascontiguousarray(mat, np.float64)
+    if mat.shape[0] <= HOST_DENSE_MAX:
+        return np.linalg.inv(mat)
+    ctx = _ctx()
     out = ctx.empty(mat.shape)
     ctx.dense_inv_logdet(ctx.array(mat), mat.shape[0], out, want_logdet=False)
     return out.to_host()
