@@ -128,7 +128,10 @@ def load():
             # bundles must be registered with the HIP runtime BEFORE the first kernel launch of
             # the process: registered afterwards they are unpacked eagerly, which takes minutes.
             # So it is opened here, together with the main library, never later.
-            _open_dense()
+            try:
+                _open_dense()
+            except OSError:
+                pass     # dense_* calls will raise; the main library is unaffected
     return _lib
 
 

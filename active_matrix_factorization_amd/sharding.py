@@ -38,13 +38,16 @@ class Comm(object):
         self.dist = None
         self.rank, self.world = 0, 1
         self.device = device
-        try:
+        # torch is only touched when the caller has already imported it (a process group can
+        # only exist then).  Import order matters on ROCm: torch bundles its own rocBLAS /
+        # rocSOLVER, so in a multi-GPU run `import torch` must come BEFORE the first Context
+        # (libapmf_dense.so then binds to the copies torch loaded).
+        import sys
+        if 'torch' in sys.modules:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
                 self.dist = dist
                 self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        except ImportError:
-            pass
 
     def _tensor(self, a):
         import torch
