@@ -39,7 +39,8 @@ def _worker(rank, world, port, q):
 
 
 def test_hip_engine_two_ranks_one_gpu():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp   # NOT torch.multiprocessing: the parent must not import torch
+                                   # after the HIP libraries are loaded (see sharding.Comm)
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]

@@ -40,7 +40,8 @@ def _worker(rank, world, port, q):
 
 @pytest.mark.parametrize('world', [2, 3])
 def test_sharded_path_gloo(world):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp   # NOT torch.multiprocessing: the parent must not import torch
+                                   # after the HIP libraries are loaded (see sharding.Comm)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
