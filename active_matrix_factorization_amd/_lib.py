@@ -87,6 +87,8 @@ _SIGS = {
 _DENSE_SIGS = {
     'apmf_dense_project_psd': (_i, [_vp, _vp, _i, _dbl, C.POINTER(_i)]),
     'apmf_dense_inv_logdet': (_i, [_vp, _vp, _i, _vp, C.POINTER(_dbl)]),
+    'apmf_mn_kl_value': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, C.POINTER(_dbl)]),
+    'apmf_mn_kl_gradient': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
 }
 DENSE_LIB_PATH = os.path.join(_HERE, 'libapmf_dense.so')
 
@@ -424,6 +426,17 @@ class Context(object):
         _check(load_dense().apmf_dense_inv_logdet(self._h, _ptr(dmat), N, _ptr(dinv),
                                                   C.byref(ld) if want_logdet else None))
         return ld.value
+
+    def mn_kl_value(self, rt, d, mean, cov_ui, cov_lat, sig, sig_u, sig_v):
+        kl = _dbl(0.)
+        _check(load_dense().apmf_mn_kl_value(self._h, rt._h, d, _ptr(mean), _ptr(cov_ui), _ptr(cov_lat),
+                                             sig, sig_u, sig_v, C.byref(kl)))
+        return kl.value
+
+    def mn_kl_gradient(self, rt, d, mean, cov_ui, cov_lat, sig, sig_u, sig_v, g_mean, g_cov_ui, g_cov_lat):
+        _check(load_dense().apmf_mn_kl_gradient(self._h, rt._h, d, _ptr(mean), _ptr(cov_ui),
+                                                _ptr(cov_lat), sig, sig_u, sig_v, _ptr(g_mean),
+                                                _ptr(g_cov_ui), _ptr(g_cov_lat)))
 
     # -- K3 / K4 -----------------------------------------------------------------------
     def gibbs_half_sweep(self, rt, side, oth, d, alpha, mu, beta, mean_sub, z, out):

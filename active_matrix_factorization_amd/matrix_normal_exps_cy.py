@@ -7,10 +7,9 @@ cov_cols) and the KL objective / gradient of the variational fit.
   entries.  The hot loop that called exp_dotprod_sq once per candidate in the reference is
   replaced by the batched HIP kernels behind MNActivePMF (K2, csrc/k2_score.hip).
 * mn_kl_divergence / matrixnormal_gradient are the variational-fit pair (SURVEY.md 8(f)
-  rank 1, "next").  This round the per-rating sums of the gradient are vectorised over the
-  ratings on the host; the per-rating E[(U_i.V_j)^2] terms of the KL come from the K2 pool
-  kernel and the (n+m) x (n+m) inverse / log-determinant run on the device (rocSOLVER behind
-  libapmf_dense.so).  The reference's quirks are reproduced on purpose (see each comment).
+  rank 1).  Both run on the device: the per-rating sums as the K5 kernels
+  (csrc/k5_klgrad.hip), the (n+m) x (n+m) inverse / log-determinant through rocSOLVER
+  (libapmf_dense.so).  The reference's quirks are reproduced on purpose (see each comment).
 """
 import numpy as np
 
@@ -76,19 +75,6 @@ def exp_dotprod_sq(num_users, mean, cov_useritems, cov_latents, i, j):
     return e
 
 
-def _rating_operands(num_users, ratings, mean, cov_useritems):
-    ii = ratings[:, 0].astype(np.intp)
-    jj = ratings[:, 1].astype(np.intp) + num_users
-    return (ii, jj, ratings[:, 2], mean[ii], mean[jj], cov_useritems[ii, jj],
-            cov_useritems[ii, ii], cov_useritems[jj, jj])
-
-
-def _upper_mirrored(cov_latents):
-    # the reference only reads cov_latents[k, l] with k <= l
-    up = np.triu(cov_latents)
-    return up + np.triu(cov_latents, 1).T
-
-
 def _ctx():
     try:
         from . import _lib
@@ -122,49 +108,28 @@ def inverse(mat):
     return out.to_host()
 
 
-def _e_dot_sq_on_device(num_users, ratings, mean, cov_useritems, cov_latents):
-    """E[(U_i.V_j)^2] of every rated entry = Var + E^2 from the K2 pool kernel (no host path)."""
-    ctx = _ctx()
-    n = int(num_users)
-    m, d = mean.shape[0] - n, mean.shape[1]
-    cov_useritems = np.asarray(cov_useritems, np.float64)
-    cross = ctx.upload_grid(cov_useritems[:n, n:], np.float64)
-    P = ratings.shape[0]
-    pm, pv = ctx.empty(P), ctx.empty(P)
-    ctx.mn_score_pool(n, m, d, cross.shape[1], ctx.array(mean, np.float64), cross,
-                      ctx.array(np.ascontiguousarray(np.diagonal(cov_useritems)), np.float64),
-                      ctx.array(cov_latents, np.float64),
-                      ctx.array(np.ascontiguousarray(ratings[:, 0], np.int32), np.int32),
-                      ctx.array(np.ascontiguousarray(ratings[:, 1], np.int32), np.int32), P, pm, pv)
-    pm, pv = pm.to_host(), pv.to_host()
-    return pv + pm * pm
+def _ratings_on_device(ctx, ratings, num_users, num_useritems):
+    return ctx.ratings(np.ascontiguousarray(ratings, np.float64), int(num_users),
+                       int(num_useritems) - int(num_users))
 
 
 def mn_kl_divergence(num_users, ratings, mean, cov_useritems, cov_latents,
-                     sigma_sq, sigma_u_sq, sigma_v_sq, e_dot_sq=None):
+                     sigma_sq, sigma_u_sq, sigma_v_sq, _device_ratings=None):
     '''KL( MN(mean, cov_useritems, cov_latents) || PMF posterior ) up to a constant
-    (matrix_normal_exps_cy.pyx:159-213), quirks included:
+    (matrix_normal_exps_cy.pyx:159-213), evaluated on the device (K5 + LU log-determinants),
+    quirks included:
       * `num_items = num_useritems - num_useritems` = 0, so the item-covariance trace term
         is dropped (:176, :191-192);
-      * the item prior uses sigma_u_sq, not sigma_v_sq (:196-197).
-    e_dot_sq: optional precomputed E[(U_i.V_j)^2] for every rating (from the K2 pool kernel).'''
-    num_useritems, latent_d = mean.shape
-    log_det_useritems = logabsdet(cov_useritems)
-    log_det_latents = logabsdet(cov_latents)
-    kl = -(log_det_useritems * latent_d + log_det_latents * num_useritems) / 2.
-
-    tr_cov_latents = cov_latents.trace()
-    tr_cov_users = np.diagonal(cov_useritems)[:num_users].sum()
-    tr_cov_items = 0.   # sic
-    kl += ((mean[:num_users, :] ** 2).sum() + tr_cov_users * tr_cov_latents) / (2 * sigma_u_sq)
-    kl += ((mean[num_users:, :] ** 2).sum() + tr_cov_items * tr_cov_latents) / (2 * sigma_u_sq)
-
-    ii, jj, r, a, b, s, vi, vj = _rating_operands(num_users, ratings, mean, cov_useritems)
-    pred = (a * b).sum(1) + s * tr_cov_latents
-    if e_dot_sq is None:
-        e_dot_sq = _e_dot_sq_on_device(num_users, ratings, mean, cov_useritems, cov_latents)
-    bit = (e_dot_sq - 2 * r * pred + r * r).sum()
-    return kl + bit / (2 * sigma_sq)
+      * the item prior uses sigma_u_sq, not sigma_v_sq (:196-197).'''
+    ctx = _ctx()
+    mean = np.ascontiguousarray(mean, np.float64)
+    rt = _device_ratings or _ratings_on_device(ctx, ratings, num_users, mean.shape[0])
+    kl = ctx.mn_kl_value(rt, mean.shape[1], ctx.array(mean), ctx.array(cov_useritems, np.float64),
+                         ctx.array(cov_latents, np.float64), float(sigma_sq), float(sigma_u_sq),
+                         float(sigma_v_sq))
+    if _device_ratings is None:
+        rt.free()
+    return kl
 
 
 def matrixnormal_gradient(mn_apmf):
@@ -173,89 +138,29 @@ def matrixnormal_gradient(mn_apmf):
     if mn_apmf is None or mn_apmf.mean is None or mn_apmf.cov_useritems is None \
             or mn_apmf.cov_latents is None:
         raise TypeError("mean, cov are None; run initialize_approx first")
+    rt = mn_apmf._device_ratings()[1] if hasattr(mn_apmf, '_device_ratings') else None
     return _mnormal_grad(mn_apmf.mean, mn_apmf.cov_useritems, mn_apmf.cov_latents,
                          mn_apmf.ratings, mn_apmf.num_users, mn_apmf.latent_d,
-                         mn_apmf.sigma_sq, mn_apmf.sigma_u_sq, mn_apmf.sigma_v_sq)
+                         mn_apmf.sigma_sq, mn_apmf.sigma_u_sq, mn_apmf.sigma_v_sq,
+                         _device_ratings=rt)
 
 
 def _mnormal_grad(mean, cov_useritems, cov_latents, ratings, num_users, latent_d,
-                  sig_sq, sig_u_sq, sig_v_sq):
-    '''matrix_normal_exps_cy.pyx:395-485 with its helpers _quadexp_grad (:250-340) and
-    _squareexp_grad (:344-389), restated with the sums over latent pairs (k < l) in closed
-    matrix form and the sum over ratings as scatter-adds.  Like the reference, the result is
-    the derivative w.r.t. one triangular half written into both halves.'''
-    num_useritems = cov_useritems.shape[0]
-    d = latent_d
-    g_mean = np.zeros_like(mean)
-    g_cu = np.zeros_like(cov_useritems)
-    g_cl = np.zeros_like(cov_latents)
-
-    ii, jj, r, a, b, s, vi, vj = _rating_operands(num_users, ratings, mean, cov_useritems)
-    s_, vi_, vj_ = s[:, None], vi[:, None], vj[:, None]
-    om = _upper_mirrored(cov_latents)
-    dg = np.diagonal(om).copy()
-    off = om - np.diag(dg)
-    T = dg.sum()
-    p = a * b
-    P = p.sum(1, keepdims=True)
-    inv = 1. / sig_sq
-
-    # pairs k < l, each counted once with weight 1/sigma^2: terms of _quadexp_grad
-    gm_i = b * (P - p) + s_ * (b @ off) + vj_ * (a @ off) + b * s_ * (T - dg)
-    gm_j = a * (P - p) + vi_ * (b @ off) + s_ * (a @ off) + a * s_ * (T - dg)
-    off2 = (off * off).sum() / 2.                       # sum_{k<l} Omega_kl^2
-    bob = np.einsum('tk,kl,tl->t', b, off, b) / 2.      # sum_{k<l} b_k b_l Omega_kl
-    aoa = np.einsum('tk,kl,tl->t', a, off, a) / 2.
-    aob = np.einsum('tk,kl,tl->t', a, off, b)           # sum_{k<l} (a_k b_l + a_l b_k) Omega_kl
-    sdd = (T * T - (dg * dg).sum()) / 2.                # sum_{k<l} Omega_kk Omega_ll
-    pdd = (p * (T - dg)).sum(1)                         # sum_{k<l} (p_l O_kk + p_k O_ll)
-    gs_ii = bob + vj * off2
-    gs_jj = aoa + vi * off2
-    gs_ij = pdd + aob + 2 * s * sdd + 2 * s * off2
-    # squares, weight 1/(2 sigma^2): terms of _squareexp_grad
-    e_i = a * a + vi_ * dg
-    e_j = b * b + vj_ * dg
-    gm_i += .5 * (4 * b * s_ * dg + 2 * a * e_j)
-    gm_j += .5 * (4 * a * s_ * dg + 2 * b * e_i)
-    gs_ii += .5 * (e_j * dg).sum(1)
-    gs_jj += .5 * (e_i * dg).sum(1)
-    gs_ij += .5 * (4 * (p + s_ * dg) * dg).sum(1)
-    # linear term  -R_ij E[U_ik V_jk] / sigma^2
-    gm_i -= r[:, None] * b
-    gm_j -= r[:, None] * a
-    gs_ij -= r * T
-
-    np.add.at(g_mean, ii, inv * gm_i)
-    np.add.at(g_mean, jj, inv * gm_j)
-    np.add.at(g_cu, (ii, ii), inv * gs_ii)
-    np.add.at(g_cu, (jj, jj), inv * gs_jj)
-    np.add.at(g_cu, (ii, jj), inv * gs_ij)
-    np.add.at(g_cu, (jj, ii), inv * gs_ij)
-
-    # cov_latents: off-diagonal (both halves), then the diagonal
-    G = ((b * vi_).T @ b + (b * s_).T @ a + (a * s_).T @ b + (a * vj_).T @ a
-         + 2 * om * ((vi * vj).sum() + (s * s).sum()))
-    g_cl += inv * (G - np.diag(np.diagonal(G)))
-    diag_q = (s_ * (P - p) + (s_ * s_) * (T - dg)).sum(0)
-    diag_s = .5 * (4 * p * s_ + 4 * s_ * s_ * dg + vi_ * e_j + e_i * vj_).sum(0)
-    diag_l = -(r * s).sum()
-    g_cl[np.arange(d), np.arange(d)] += inv * (diag_q + diag_s + diag_l)
-
-    # priors  sum E[U_ik^2] / (2 sigma_u^2)  (+ same for V)
-    g_mean[:num_users, :] += mean[:num_users, :] / sig_u_sq
-    g_mean[num_users:, :] += mean[num_users:, :] / sig_v_sq
-    tr_latents = cov_latents.trace()
-    user_idx = np.arange(num_users)
-    item_idx = np.arange(num_users, num_useritems)
-    g_cu[user_idx, user_idx] += tr_latents / (2 * sig_u_sq)
-    g_cu[item_idx, item_idx] += tr_latents / (2 * sig_v_sq)
-    latent_idx = np.arange(d)
-    g_cl[latent_idx, latent_idx] += cov_useritems[user_idx, user_idx].sum() / (2 * sig_u_sq)
-    g_cl[latent_idx, latent_idx] += cov_useritems[item_idx, item_idx].sum() / (2 * sig_v_sq)
-
-    # entropy  d/2 ln det(Sigma) + (n+m)/2 ln det(Omega), w.r.t. a triangular half
-    inv_cu = inverse(cov_useritems)
-    g_cu -= d / 2. * (inv_cu + inv_cu.T * (1 - np.eye(num_useritems)))
-    inv_cl = inverse(cov_latents)
-    g_cl -= num_useritems / 2. * (inv_cl + inv_cl.T * (1 - np.eye(d)))
-    return g_mean, g_cu, g_cl
+                  sig_sq, sig_u_sq, sig_v_sq, _device_ratings=None):
+    '''matrix_normal_exps_cy.pyx:395-485 (+ _quadexp_grad :250-340, _squareexp_grad :344-389)
+    as the K5 kernels (csrc/k5_klgrad.hip): one wave per user / item row accumulates the
+    collapsed pair sums, the (n+m) x (n+m) and d x d inverses of the entropy term come from
+    rocSOLVER.  Returns (g_mean, g_cov_useritems, g_cov_latents) as NumPy arrays; like the
+    reference, the derivative w.r.t. one triangular half is written into both halves.'''
+    ctx = _ctx()
+    mean = np.ascontiguousarray(mean, np.float64)
+    N, d = mean.shape
+    rt = _device_ratings or _ratings_on_device(ctx, ratings, num_users, N)
+    g_mean, g_cu, g_cl = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+    ctx.mn_kl_gradient(rt, d, ctx.array(mean), ctx.array(cov_useritems, np.float64),
+                       ctx.array(cov_latents, np.float64), float(sig_sq), float(sig_u_sq),
+                       float(sig_v_sq), g_mean, g_cu, g_cl)
+    out = g_mean.to_host(), g_cu.to_host(), g_cl.to_host()
+    if _device_ratings is None:
+        rt.free()
+    return out

@@ -68,13 +68,9 @@ class MNActivePMF(_ActiveBase):
         cov_useritems = self.cov_useritems if cov_useritems is None else cov_useritems
         cov_latents = self.cov_latents if cov_latents is None else cov_latents
         self._require_approx(mean, cov_useritems, cov_latents)
-        # E[(U_i.V_j)^2] of every rated entry = Var + E^2, from the K2 pool kernel
-        pi = np.ascontiguousarray(self.ratings[:, 0], np.int32)
-        pj = np.ascontiguousarray(self.ratings[:, 1], np.int32)
-        pm, pv = self._score_pool(pi, pj, (mean, cov_useritems, cov_latents))
         return mn_kl_divergence(self.num_users, self.ratings, mean, cov_useritems, cov_latents,
                                 self.sigma_sq, self.sigma_u_sq, self.sigma_v_sq,
-                                e_dot_sq=pv + pm * pm)
+                                _device_ratings=self._device_ratings()[1])
 
     def fit_normal_kls(self):
         '''Projected gradient descent on the KL, yielding it after each accepted step

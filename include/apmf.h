@@ -245,6 +245,20 @@ int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, 
  * (nullable).  Singular -> APMF_ENOTPD (NumPy raises LinAlgError("Singular matrix")). */
 int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_inv, double *h_logdet);
 
+/* ---- K5: KL objective and gradient of the matrix-normal variational fit (libapmf_dense.so)
+ * d_mean (n+m, d), d_cov_useritems (n+m, n+m), d_cov_latents (d, d), float64, device.
+ * mn_kl_divergence(), matrix_normal_exps_cy.pyx:159-213 (quirks kept: the item-covariance
+ * trace term is dropped and the item prior uses sigma_u_sq). */
+int apmf_mn_kl_value(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                     const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
+                     double sigma_u_sq, double sigma_v_sq, double *h_kl);
+/* matrixnormal_gradient() / _mnormal_grad(), matrix_normal_exps_cy.pyx:216-485: gradient
+ * w.r.t. one triangular half written into both halves, like the reference. */
+int apmf_mn_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                        const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
+                        double sigma_u_sq, double sigma_v_sq, double *d_g_mean,
+                        double *d_g_cov_useritems, double *d_g_cov_latents);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ def test_header_and_binding_agree(lib):
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
     so, dense = lib.load(), lib.load_dense()
     for name in declared:
-        assert getattr(dense if name.startswith('apmf_dense_') else so, name) is not None
+        assert getattr(dense if name in lib._DENSE_SIGS else so, name) is not None
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -555,3 +555,44 @@ def test_dense_project_psd_and_inverse(ctx, N):
     assert abs(ld2 - np.linalg.slogdet(gen)[1]) <= 1e-11 * abs(ld2) + 1e-12
     with pytest.raises(np.linalg.LinAlgError):
         ctx.dense_inv_logdet(ctx.array(np.zeros((N, N))), N, inv2)
+
+
+# ---------------------------------------------------------------------------- K5 (variational fit)
+@pytest.mark.parametrize('shape', [(7, 5, 1), (13, 9, 2), (30, 41, 5), (25, 60, 10), (40, 33, 16), (12, 10, 23)])
+def test_kl_gradient_and_value_vs_numpy(ctx, shape):
+    """K5 kernels vs an independent NumPy restatement of matrix_normal_exps_cy.pyx:395-485
+    (tests/mn_grad_numpy.py, itself pinned to the reference's golden gradients elsewhere)."""
+    import mn_grad_numpy as ref
+    n, m, d = shape
+    rs = np.random.RandomState(n * 100 + d)
+    N = n + m
+    pairs = rs.permutation(n * m)[:min(n * m, 4 * N)]
+    ii, jj = np.concatenate([np.arange(n), pairs // m]), np.concatenate([rs.randint(0, m, n), pairs % m])
+    keep = np.unique(ii * m + jj, return_index=True)[1]          # unique (i, j)
+    ii, jj = ii[np.sort(keep)], jj[np.sort(keep)]
+    ratings = np.column_stack([ii, jj, rs.normal(2, 1, ii.size)]).astype(float)
+    mean = rs.normal(size=(N, d))
+    A = rs.normal(size=(N, N)) / np.sqrt(N)
+    S = A @ A.T + .3 * np.eye(N)
+    Bm = rs.normal(size=(d, d)) / np.sqrt(d)
+    O = Bm @ Bm.T + .2 * np.eye(d)
+    sig, su, sv = 0.7, 4.0, 6.0
+    rt = ctx.ratings(ratings, n, m)
+    gm, gs, go = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+    ctx.mn_kl_gradient(rt, d, ctx.array(mean), ctx.array(S), ctx.array(O), sig, su, sv, gm, gs, go)
+    rm, rsg, ro = ref._mnormal_grad(mean, S, O, ratings, n, d, sig, su, sv)
+    np.testing.assert_allclose(gm.to_host(), rm, rtol=1e-10, atol=1e-10 * np.abs(rm).max())
+    np.testing.assert_allclose(gs.to_host(), rsg, rtol=1e-9, atol=1e-10 * np.abs(rsg).max())
+    np.testing.assert_allclose(go.to_host(), ro, rtol=1e-9, atol=1e-10 * np.abs(ro).max())
+    # KL value against the oracle's per-rating E[(u.v)^2] and NumPy log-determinants
+    kl = ctx.mn_kl_value(rt, d, ctx.array(mean), ctx.array(S), ctx.array(O), sig, su, sv)
+    trO = np.trace(O)
+    bit = 0.
+    for i, j, r in ratings:
+        i, j = int(i), int(j)
+        e2 = orc.mn_exp_dotprod_sq(n, mean, S, O, i, j)
+        bit += e2 - 2 * r * ((mean[i] * mean[n + j]).sum() + S[i, n + j] * trO) + r * r
+    ref_kl = (-(np.linalg.slogdet(S)[1] * d + np.linalg.slogdet(O)[1] * N) / 2.
+              + ((mean[:n] ** 2).sum() + np.trace(S[:n, :n]) * trO) / (2 * su)
+              + ((mean[n:] ** 2).sum()) / (2 * su) + bit / (2 * sig))
+    assert abs(kl - ref_kl) <= 1e-10 * abs(ref_kl)

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Variational fit (fit_normal_kls) at the MovieLens shape: time per
+accepted step and where it goes.  Dev tool; numbers go to BASELINE.md."""
+import os, sys, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from active_matrix_factorization_amd import mn_active_pmf, matrix_normal_exps_cy as mnx
+from active_matrix_factorization_amd._active_base import project_psd
+
+ratings, _ = bench.synth_ratings(0)
+np.random.seed(1)
+a = mn_active_pmf.MNActivePMF(ratings, latent_d=10)
+a.do_fit()
+a.initialize_approx()
+out = {}
+t0 = time.perf_counter(); g = mnx.matrixnormal_gradient(a); out['gradient_s'] = time.perf_counter() - t0
+t0 = time.perf_counter(); kl = a.kl_divergence(); out['kl_s'] = time.perf_counter() - t0
+t0 = time.perf_counter(); p = project_psd(a.cov_useritems - 1e-4 * g[1], 1e-5); out['project_psd_s'] = time.perf_counter() - t0
+it = a.fit_normal_kls()
+t0 = time.perf_counter(); kls = [next(it) for _ in range(3)]; out['three_accepted_steps_s'] = time.perf_counter() - t0
+out['kls'] = kls
+print(json.dumps(out, indent=1))
