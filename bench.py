@@ -13,7 +13,10 @@ Workload (config.workload = "943x1682-d10-B256", BASELINE.json configs[1] shape)
     gradient + trial log-likelihood + update) on the synthetic N = 100 000 ratings, f64.
 Multi-GPU (--gpus N, one process per GPU): posterior states and independent PMF refits are
 sharded across ranks (each rank owns B states / its own refit); the sweep has no data-path
-collective, so scaling is weak and `value` is the whole-job aggregate.
+collective, so scaling is weak and `value` is the whole-job aggregate.  The path's one real
+exchange step - after an outer iteration every rank publishes its row block of the refitted
+factors U, V and of diag(Sigma) - is an RCCL all-gather (torch.distributed "nccl" group) issued
+once per step on its own stream, overlapped with the next sweep.
 """
 import argparse
 import json
@@ -97,6 +100,39 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # exchange step over RCCL (xGMI): (n + m) x (d + 1) float64 factor/diagonal blocks
+    exch = {'group': None, 'note': 'single rank: no exchange'}
+    if dist is not None:
+        # torch (with its bundled rocBLAS) is already imported: now the HIP libraries may load
+        from active_matrix_factorization_amd import _lib as _early
+        _early.load()
+        try:
+            import torch
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) %
+                                  max(torch.cuda.device_count(), 1))
+            grp = dist.new_group(backend='nccl')
+            rows = -(-(N_USERS + N_ITEMS) // world)
+            blk = torch.randn(rows, LATENT_D + 1, dtype=torch.float64, device='cuda')
+            full = torch.empty(world * rows, LATENT_D + 1, dtype=torch.float64, device='cuda')
+            dist.all_gather_into_tensor(full, blk, group=grp)
+            torch.cuda.synchronize()
+            exch = {'group': grp, 'blk': blk, 'full': full, 'torch': torch,
+                    'note': 'RCCL all_gather_into_tensor of %d x %d f64 per rank per step, overlapped'
+                            % (rows, LATENT_D + 1)}
+        except Exception as e:     # never let the plumbing take the measurement down
+            exch = {'group': None, 'note': 'exchange skipped: %s' % str(e).splitlines()[0][:160]}
+
+    def exchange():
+        if exch['group'] is not None:
+            return dist.all_gather_into_tensor(exch['full'], exch['blk'], group=exch['group'],
+                                               async_op=True)
+        return None
+
+    def device_sync():
+        ctx.sync()
+        if exch['group'] is not None:
+            exch['torch'].cuda.synchronize()
+
     def max_over_ranks(x):
         if dist is None:
             return x
@@ -133,14 +169,21 @@ def main():
     # ------------------------------------------------------------------ region A: scoring
     for _ in range(W):
         sweep()
-    ctx.sync()
+        exchange()
+    device_sync()
     barrier()
     ctx.profile_begin(min(K, 1024))
-    ctx.sync()
+    device_sync()
     t0 = time.perf_counter()
+    pending = None
     for _ in range(K):
-        sweep()
-    ctx.sync()
+        sweep()                 # enqueued on the ctx stream
+        if pending is not None:
+            pending.wait()
+        pending = exchange()    # RCCL stream: runs beside the sweep just enqueued
+    if pending is not None:
+        pending.wait()
+    device_sync()
     barrier()
     t_score = max_over_ranks(time.perf_counter() - t0)
     kern_ms = ctx.profile_end()
@@ -207,7 +250,8 @@ def main():
             'config': {'workload': '943x1682-d10-B%d' % B, 'states_per_gpu': B,
                        'candidates_per_step_per_gpu': cand_per_step,
                        'outputs': 'scores written + per-state sum + arg-max over unrated',
-                       'parallelism': 'states sharded over %d rank(s), no data-path collective' % world},
+                       'parallelism': 'states sharded over %d rank(s), no collective inside the sweep' % world,
+                       'exchange': exch['note']},
             'roofline': {'bound': 'hbm', 'kernel': 'k_mn_grid<float,10,4>',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS if achieved else None,
