@@ -89,7 +89,7 @@ def main():
         args.gpus = world
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('APMF_BENCH_FORCE_EXCHANGE'):   # the latter: one-rank rehearsal
         # torch.distributed is plumbing only: rendezvous, barrier and the max over ranks
         import torch
         import torch.distributed as dist
