@@ -148,6 +148,17 @@ def main():
             p.update_sigma()
             p.update_sigma_uv()
             out.update(sigma_after=np.array([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq]))
+            # fit_with_sigmas_lls (pmf_cy.pyx:384-403) from the SAME start: LL trace with the
+            # variance updates interleaved, first 40 yields
+            q = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=d,
+                                                        subtract_mean=subtract_mean)
+            q.users, q.items = U0.copy(), V0.copy()
+            if sig is not None:
+                q.sigma_sq, q.sigma_u_sq, q.sigma_v_sq = sig
+            from itertools import islice as _isl
+            sig_trace = np.array(list(_isl(q.fit_with_sigmas_lls(), 40)))
+            out.update(sigmas_ll_trace=sig_trace, sigmas_U=q.users.copy(), sigmas_V=q.items.copy(),
+                       sigmas_final=np.array([q.sigma_sq, q.sigma_u_sq, q.sigma_v_sq]))
         save(name, **out)
 
     # config 1: generate.py 10x10 rank-2 discrete, known diagonal
@@ -280,10 +291,20 @@ def main():
         pool = list(a.unrated)
         vals = a._get_key_vals(pool, active_pmf.ActivePMF.pred_variance, 1, None)
         pick = a.pick_query_point(key=active_pmf.ActivePMF.pred_variance)
-        save(name, ratings=ratings, d=d, users=a.users, items=a.items,
-             mean=a.mean, cov=a.cov, p_mean=p_mean, p_var=p_var,
-             pool=np.array(pool), pool_vals=np.array(vals), pick_max=np.array(pick),
-             kl=a.kl_divergence(), u_idx=a.u, v_idx=a.v)
+        out = dict(ratings=ratings, d=d, users=a.users, items=a.items,
+                   mean=a.mean, cov=a.cov, p_mean=p_mean, p_var=p_var,
+                   pool=np.array(pool), pool_vals=np.array(vals), pick_max=np.array(pick),
+                   kl=a.kl_divergence(), u_idx=a.u, v_idx=a.v,
+                   sigma=np.array([a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq]))
+        g_mean, g_cov = nx.normal_gradient(a)
+        out.update(g_mean=g_mean, g_cov=g_cov)
+        kls = []
+        for k, kl in enumerate(a.fit_normal_kls()):
+            kls.append(kl)
+            if k >= 2:
+                break
+        out.update(kl_trace=np.array(kls), mean_fit=a.mean, cov_fit=a.cov)
+        save(name, **out)
 
     seed(20)
     r, _, _ = fake(6, 5, 3, 2)
@@ -383,6 +404,22 @@ def main():
                init_cov_useritems=init.cov_useritems,
                init_cov_latents=init.cov_latents)
     save('trace_c1_mn', **out)
+
+    # ------------------------- E2. one-step lookahead criteria on config 1 (mn_active_pmf.py:600-696)
+    seed(41)
+    a = mn_active_pmf.MNActivePMF(ratings_c1.copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5),
+                                  discrete_expectations=True)
+    a.do_fit()
+    a.initialize_approx()
+    a.fit_normal()
+    cand = sorted(a.unrated)[7]
+    save('lookahead_c1_mn', ratings=ratings_c1, users=a.users, items=a.items, mean=a.mean,
+         cov_useritems=a.cov_useritems, cov_latents=a.cov_latents, cand=np.array(cand),
+         exp_total_variance=a.exp_total_variance(cand),
+         exp_total_variance_byapprox=a.exp_total_variance_byapprox(cand),
+         exp_approx_entropy=a.exp_approx_entropy(cand),
+         onestep_ge_3_5=a.onestep_ge_3_5(cand),
+         prob_ge_3_5=a.prob_ge_3_5(cand), pred=a.pred(cand))
 
     # ------------------------- F. moments (what test_normal_exps.py pins statistically)
     seed(50)

@@ -404,3 +404,51 @@ def test_module_level_kl_matches_class(pkg):
     i, j = 3, 5
     e2 = mnx.exp_dotprod_sq(a.num_users, a.mean, a.cov_useritems, a.cov_latents, i, j)
     assert e2 == g['e2'][i, j]        # scalar convenience keeps the reference's term order
+
+
+@pytest.mark.parametrize('name,s', PMF_CASES)
+def test_pmf_fit_with_sigmas_golden(pkg, name, s):
+    """fit_with_sigmas_lls (pmf_cy.pyx:384-403): the sigmas change between yields while the search
+    keeps comparing against the LL of the previous step - carried across device calls."""
+    g = load_golden(name)
+    p = _make_pmf(pkg, g, s)
+    want = g['sigmas_ll_trace']
+    got = np.array(list(islice(p.fit_with_sigmas_lls(), want.size)))
+    assert got.size == want.size
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    if want.size == 40:      # stopped by the islice, not by convergence: same state as recorded
+        np.testing.assert_allclose(p.users, g['sigmas_U'], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq], g['sigmas_final'], rtol=1e-8)
+
+
+@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
+def test_full_variational_fit(pkg, name):
+    """ActivePMF: KL gradient (normal_exps_cy.pyx:217-303, quirks included) and the first accepted
+    steps of fit_normal_kls vs the reference."""
+    g = load_golden(name)
+    a = pkg.full.ActivePMF(g['ratings'].copy(), latent_d=int(g['d']))
+    a.users, a.items, a.mean, a.cov = g['users'].copy(), g['items'].copy(), g['mean'].copy(), g['cov'].copy()
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    gm, gc = pkg.full.normal_gradient(a)
+    np.testing.assert_allclose(gm, g['g_mean'], rtol=1e-9, atol=1e-9 * np.abs(g['g_mean']).max())
+    np.testing.assert_allclose(gc, g['g_cov'], rtol=1e-9, atol=1e-9 * np.abs(g['g_cov']).max())
+    kls = list(islice(a.fit_normal_kls(), g['kl_trace'].size))
+    np.testing.assert_allclose(kls, g['kl_trace'], rtol=1e-8)
+    np.testing.assert_allclose(a.mean, g['mean_fit'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(a.cov, g['cov_fit'], rtol=1e-5, atol=1e-7 * np.abs(g['cov_fit']).max())
+
+
+def test_mn_lookahead_golden(pkg):
+    """One-step lookahead criteria of the reference (mn_active_pmf.py:600-696) on config 1:
+    deepcopy + add_rating + fit_normal (to convergence) + sweep per rating value."""
+    g = load_golden('lookahead_c1_mn')
+    a = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5),
+                           discrete_expectations=True)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+    cand = tuple(int(x) for x in g['cand'])
+    assert abs(a.pred(cand) - g['pred']) <= 1e-12 * abs(g['pred'])
+    assert abs(a.prob_ge_3_5(cand) - g['prob_ge_3_5']) <= 1e-7 * abs(g['prob_ge_3_5']) + 1e-300
+    for key in ('exp_total_variance', 'exp_total_variance_byapprox', 'exp_approx_entropy', 'onestep_ge_3_5'):
+        got = getattr(a, key)(cand)
+        assert abs(got - g[key]) <= 2e-4 * abs(g[key]), (key, got, float(g[key]))

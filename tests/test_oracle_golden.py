@@ -172,3 +172,64 @@ def test_sample_stats(name):
     np.testing.assert_array_equal(p35[which], g['prob_ge'])
     _, _, p05 = orc.sample_stats(g['chain_U'], g['chain_V'], add=add, cutoff=0.5)
     np.testing.assert_array_equal(p05, g['prob_ge_full'])
+
+
+def _fit_with_sigmas_trace(g, count):
+    """fit_with_sigmas_lls (pmf_cy.pyx:384-403) composed from the oracle's gradient / LL: the
+    generator keeps the LL of the previous step as `old_ll` even after the sigmas change."""
+    ratings, d = g['ratings'], int(g['d'])
+    sub, mr = bool(g['subtract_mean']), float(g['mean_rating'])
+    st = dict(zip(('sig', 'sig_u', 'sig_v'), (float(x) for x in g['sigma'])))
+    U, V = g['U0'].copy(), g['V0'].copy()
+    n, m = U.shape[0], V.shape[0]
+
+    def ll(A, B):
+        return orc.pmf_log_likelihood(ratings, A, B, subtract_mean=sub, mean_rating=mr, **st)
+
+    def fit_lls():
+        nonlocal U, V
+        lr, old_ll, conv = 1e-4, ll(U, V), False
+        while not conv:
+            gU, gV = orc.pmf_gradient(ratings, U, V, subtract_mean=sub, mean_rating=mr, **st)
+            while True:
+                nU, nV = U + lr * gU, V + lr * gV
+                new_ll = ll(nU, nV)
+                if new_ll > old_ll:
+                    U, V = nU, nV
+                    lr *= 1.25
+                    if new_ll - old_ll < 1e-2:
+                        conv = True
+                    yield new_ll
+                    old_ll = new_ll
+                    break
+                lr *= .5
+                if lr < 1e-10:
+                    conv = True
+                    break
+
+    out, cont = [], True
+    while cont and len(out) < count:
+        cont = False
+        for i, v in enumerate(fit_lls()):
+            if i % 5 == 0:
+                st['sig'] = orc.pmf_sq_error(ratings, U, V, sub, mr) / ratings.shape[0]
+            if i % 2 == 0:
+                st['sig_u'] = (U * U).sum() / n / d
+                st['sig_v'] = (V * V).sum() / m / d
+            out.append(v)
+            cont = True
+            if len(out) >= count:
+                return np.array(out), U, V, st
+        st['sig'] = orc.pmf_sq_error(ratings, U, V, sub, mr) / ratings.shape[0]
+        st['sig_u'] = (U * U).sum() / n / d
+        st['sig_v'] = (V * V).sum() / m / d
+    return np.array(out), U, V, st
+
+
+@pytest.mark.parametrize('name', PMF_CASES)
+def test_pmf_fit_with_sigmas_trace(name):
+    g = load_golden(name)
+    want = g['sigmas_ll_trace']
+    got, U, V, st = _fit_with_sigmas_trace(g, want.size)
+    assert got.size == want.size
+    np.testing.assert_allclose(got, want, rtol=1e-9)
