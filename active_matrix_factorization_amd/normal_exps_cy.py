@@ -88,9 +88,20 @@ def _normal_grad(mean, cov, ratings, d, u, v, sig, sig_u, sig_v):
     up = np.triu(np.ones((d, d)), 1)                                   # [k, l] = 1 for l > k
 
     g_mu = np.empty_like(mu)
-    # pairs k != l (normal_exps_cy.pyx:239-249)
-    g_mu[:, :d] = b * Eo + np.einsum('txy,ty->tx', Cvv * off, a) + np.einsum('tyx,ty->tx', Cuv * off, b)
-    g_mu[:, d:] = a * Eo + np.einsum('txy,ty->tx', Cuu * off, b) + np.einsum('txy,ty->tx', Cuv * off, a)
+    # pairs k < l (normal_exps_cy.pyx:239-249).  The k-side entries get their own sums over l;
+    # the l-side entries all receive the SAME scalar - sum_tripexpect_ccl() sums over l before
+    # `grad_mean[uli] += ...` broadcasts it - so u_x / v_x collect sum_{k < x} S(k).
+    bx, ax = b[:, :, None], a[:, :, None]
+    by, ay = b[:, None, :], a[:, None, :]
+    ey = e[:, None, :]
+    Ku = ((bx * ey + ay * Cvv + by * np.swapaxes(Cuv, 1, 2)) * up).sum(2)
+    Kv = ((ax * ey + ay * Cuv + by * Cuu) * up).sum(2)
+    S1 = ((p[:, :, None] * by + ax * Cvv + bx * Cuv + by * cuv[:, :, None]) * up).sum(2)
+    S2 = ((p[:, :, None] * ay + ax * np.swapaxes(Cuv, 1, 2) + bx * Cuu + ay * cuv[:, :, None]) * up).sum(2)
+    Lu = np.cumsum(S1, axis=1) - S1          # sum over k < x
+    Lv = np.cumsum(S2, axis=1) - S2
+    g_mu[:, :d] = Ku + Lu
+    g_mu[:, d:] = Kv + Lv
     # squares and the linear term (:266-280)
     g_mu[:, :d] += 2 * b * cuv + a * (b * b + cvv) - b * r[:, None]
     g_mu[:, d:] += 2 * a * cuv + b * (a * a + cuu) - a * r[:, None]
