@@ -596,3 +596,52 @@ def test_kl_gradient_and_value_vs_numpy(ctx, shape):
               + ((mean[:n] ** 2).sum() + np.trace(S[:n, :n]) * trO) / (2 * su)
               + ((mean[n:] ** 2).sum()) / (2 * su) + bit / (2 * sig))
     assert abs(kl - ref_kl) <= 1e-10 * abs(ref_kl)
+
+
+# ---------------------------------------------------------------------------- rank-64 shape (configs[4] family)
+def test_rank64_paths(ctx):
+    """The d = 64 code paths (BASELINE.json configs[4] uses rank 64) at a size the oracle still
+    checks in seconds: K1 gradient/LL, K2 f32 sweep with fused reductions, K3 half-sweep."""
+    rs = np.random.RandomState(64)
+    n, m, d, N = 1500, 1100, 64, 120000
+    flat = rs.choice(n * m, N, replace=False)
+    ii, jj = flat // m, flat % m
+    ii[:n], jj[:m] = np.arange(n), np.arange(m)                  # every row / column rated
+    ratings = np.column_stack([ii, jj, rs.normal(size=N)]).astype(float)
+    U, V = rs.normal(size=(n, d)) / 4, rs.normal(size=(m, d)) / 4
+    kw = dict(sig=1., sig_u=10., sig_v=10., subtract_mean=False, mean_rating=0.)
+    gU, gV, ll, _ = _grad(ctx, ratings, U, V, kw)
+    oU, oV = orc.pmf_gradient(ratings, U, V, **kw)
+    np.testing.assert_allclose(gU, oU, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(gV, oV, rtol=1e-10, atol=1e-10)
+    assert abs(ll - orc.pmf_log_likelihood(ratings, U, V, **kw)) <= 1e-12 * abs(ll)
+    # K2, f32, two states, compact inputs
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld, B = grid_ld(m), 2
+    mean = rs.normal(size=(B, n + m, d)) / 4
+    cross = np.zeros((B, n, ld))
+    cross[:, :, :m] = rs.normal(0, .05, (B, n, m))
+    diag = rs.rand(B, n + m) + .5
+    om = np.array([(lambda x: x @ x.T / d + .1 * np.eye(d))(rs.normal(size=(d, d))) for _ in range(B)])
+    var = ctx.empty((B, n, ld), np.float32)
+    dsum, bv, bi = ctx.empty(B), ctx.empty(B, np.float32), ctx.empty(B, np.int64)
+    ctx.mn_score_grid(np.float32, B, n, m, d, ld, *(ctx.array(x, np.float32) for x in (mean, cross, diag, om)),
+                      var=var, dsum=dsum, want=1, best_val=bv, best_idx=bi)
+    v = ctx.download_grid(var, m)
+    for b in range(B):
+        _, ov = orc.mn_pred_means_vars_compact(40, m, np.vstack([mean[b, :40], mean[b, n:]]),
+                                               cross[b, :40, :m], np.concatenate([diag[b, :40], diag[b, n:]]),
+                                               om[b])
+        assert np.all(np.abs(v[b, :40] - ov) <= 2e-5 * np.abs(ov).max())
+        k = int(bi.to_host()[b])
+        assert v[b].ravel()[k // m * m + k % m] == v[b].max()
+        assert abs(dsum.to_host()[b] - v[b].astype(np.float64).sum()) <= 1e-6 * dsum.to_host()[b]
+    # K3 at d = 64
+    rt = ctx.ratings(ratings, n, m)
+    a = rs.normal(size=(d, d))
+    alpha, mu, z = a @ a.T / d + np.eye(d), rs.normal(size=d), rs.normal(size=(n, d))
+    out = ctx.empty((n, d))
+    ctx.gibbs_half_sweep(rt, 0, ctx.array(V), d, ctx.array(alpha), ctx.array(mu), 2.0, 0., ctx.array(z), out)
+    ptr, idx, rat = orc.csr_by_row(ratings, 0, n)
+    ref = orc.gibbs_half_sweep(ptr[:51], idx, rat, V, alpha, mu, 2.0, 0., z[:50])
+    np.testing.assert_allclose(out.to_host()[:50], ref, rtol=1e-8, atol=1e-10)
