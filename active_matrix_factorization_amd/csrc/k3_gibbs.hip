@@ -7,17 +7,17 @@
 //     cov  = A^-1,  mean = cov (beta F'(r - sub) + alpha mu)
 //     out  = chol(cov) z + mean                   (LOWER Cholesky of the covariance, as the
 //                                                  reference draws it: bayes_pmf.py:214-216)
-// One wave (64-thread block) owns a row.  The gathered rows are staged through LDS in
-// chunks of CH rows; each lane keeps NSLOT (k,l) pairs of the symmetric F'F in registers
-// (d(d+1)/2 pairs over 64 lanes) and sums them over the ratings in storage order.  The
-// d x d factorisations run in LDS, one lane per matrix row.  d^3 work per row is tiny: the
+// One wave (64-thread block) owns a row.  The normal-equation build F'F runs on the matrix
+// cores: v_mfma_f64_16x16x4_f64 tiles with the latent dimension zero-padded to 16 (this is the
+// one place of the path where MFMA fits: a rank-4 update of a d x d accumulator per
+// instruction), fed straight from coalesced gathers of the other side's rows.  The d x d
+// factorisations then run in LDS, one lane per matrix row.  d^3 work per row is tiny: the
 // sweep is bound by the gather (nnz*(8+8d) bytes) and by launch latency at MovieLens size.
 #include "common.h"
 
 
 namespace {
 
-constexpr int CH = 32;  // gathered rows staged per chunk
 
 // in-place lower Cholesky of the symmetric matrix held in LDS (leading dim lda); lane = row.
 // Returns false (wave-uniform) if a pivot is not positive.
@@ -41,7 +41,14 @@ __device__ __forceinline__ bool chol_lds(double *A, int d, int lda, int lane)
     return ok;
 }
 
-template <int NSLOT>
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+// TL = ceil(d / 16): F'F is built as TL x TL tiles of v_mfma_f64_16x16x4_f64 (upper triangle
+// only).  For the tile (ti, tj) and 4 consecutive ratings r0..r0+3, lane l supplies
+// F[r0 + (l >> 4)][16 t + (l & 15)] - the same element pattern for the A and the B operand - so
+// one coalesced load per lane per tile column feeds the matrix core, and the latent dimension
+// is simply zero-padded to the 16-wide tile (d = 15 -> one tile, d = 64 -> 10 tiles).
+template <int TL>
 __global__ __launch_bounds__(64) void k_gibbs_rows(int row_lo, int rows, int d, const int64_t *__restrict__ ptr,
                                                    const int32_t *__restrict__ idx,
                                                    const double *__restrict__ val,
@@ -56,63 +63,66 @@ __global__ __launch_bounds__(64) void k_gibbs_rows(int row_lo, int rows, int d, 
     const int row = row_lo + blockIdx.x;
     if (row >= rows) return;
     const int lda = d + 1;
-    double *Fs = smem;                    // CH x d
-    double *rs = Fs + CH * d;             // CH (rating - sub)
-    double *A = rs + CH;                  // d x lda : A, then its Cholesky factor, then chol(cov)
+    double *A = smem;                     // d x lda : A, then its Cholesky factor, then chol(cov)
     double *X = A + d * lda;              // d x lda : L^-1, then cov
     double *rhs = X + d * lda;            // d
     double *mean = rhs + d;               // d
 
-    // pair slots: p = lane + 64*s -> (k, l), k <= l
-    int pk[NSLOT], pl[NSLOT];
-    double acc[NSLOT];
-    const int npairs = d * (d + 1) / 2;
+    const int q = lane >> 4, c = lane & 15;   // rating slot within a group of 4, column in a tile
+    f64x4 acc[TL][TL];
 #pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        int p = lane + 64 * s;
-        int k = 0, l = 0;
-        if (p < npairs) {
-            // row-wise enumeration of the upper triangle
-            int rem = p;
-            k = 0;
-            while (rem >= d - k) { rem -= d - k; k++; }
-            l = k + rem;
-        }
-        pk[s] = k; pl[s] = l; acc[s] = 0.;
-    }
-    double racc = 0.;  // lane k < d: sum_r F[r][k] * (rating_r - sub)
+    for (int ti = 0; ti < TL; ti++)
+#pragma unroll
+        for (int tj = 0; tj < TL; tj++) acc[ti][tj] = (f64x4){0., 0., 0., 0.};
+    double racc[TL];                       // sum_r F[r][16 t + c] * (rating_r - sub), this lane's slot
+#pragma unroll
+    for (int t = 0; t < TL; t++) racc[t] = 0.;
 
     const int64_t beg = ptr[row], end = ptr[row + 1];
-    for (int64_t c0 = beg; c0 < end; c0 += CH) {
-        const int cnt = (int)min((int64_t)CH, end - c0);
-        __syncthreads();
-        for (int e = lane; e < cnt * d; e += 64) {
-            const int r = e / d, k = e - r * d;
-            Fs[r * d + k] = oth[(size_t)idx[c0 + r] * d + k];
-        }
-        if (lane < cnt) rs[lane] = val[c0 + lane] - mean_sub;
-        __syncthreads();
-        for (int r = 0; r < cnt; r++) {
+    for (int64_t r0 = beg; r0 < end; r0 += 4) {
+        const int64_t r = r0 + q;
+        const bool ok = r < end;
+        const int32_t src = ok ? idx[r] : 0;
+        const double rv = ok ? val[r] - mean_sub : 0.;
+        double f[TL];
 #pragma unroll
-            for (int s = 0; s < NSLOT; s++) acc[s] += Fs[r * d + pk[s]] * Fs[r * d + pl[s]];
-            if (lane < d) racc += Fs[r * d + lane] * rs[r];
+        for (int t = 0; t < TL; t++) {
+            const int col = 16 * t + c;
+            f[t] = (ok && col < d) ? oth[(size_t)src * d + col] : 0.;
+            racc[t] += f[t] * rv;
         }
-    }
-    __syncthreads();
-    // A = alpha + beta F'F (symmetric fill), rhs = beta F'r + alpha mu
 #pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        const int p = lane + 64 * s;
-        if (p < npairs) {
-            const int k = pk[s], l = pl[s];
-            A[k * lda + l] = alpha[k * d + l] + beta * acc[s];
-            if (k != l) A[l * lda + k] = alpha[l * d + k] + beta * acc[s];
-        }
+        for (int ti = 0; ti < TL; ti++)
+#pragma unroll
+            for (int tj = ti; tj < TL; tj++)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ti], f[tj], acc[ti][tj], 0, 0, 0);
     }
-    if (lane < d) {
-        double am = 0.;
-        for (int l = 0; l < d; l++) am += alpha[lane * d + l] * mu[l];
-        rhs[lane] = beta * racc + am;
+    // A = alpha + beta F'F : C/D layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 reg
+#pragma unroll
+    for (int ti = 0; ti < TL; ti++)
+#pragma unroll
+        for (int tj = ti; tj < TL; tj++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int i = 16 * ti + q + 4 * reg, j = 16 * tj + c;
+                if (i < d && j < d) {
+                    const double v = beta * acc[ti][tj][reg];
+                    A[i * lda + j] = alpha[i * d + j] + v;
+                    if (ti != tj) A[j * lda + i] = alpha[j * d + i] + v;
+                }
+            }
+    // rhs = beta F'r + alpha mu : combine the 4 rating slots
+#pragma unroll
+    for (int t = 0; t < TL; t++) {
+        double v = racc[t];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        const int k = 16 * t + c;
+        if (q == 0 && k < d) {
+            double am = 0.;
+            for (int l = 0; l < d; l++) am += alpha[k * d + l] * mu[l];
+            rhs[k] = beta * v + am;
+        }
     }
     __syncthreads();
 
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(64) void k_gibbs_rows(int row_lo, int rows, int d, 
 
 size_t gibbs_smem(int d)
 {
-    return sizeof(double) * ((size_t)CH * d + CH + 2 * (size_t)d * (d + 1) + 2 * d);
+    return sizeof(double) * (2 * (size_t)d * (d + 1) + 2 * d);
 }
 
 } // namespace
@@ -211,23 +221,19 @@ static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo
     APMF_TRY(apmf_ws(ctx, 2, 64, &w));
     int *d_status = (int *)w;
     APMF_CHECK_HIP(hipMemsetAsync(d_status, 0, sizeof(int), ctx->stream));
-    const int npairs = d * (d + 1) / 2;
-    const int nslot = (npairs + 63) / 64;
+    const int tl = (d + 15) / 16;
     const size_t smem = gibbs_smem(d);
-#define LAUNCH_GIBBS(NS)                                                                          \
-    hipLaunchKernelGGL((k_gibbs_rows<NS>), dim3(row_hi - row_lo), dim3(64), smem, ctx->stream,    \
-                       row_lo, row_hi, d,                                                         \
-                       r->ptr[side], r->idx[side], r->val[side], d_oth, d_alpha, d_mu, beta,      \
-                       mean_sub, d_z, d_out, d_status)
+#define LAUNCH_GIBBS(TLV)                                                                         \
+    hipLaunchKernelGGL((k_gibbs_rows<TLV>), dim3(row_hi - row_lo), dim3(64), smem, ctx->stream,   \
+                       row_lo, row_hi, d, r->ptr[side], r->idx[side], r->val[side], d_oth, d_alpha, \
+                       d_mu, beta, mean_sub, d_z, d_out, d_status)
     if (smem > 64 * 1024)
-        APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_gibbs_rows<33>,
+        APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_gibbs_rows<4>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    if (nslot <= 1) LAUNCH_GIBBS(1);
-    else if (nslot <= 2) LAUNCH_GIBBS(2);
-    else if (nslot <= 4) LAUNCH_GIBBS(4);
-    else if (nslot <= 9) LAUNCH_GIBBS(9);
-    else if (nslot <= 17) LAUNCH_GIBBS(17);
-    else LAUNCH_GIBBS(33);
+    if (tl == 1) LAUNCH_GIBBS(1);
+    else if (tl == 2) LAUNCH_GIBBS(2);
+    else if (tl == 3) LAUNCH_GIBBS(3);
+    else LAUNCH_GIBBS(4);
 #undef LAUNCH_GIBBS
     APMF_CHECK_LAUNCH();
     int status = 0;
