@@ -63,6 +63,7 @@ struct GridDims {
     int nblk_x, nblk_y;
     int want;          // +1 max, -1 min, 0 none
     int want_sum;
+    int csteps;        // MFMA sweep: tiles of 32 rows per block
 };
 
 // Operands are separate `const __restrict__` kernel parameters (not members of a struct)
@@ -89,7 +90,7 @@ struct GridArgs {
 // wave-uniform operands (scalar loads); padding columns of colpack are zeroed.
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int D, int ld, int rs,
-                                                 const T *__restrict__ mean,
+                                                 int tiled, const T *__restrict__ mean,
                                                  const T *__restrict__ diag,
                                                  const T *__restrict__ omega,
                                                  T *__restrict__ rowpack, T *__restrict__ colpack,
@@ -133,7 +134,12 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
     const T *a = sA + threadIdx.x * st;
     const T sd = diag[(size_t)b * (n + m) + t];
     T quad = 0;
-    T *rp = rowpack + ((size_t)b * n + t) * rs;
+    // user pack: row-major [Oa | a | a'Oa | s_ii] with stride rs, or (tiled, for the matrix-core
+    // sweep) tile-major transposed: tile t/32 holds (2D+2) x 32 floats [Oa | a'Oa | s_ii | a]
+    T *rp = tiled ? rowpack + (((size_t)b * ((n + 31) >> 5) + (t >> 5)) * (2 * D + 2)) * 32 + (t & 31)
+                  : rowpack + ((size_t)b * n + t) * rs;
+    const size_t rstr = tiled ? 32 : 1;
+    const int pos_a = tiled ? D + 2 : D, pos_q = tiled ? D : 2 * D;
     if (DT > 0) {
         // the row in registers, loops fully unrolled; the reference only reads Omega[k, l]
         // with k <= l, so the upper triangle is mirrored
@@ -150,12 +156,12 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
                 quad += av[k] * w;
             }
             if (k < D) {
-                if (is_user) { rp[k] = w; rp[D + k] = av[k]; }
+                if (is_user) { rp[k * rstr] = w; rp[(pos_a + k) * rstr] = av[k]; }
                 else cp[(size_t)k * ld + j] = av[k];
             }
         }
         for (int k = DT; k < D; k++) {
-            if (is_user) { rp[k] = 0; rp[D + k] = 0; }
+            if (is_user) { rp[k * rstr] = 0; rp[(pos_a + k) * rstr] = 0; }
             else cp[(size_t)k * ld + j] = 0;
         }
     } else {
@@ -168,16 +174,16 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
                 quad += ak * w;
             }
             if (is_user) {
-                rp[k] = w;
-                rp[D + k] = ak;
+                rp[k * rstr] = w;
+                rp[(pos_a + k) * rstr] = ak;
             } else {
                 cp[(size_t)k * ld + j] = ak;
             }
         }
     }
     if (is_user) {
-        rp[2 * D] = quad;
-        rp[2 * D + 1] = sd;
+        rp[pos_q * rstr] = quad;
+        rp[(pos_q + 1) * rstr] = sd;
     } else {
         cp[(size_t)D * ld + j] = quad;
         cp[(size_t)(D + 1) * ld + j] = sd;
@@ -185,19 +191,31 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
 }
 
 // (n, ld) uint8 mask -> (ceil(n/16), ld) uint16 words, bit r = row 16 g + r: a lane fetches
-// the candidate bits of its columns for all 16 rows of its wave with ONE small load
+// the candidate bits of its columns for all 16 rows of its wave with ONE small load.
+// A thread packs 4 adjacent columns (one 4-byte load per row, one 8-byte store).
 __global__ __launch_bounds__(256) void k_mask_pack(int n, int ld, const uint8_t *__restrict__ mask,
                                                    uint16_t *__restrict__ maskT)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
     const int g = blockIdx.y;
     if (j >= ld) return;
-    unsigned w = 0;
+    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    const int rows = min(16, n - g * 16);
+    const uint8_t *src = mask + (size_t)g * 16 * ld + j;
+#pragma unroll
     for (int r = 0; r < 16; r++) {
-        const int i = g * 16 + r;
-        if (i < n && mask[(size_t)i * ld + j]) w |= 1u << r;
+        if (r < rows) {
+            const unsigned v = *reinterpret_cast<const unsigned *>(src + (size_t)r * ld);
+            w0 |= ((v & 0xFFu) ? 1u : 0u) << r;
+            w1 |= ((v & 0xFF00u) ? 1u : 0u) << r;
+            w2 |= ((v & 0xFF0000u) ? 1u : 0u) << r;
+            w3 |= ((v & 0xFF000000u) ? 1u : 0u) << r;
+        }
     }
-    maskT[(size_t)g * ld + j] = (uint16_t)w;
+    uint2 out;
+    out.x = w0 | (w1 << 16);
+    out.y = w2 | (w3 << 16);
+    *reinterpret_cast<uint2 *>(maskT + (size_t)g * ld + j) = out;
 }
 
 // ---- the sweep ----------------------------------------------------------------------
@@ -272,12 +290,21 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
     // XCD-aware decode of the 1-D grid: workgroups are dealt round-robin over the 8 XCDs, so
     // all tiles of one posterior state go to the same XCD and its packs stay in ONE L2.
     // (Placement is a speed matter only: any mapping covers every (state, tile) exactly once.)
+    // States beyond the last full group of 8 (all of them when B < 8) have their tiles dealt
+    // over all XCDs instead, so that a single-state sweep still fills the chip.
     const int per_state = a.nblk_x * a.nblk_y;
     const int L = blockIdx.x;
-    const int xcd = L & 7, q = L >> 3;
-    const int b = (q / per_state) * 8 + xcd;
-    if (b >= a.B) return;   // block-uniform
-    const int tile = q % per_state;
+    const int full = (a.B >> 3) * per_state * 8;
+    int b, tile;
+    if (L < full) {
+        const int xcd = L & 7, q = L >> 3;
+        b = (q / per_state) * 8 + xcd;
+        tile = q % per_state;
+    } else {
+        const int q = L - full;
+        b = (a.B & ~7) + q / per_state;
+        tile = q % per_state;
+    }
     const int bx = tile % a.nblk_x, by = tile / a.nblk_x;
     const int j0 = (bx * 64 + lane) * VEC;
     const bool colok = j0 < a.ld;
@@ -461,6 +488,263 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
     }
 }
 
+// ---- the sweep for d > 16, float32: the rank-d term on the matrix cores ----------------
+// At d = 64 a candidate costs 2d = 128 flops against 8 bytes: the sweep is no longer a pure
+// stream, the bilinear term G = (A Omega) B' IS a GEMM (n x d by d x m), and the f32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact f32, an fmaf chain) does it at the full f32 rate while the
+// VALU is left to the epilogue.
+// A block is 4 waves x 32 columns = 128 adjacent item columns (512 contiguous bytes of every
+// grid row it touches).  Each wave keeps ITS 32 items' b_j in registers as the MFMA B operand
+// for the whole walk (plus q_j, s_jj), and the block walks `csteps` tiles of 32 user rows; the
+// user-side operands of a tile (Omega a, a'Oa, s_ii, and a for the mean output) are staged
+// through LDS, double-buffered, shared by the 4 waves.  They come from `rowT`, the tile-major
+// transposed pack written by k_mn_prep (tile t: (2D+2) x 32 floats, row k of it contiguous),
+// so staging is one contiguous copy and every LDS read of the MFMA loop is conflict-free.
+// k is permuted so that lane half h = lane >> 5 owns k in [h D/2, (h+1) D/2).
+// Accumulator layout (32x32): col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5):
+// a lane owns ONE item column for the whole walk and visits its rows in ascending order, so
+// the arg-extremum needs only a strict compare to keep the lowest flat index on ties.
+constexpr int MF_BCOLS = 128;   // columns per block (4 waves x 32)
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+#ifndef APMF_MF_WAVES
+#define APMF_MF_WAVES 3   // waves per SIMD the register budget is held to (<= 168 VGPRs)
+#endif
+template <int D, bool RED, bool MEAN>
+__global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridDims a, const float *__restrict__ p_cross,
+                                                      const float *__restrict__ p_rowT,
+                                                      const float *__restrict__ p_colpack,
+                                                      const float *__restrict__ p_state,
+                                                      const uint16_t *__restrict__ p_maskT,
+                                                      float *__restrict__ p_var,
+                                                      float *__restrict__ p_pmean,
+                                                      double *__restrict__ part_sum,
+                                                      float *__restrict__ part_val,
+                                                      long long *__restrict__ part_idx)
+{
+    static_assert(D % 8 == 0 && D <= 64, "D/2 must be a multiple of 4");
+    constexpr int KH = D / 2;
+    constexpr int AROWS = MEAN ? 2 * D + 2 : D + 2;   // staged rows of a user tile
+    constexpr int TSTRIDE = (2 * D + 2) * 32;         // floats per user tile in rowT
+    constexpr int NF4 = AROWS * 8;                    // float4 per staged tile
+    constexpr int NLD = (NF4 + 255) / 256;            // float4 per thread per tile
+    static_assert(NLD <= 5, "5 staging fragments");
+    __shared__ __attribute__((aligned(16))) float sA[2][NLD * 1024];
+
+    const int lane = threadIdx.x & 63, wave = wave_id_uniform();
+    const int h = lane >> 5, c = lane & 31;
+    const int per_state = a.nblk_x * a.nblk_y;
+    const int L = blockIdx.x;
+    const int full_grp = (a.B >> 3) * per_state * 8;
+    int b, tile;
+    if (L < full_grp) {
+        const int xcd = L & 7, q = L >> 3;
+        b = (q / per_state) * 8 + xcd;
+        tile = q % per_state;
+    } else {
+        const int q = L - full_grp;
+        b = (a.B & ~7) + q / per_state;
+        tile = q % per_state;
+    }
+    const int bx = tile % a.nblk_x, by = tile / a.nblk_x;
+    const int ld = a.ld, n = a.n, m = a.m;
+    const int ntile = (n + 31) >> 5;
+    const int T0 = by * a.csteps;
+    const int nT = min(a.csteps, ntile - T0);
+    const int col0 = bx * MF_BCOLS + wave * 32;       // wave-uniform; ld is a multiple of 64
+    const bool cok = col0 < ld;                       // a whole wave is in or out
+    const int col = col0 + c;
+    const float t2 = p_state[2 * b], trO = p_state[2 * b + 1];
+    const bool do_var = p_var != nullptr;
+
+    // B operand: this lane's item, k in [h KH, (h+1) KH); then the per-item scalars
+    float bw[KH];
+    float qq = 0.f, sjj = 0.f;
+    {
+        const float *cp = p_colpack + (size_t)b * (D + 2) * ld + (cok ? col : 0);
+#pragma unroll
+        for (int s = 0; s < KH; s++) bw[s] = cok ? cp[(size_t)(h * KH + s) * ld] : 0.f;
+        if (cok) { qq = cp[(size_t)D * ld]; sjj = cp[(size_t)(D + 1) * ld]; }
+    }
+    const float cA = fmaf(t2, sjj, qq);
+    const float ht2 = .5f * t2;
+
+    // staging of a user tile: NLD float4 per thread (plain locals: never an indexed stack
+    // object); fragments past the tile repeat its last float4 and land in unread LDS padding
+    const float *rowT_b = p_rowT + (size_t)b * ntile * TSTRIDE;
+    float4 st0, st1, st2, st3, st4;
+    st0 = st1 = st2 = st3 = st4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define MF_FETCH1(k, fsrc) \
+    if (NLD > k) st##k = *reinterpret_cast<const float4 *>((fsrc) + 4 * min(k * 256 + (int)threadIdx.x, NF4 - 1));
+#define MF_FETCH(T)                                                                             \
+    {                                                                                            \
+        const float *fsrc = rowT_b + (size_t)(T0 + (T)) * TSTRIDE;                               \
+        MF_FETCH1(0, fsrc) MF_FETCH1(1, fsrc) MF_FETCH1(2, fsrc) MF_FETCH1(3, fsrc) MF_FETCH1(4, fsrc) \
+    }
+#define MF_COMMIT1(k, buf) \
+    if (NLD > k) *reinterpret_cast<float4 *>(&sA[buf][(k * 256 + threadIdx.x) * 4]) = st##k;
+#define MF_COMMIT(buf)                                                                          \
+    { MF_COMMIT1(0, buf) MF_COMMIT1(1, buf) MF_COMMIT1(2, buf) MF_COMMIT1(3, buf) MF_COMMIT1(4, buf) }
+
+    // The streamed operand: register i of a tile is row 32 T + RL(i) + 4h.  The row part of the
+    // address is wave-uniform (scalar base), the lane part one 32-bit offset.  Only the last
+    // tile of a state needs row guards.
+#define MF_RL(i) (((i) & 3) + 8 * ((i) >> 2))
+    const size_t state_base = (size_t)b * n * ld + col0;      // wave-uniform
+    const unsigned lane_off = (unsigned)(4 * h * ld + c);
+#define MF_LOAD_TILE(dst, dmb, T)                                                               \
+    {                                                                                            \
+        const int lr0 = (T0 + (T)) * 32;                                                         \
+        const int lrem = min(32, n - lr0);                                                       \
+        const float *lsrc = p_cross + state_base + (size_t)lr0 * ld;                             \
+        if (!cok) {                                                                              \
+            _Pragma("unroll") for (int i = 0; i < 16; i++) dst[i] = 0.f;                         \
+        } else if (lrem == 32) {                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 16; i++)                                       \
+                dst[i] = __builtin_nontemporal_load(lsrc + (size_t)MF_RL(i) * ld + lane_off);    \
+        } else {                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 16; i++)                                       \
+                dst[i] = (MF_RL(i) + 4 * h < lrem)                                               \
+                             ? __builtin_nontemporal_load(lsrc + (size_t)MF_RL(i) * ld + lane_off) \
+                             : 0.f;                                                              \
+        }                                                                                        \
+        if (RED) {                                                                               \
+            /* candidate bits, pre-shifted by 4h: bit RL(i) <-> accumulator register i */        \
+            unsigned w = 0xFFFFFFFFu;                                                            \
+            if (p_maskT && cok) {                                                                \
+                const size_t g0 = (size_t)(lr0 >> 4);                                            \
+                const unsigned lo = p_maskT[g0 * ld + col];                                      \
+                const unsigned hi = (lrem > 16) ? p_maskT[(g0 + 1) * ld + col] : 0u;             \
+                w = lo | (hi << 16);                                                             \
+            }                                                                                    \
+            const unsigned rowbits = lrem >= 32 ? 0xFFFFFFFFu : ((1u << lrem) - 1u);             \
+            dmb = (cok && col < m) ? ((w & rowbits) >> (4 * h)) : 0u;                            \
+        }                                                                                        \
+    }
+
+    double sum = 0.;
+    const float sgn = a.want < 0 ? -1.f : 1.f;          // arg-extremum on key = sgn * value
+    float bestkey = -__builtin_inff();
+    int bestcode = -1;
+
+    // one tile: prefetch the next tile's operands, run the matrix core on this one, finish it
+#define MF_TILE(T, cur, curmb, nxt, nxtmb, buf)                                                 \
+    {                                                                                            \
+        MF_FETCH(min((T) + 1, nT - 1));                                                          \
+        MF_LOAD_TILE(nxt, nxtmb, min((T) + 1, nT - 1));                                          \
+        f32x16 acc, accm;                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 16; i++) { acc[i] = 0.f; accm[i] = 0.f; }          \
+        const float *at = &sA[buf][(h * KH) * 32 + c];                                           \
+        _Pragma("unroll") for (int s = 0; s < KH; s++) {                                         \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s * 32], bw[s], acc, 0, 0, 0);         \
+            if (MEAN) accm = __builtin_amdgcn_mfma_f32_32x32x2f32(at[(D + 2 + s) * 32], bw[s], accm, 0, 0, 0); \
+        }                                                                                        \
+        const int r0 = (T0 + (T)) * 32;                                                          \
+        const int rem = min(32, n - r0);                                                         \
+        const float *prow = &sA[buf][D * 32 + 4 * h];                                            \
+        /* Var = s_ii (t2 s_jj + q_j) + p_i s_jj + 2 x (t2 x / 2 + G) */                          \
+        _Pragma("unroll") for (int i = 0; i < 16; i++) {                                         \
+            const float pi = prow[MF_RL(i)], sii = prow[32 + MF_RL(i)];                          \
+            const float x = cur[i];                                                              \
+            const float u = fmaf(ht2, x, acc[i]);                                                \
+            acc[i] = fmaf(sii, cA, fmaf(x + x, u, pi * sjj));                                    \
+            if (MEAN) accm[i] = fmaf(x, trO, accm[i]);                                           \
+        }                                                                                        \
+        float *vdst = p_var + state_base + (size_t)r0 * ld;                                      \
+        float *mdst = p_pmean + state_base + (size_t)r0 * ld;                                    \
+        if (cok && rem == 32) {                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 16; i++) {                                     \
+                if (do_var) __builtin_nontemporal_store(acc[i], vdst + (size_t)MF_RL(i) * ld + lane_off); \
+                if (MEAN) __builtin_nontemporal_store(accm[i], mdst + (size_t)MF_RL(i) * ld + lane_off); \
+            }                                                                                    \
+        } else if (cok) {                                                                        \
+            _Pragma("unroll") for (int i = 0; i < 16; i++) {                                     \
+                if (MF_RL(i) + 4 * h < rem) {                                                    \
+                    if (do_var) __builtin_nontemporal_store(acc[i], vdst + (size_t)MF_RL(i) * ld + lane_off); \
+                    if (MEAN) __builtin_nontemporal_store(accm[i], mdst + (size_t)MF_RL(i) * ld + lane_off); \
+                }                                                                                \
+            }                                                                                    \
+        }                                                                                        \
+        if (RED) {                                                                               \
+            float tsum = 0.f;                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 16; i++) {                                     \
+                const int sel = __builtin_amdgcn_sbfe((int)curmb, MF_RL(i), 1);   /* 0 or -1 */  \
+                if (a.want_sum) tsum += __int_as_float(__float_as_int(acc[i]) & sel);            \
+                if (a.want) {                                                                    \
+                    const float key = sgn * acc[i];                                              \
+                    const bool better = sel && key > bestkey;                                    \
+                    bestkey = better ? key : bestkey;                                            \
+                    bestcode = better ? (T) * 16 + i : bestcode;                                 \
+                }                                                                                \
+            }                                                                                    \
+            sum += (double)tsum;                                                                 \
+        }                                                                                        \
+        MF_COMMIT((buf) ^ 1);                                                                    \
+        __syncthreads();                                                                         \
+    }
+
+    float svA[16], svB[16];
+    unsigned mbA = 0u, mbB = 0u;
+    MF_FETCH(0);
+    MF_COMMIT(0);
+    MF_LOAD_TILE(svA, mbA, 0);
+    __syncthreads();
+#pragma unroll 1
+    for (int T = 0; T < nT; T += 2) {
+        MF_TILE(T, svA, mbA, svB, mbB, 0);
+        if (T + 1 < nT) MF_TILE(T + 1, svB, mbB, svA, mbA, 1);
+    }
+    float bestv = sgn * bestkey;
+    long long besti = -1;
+    if (bestcode >= 0)
+        besti = (long long)((T0 + (bestcode >> 4)) * 32 + MF_RL(bestcode & 15) + 4 * h) * m + col;
+#undef MF_TILE
+#undef MF_FETCH
+#undef MF_FETCH1
+#undef MF_COMMIT
+#undef MF_COMMIT1
+#undef MF_LOAD_TILE
+#undef MF_RL
+
+    if (RED) {
+        __shared__ double sh_sum[WAVES];
+        __shared__ float sh_val[WAVES];
+        __shared__ long long sh_idx[WAVES];
+        sum = wave_sum(sum);
+        if (a.want) wave_argext(bestv, besti, a.want);
+        if (lane == 0) { sh_sum[wave] = sum; sh_val[wave] = bestv; sh_idx[wave] = besti; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double ts = sh_sum[0];
+            float bv = sh_val[0];
+            long long bi = sh_idx[0];
+            for (int w = 1; w < WAVES; w++) {
+                ts += sh_sum[w];
+                if (a.want) argext_merge(bv, bi, sh_val[w], sh_idx[w], a.want);
+            }
+            const size_t slot = (size_t)b * per_state + tile;
+            part_sum[slot] = ts;
+            part_val[slot] = bv;
+            part_idx[slot] = bi;
+        }
+    }
+}
+
+template <int D>
+void launch_grid_mfma(const GridArgs<float> &a, hipStream_t st)
+{
+    const bool red = a.g.want != 0 || a.g.want_sum, mean = a.pmean != nullptr;
+    dim3 grid((unsigned)((long long)a.g.B * a.g.nblk_x * a.g.nblk_y));
+#define APMF_MF(R, M)                                                                              \
+    hipLaunchKernelGGL((k_mn_grid_mfma<D, R, M>), grid, dim3(256), 0, st, a.g, a.cross, a.rowpack,  \
+                       a.colpack, a.state, a.maskT, a.var, a.pmean, a.part_sum, a.part_val, a.part_idx)
+    if (red && mean) APMF_MF(true, true);
+    else if (red) APMF_MF(true, false);
+    else if (mean) APMF_MF(false, true);
+    else APMF_MF(false, false);
+#undef APMF_MF
+}
+
 // one block per state: fixed-order combine of the per-block partials
 template <typename T>
 __global__ __launch_bounds__(256) void k_grid_finish(int nblk, int want, const double *__restrict__ part_sum,
@@ -518,8 +802,8 @@ template <typename T, int D, int VEC, bool RED, bool MEAN>
 void launch_grid_v(const GridArgs<T> &a, hipStream_t st)
 {
     const int per_state = a.g.nblk_x * a.g.nblk_y;
-    const long long groups = (a.g.B + 7) / 8;   // states are dealt to the 8 XCDs in groups of 8
-    dim3 grid((unsigned)(groups * per_state * 8));
+    // full groups of 8 states are dealt one state per XCD; the remaining states tile by tile
+    dim3 grid((unsigned)((long long)a.g.B * per_state));
     hipLaunchKernelGGL((k_mn_grid<T, D, VEC, RED, MEAN>), grid, dim3(256), 0, st, a.g, a.cross, a.rowpack,
                        a.colpack, a.state, a.maskT, a.var, a.pmean, a.part_sum, a.part_val,
                        a.part_idx);
@@ -554,11 +838,11 @@ int dispatch_grid<float>(const GridArgs<float> &a, int D, hipStream_t st)
     case 8: launch_grid<float, 8, 4>(a, st); break;
     case 10: launch_grid<float, 10, 4>(a, st); break;
     case 12: launch_grid<float, 12, 4>(a, st); break;
-    case 16: launch_grid<float, 16, 4>(a, st); break;
-    case 24: launch_grid<float, 24, 2>(a, st); break;
-    case 32: launch_grid<float, 32, 2>(a, st); break;
-    case 48: launch_grid<float, 48, 1>(a, st); break;
-    case 64: launch_grid<float, 64, 1>(a, st); break;
+    case 16: if (a.g.csteps) launch_grid_mfma<16>(a, st); else launch_grid<float, 16, 4>(a, st); break;
+    case 24: if (a.g.csteps) launch_grid_mfma<24>(a, st); else launch_grid<float, 24, 2>(a, st); break;
+    case 32: if (a.g.csteps) launch_grid_mfma<32>(a, st); else launch_grid<float, 32, 2>(a, st); break;
+    case 48: if (a.g.csteps) launch_grid_mfma<48>(a, st); else launch_grid<float, 48, 1>(a, st); break;
+    case 64: if (a.g.csteps) launch_grid_mfma<64>(a, st); else launch_grid<float, 64, 1>(a, st); break;
     default: return APMF_EINVAL;
     }
     return APMF_OK;
@@ -601,20 +885,42 @@ int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_
     APMF_REQUIRE(((uintptr_t)d_cross % 16) == 0 && (!d_var || ((uintptr_t)d_var % 16) == 0) &&
                      (!d_pmean || ((uintptr_t)d_pmean % 16) == 0),
                  "grids must be 16-byte aligned");
+    APMF_REQUIRE(!d_mask || ((uintptr_t)d_mask % 4) == 0, "d_mask must be 4-byte aligned");
     if (!d_var && !d_pmean && !d_sum && want == 0) return APMF_OK;
 
     const Plan<T> pl = plan_for<T>(d);
-    const int D = pl.D;
-    const int rs = round_up(2 * D + 2, 4);
+    int D = pl.D;
+    int rs = round_up(2 * D + 2, 4);
     GridArgs<T> a;
     memset(&a, 0, sizeof(a));
     a.g.B = B; a.g.n = n; a.g.m = m; a.g.d = d; a.g.ld = ld; a.g.rs = rs;
     a.g.nblk_x = (ld + 64 * pl.VEC - 1) / (64 * pl.VEC);
     a.g.nblk_y = (n + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    bool mfma = false;
+    // float32 kernel choice: the matrix-core sweep from the rank-16 bucket up, and for sweeps
+    // that write no grid (sum / arg-extremum only), where it is ahead at every rank; the
+    // streaming VALU kernel otherwise.  APMF_K2_KERNEL=mfma|valu overrides (tuning, tests).
+    bool use_mfma = sizeof(T) == 4 && (D >= 16 || (!d_var && !d_pmean));
+    if (const char *e = getenv("APMF_K2_KERNEL")) {
+        if (!strcmp(e, "mfma")) use_mfma = sizeof(T) == 4;
+        else if (!strcmp(e, "valu")) use_mfma = false;
+    }
+    if (use_mfma) {
+        if (D < 16) { D = 16; rs = round_up(2 * D + 2, 4); a.g.rs = rs; }
+        // matrix-core sweep: 128-column blocks walking csteps tiles of 32 rows; shorter walks
+        // when the grid would otherwise be too small to fill 256 CUs
+        mfma = true;
+        a.g.nblk_x = (ld + MF_BCOLS - 1) / MF_BCOLS;
+        const int ntile = (n + 31) / 32;
+        int cs = 16;
+        while (cs > 1 && (long long)B * a.g.nblk_x * ((ntile + cs - 1) / cs) < 2048) cs >>= 1;
+        a.g.csteps = cs;
+        a.g.nblk_y = (ntile + cs - 1) / cs;
+    }
     const size_t nblk = (size_t)a.g.nblk_x * a.g.nblk_y;
 
     // workspace 0: packs; workspace 1: partials
-    const size_t rp_el = (size_t)B * n * rs, cp_el = (size_t)B * (D + 2) * ld, st_el = (size_t)B * 2;
+    const size_t rp_el = mfma ? (size_t)B * ((n + 31) / 32) * (2 * D + 2) * 32 : (size_t)B * n * rs, cp_el = (size_t)B * (D + 2) * ld, st_el = (size_t)B * 2;
     void *w0;
     APMF_TRY(apmf_ws(ctx, 0, (rp_el + cp_el + st_el) * sizeof(T) + 64, &w0));
     T *rowpack = (T *)w0;
@@ -632,23 +938,23 @@ int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_
     const dim3 prep_grid((n + ld + prep_rows - 1) / prep_rows, B);
     if (d <= 4)
         hipLaunchKernelGGL((k_mn_prep<T, 4>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m, d,
-                           D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+                           D, ld, rs, (int)mfma, d_mean, d_diag, d_omega, rowpack, colpack, state);
     else if (d <= 10)
         hipLaunchKernelGGL((k_mn_prep<T, 10>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m,
-                           d, D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+                           d, D, ld, rs, (int)mfma, d_mean, d_diag, d_omega, rowpack, colpack, state);
     else if (d <= 16)
         hipLaunchKernelGGL((k_mn_prep<T, 16>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m,
-                           d, D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+                           d, D, ld, rs, (int)mfma, d_mean, d_diag, d_omega, rowpack, colpack, state);
     else
         hipLaunchKernelGGL((k_mn_prep<T, 0>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m, d,
-                           D, ld, rs, d_mean, d_diag, d_omega, rowpack, colpack, state);
+                           D, ld, rs, (int)mfma, d_mean, d_diag, d_omega, rowpack, colpack, state);
     APMF_CHECK_LAUNCH();
     const uint16_t *maskT = nullptr;
     if (d_mask && (want != 0 || d_sum)) {
         const int ngrp = (n + 15) / 16;
         void *w2;
         APMF_TRY(apmf_ws(ctx, 2, (size_t)ngrp * ld * sizeof(uint16_t) + 64, &w2));
-        hipLaunchKernelGGL(k_mask_pack, dim3((ld + 255) / 256, ngrp), dim3(256), 0, ctx->stream, n, ld,
+        hipLaunchKernelGGL(k_mask_pack, dim3((ld / 4 + 255) / 256, ngrp), dim3(256), 0, ctx->stream, n, ld,
                            d_mask, (uint16_t *)w2);
         APMF_CHECK_LAUNCH();
         maskT = (const uint16_t *)w2;

@@ -310,6 +310,59 @@ def test_mn_grid_batched_states(ctx):
             assert abs(opv[i, j] - opv.min()) <= 2 * tol * np.abs(opv).max()
 
 
+@pytest.mark.parametrize('kernel', ['valu', 'mfma'])
+@pytest.mark.parametrize('shape', [(5, 64, 3), (65, 300, 10), (130, 70, 16), (97, 257, 24), (33, 130, 64)])
+def test_mn_grid_f32_kernel_variants(ctx, monkeypatch, kernel, shape):
+    """Both float32 sweeps (streaming VALU kernel, matrix-core kernel) at every rank bucket:
+    values against the oracle, fused sum / arg-extremum against the kernel's OWN written grid
+    (first occurrence in flat order, exact), with and without the grid output, and a state full
+    of exact ties (identical users, zero cross-covariance)."""
+    monkeypatch.setenv('APMF_K2_KERNEL', kernel)
+    n, m, d = shape
+    rs = np.random.RandomState(n + 7 * m + d)
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld = grid_ld(m)
+    b = rs.normal(size=(d, d)) / np.sqrt(d)
+    Om = b @ b.T + 0.1 * np.eye(d)
+    mask = rs.rand(n, m) < 0.8
+    mask[-1, -1] = True
+    dmask = ctx.upload_grid(mask.astype(np.uint8), np.uint8, ld=ld)
+    for ties in (False, True):
+        mean = rs.normal(size=(n + m, d))
+        a = rs.normal(size=(n + m, n + m)) / np.sqrt(n + m)
+        R = a @ a.T + 0.1 * np.eye(n + m)
+        if ties:
+            mean[:n] = mean[0]
+            mean[n:] = mean[n]
+            R = np.eye(n + m) * 1.5
+        dm, dc, dd, do, _ = _mn_state(ctx, mean, R, Om, np.float32, n, m)
+        _, opv, oe2 = orc.mn_pred_means_vars(n, m, mean, R, Om, want_e2=True)
+        scale = np.maximum(np.abs(oe2), np.abs(opv))
+        for want in (1, -1):
+            var = ctx.empty((n, ld), np.float32)
+            dsum, bv, bi = ctx.empty(1), ctx.empty(1, np.float32), ctx.empty(1, np.int64)
+            ctx.mn_score_grid(np.float32, 1, n, m, d, ld, dm, dc, dd, do, mask=dmask, var=var, dsum=dsum,
+                              want=want, best_val=bv, best_idx=bi)
+            v = ctx.download_grid(var, m)
+            assert np.all(np.abs(v - opv) <= 1e-5 * scale)
+            cand = np.where(mask, v, -np.inf if want > 0 else np.inf)
+            flat = int(np.argmax(cand)) if want > 0 else int(np.argmin(cand))
+            assert int(bi.to_host()[0]) == flat
+            assert bv.to_host()[0] == cand.ravel()[flat]
+            tot = v[mask].astype(np.float64).sum()
+            assert abs(dsum.to_host()[0] - tot) <= 1e-6 * abs(tot)
+            # reductions only (no grid written): same selection, same total
+            dsum2, bv2, bi2 = ctx.empty(1), ctx.empty(1, np.float32), ctx.empty(1, np.int64)
+            ctx.mn_score_grid(np.float32, 1, n, m, d, ld, dm, dc, dd, do, mask=dmask, dsum=dsum2,
+                              want=want, best_val=bv2, best_idx=bi2)
+            if kernel == 'valu' or d >= 13:     # same kernel as above: bit-identical
+                assert int(bi2.to_host()[0]) == flat and bv2.to_host()[0] == bv.to_host()[0]
+            else:
+                i2, j2 = divmod(int(bi2.to_host()[0]), m)
+                assert mask[i2, j2] and abs(opv[i2, j2] - opv.ravel()[flat]) <= 2e-5 * scale.max()
+            assert abs(dsum2.to_host()[0] - tot) <= 1e-5 * abs(tot)
+
+
 def test_mn_pool_and_exact_selection(ctx):
     """f32 sweep -> near-extremum short list -> f64 re-score = the f64 argmax (exact index)."""
     g = load_golden('mn_24x17_d5_rand')

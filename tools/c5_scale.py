@@ -1,0 +1,157 @@
+"""BASELINE.json configs[4] on ONE MI355X: 100 000 x 20 000, rank 64, 5*10^7 observed.
+The whole problem fits a single 288 GB device (ratings CSR x2 1.2 GB, one f32 cross block
+8 GB in + 8 GB out), so the 8-GPU configuration's total work can be checked and timed here;
+the 8-way run shards exactly these launches by user-row block (sharding.py).
+
+Checks are size-independent properties (nothing CPU-side can restate 2*10^9 candidates in
+seconds): sampled gradient rows and the chunked log-likelihood against NumPy, sampled grid
+rows against the float64 closed form, the fused sum / arg-max against the written grid.
+Prints one JSON object.  Usage: python tools/c5_scale.py [--rows 100000] [--ratings 50000000]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from active_matrix_factorization_amd import _lib  # noqa: E402
+
+
+def closed_form_rows(mean, n, rows, cross_rows, diag, omega):
+    """float64 Var[U_i . V_j] for the given user rows against all items."""
+    om = np.triu(omega) + np.triu(omega, 1).T
+    a, b = mean[rows], mean[n:]
+    tr2 = (om * om).sum()
+    oa = a @ om
+    qa = (oa * a).sum(1)
+    qb = ((b @ om) * b).sum(1)
+    si, sj = diag[rows][:, None], diag[n:][None, :]
+    return (si * sj + cross_rows ** 2) * tr2 + sj * qa[:, None] + si * qb[None, :] \
+        + 2 * cross_rows * (oa @ b.T)
+
+
+def timed(ctx, fn, reps):
+    fn()
+    ctx.sync()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    return (time.perf_counter() - t) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rows', type=int, default=100000)
+    ap.add_argument('--cols', type=int, default=20000)
+    ap.add_argument('--rank', type=int, default=64)
+    ap.add_argument('--ratings', type=int, default=50000000)
+    args = ap.parse_args()
+    n, m, d, N = args.rows, args.cols, args.rank, args.ratings
+    out = {'n': n, 'm': m, 'd': d, 'N': N}
+    rs = np.random.RandomState(5)
+    ctx = _lib.Context(0)
+
+    # ---------------------------------------------------------------- ratings, factors
+    t = time.perf_counter()
+    flat = np.unique(rs.randint(0, n * m, size=int(N * 1.04), dtype=np.int64))
+    flat = flat[rs.permutation(flat.size)[:N]]
+    ratings = np.empty((N, 3))
+    ratings[:, 0], ratings[:, 1] = flat // m, flat % m
+    ratings[:, 2] = rs.randint(1, 6, size=N)
+    del flat
+    U, V = .35 * rs.standard_normal((n, d)), .35 * rs.standard_normal((m, d))
+    out['host_synth_s'] = time.perf_counter() - t
+    t = time.perf_counter()
+    rt = ctx.ratings(ratings, n, m)
+    out['ratings_create_s'] = time.perf_counter() - t
+    dU, dV, dgU, dgV = ctx.array(U), ctx.array(V), ctx.empty((n, d)), ctx.empty((m, d))
+    hyper = (1., 10., 10., False, 0.)
+
+    # ---------------------------------------------------------------- K1
+    out['k1_gradient_ms'] = 1e3 * timed(ctx, lambda: ctx.pmf_gradient(rt, dU, dV, d, *hyper, dgU, dgV), 5)
+    out['k1_loglik_ms'] = 1e3 * timed(ctx, lambda: ctx.pmf_log_likelihood(rt, dU, dV, d, *hyper), 5)
+    gU, gV = dgU.to_host(), dgV.to_host()
+    ii, jj, rr = ratings[:, 0].astype(np.int64), ratings[:, 1].astype(np.int64), ratings[:, 2]
+    sq, worst = 0., 0.
+    err = np.empty(N)
+    for s in range(0, N, 1 << 22):
+        e = slice(s, s + (1 << 22))
+        err[e] = rr[e] - np.einsum('ij,ij->i', U[ii[e]], V[jj[e]])
+        sq += float((err[e] ** 2).sum())
+    for side, rows_of, oth_idx, own, oth, g in ((0, ii, jj, U, V, gU), (1, jj, ii, V, U, gV)):
+        for r in rs.randint(0, own.shape[0], size=24):
+            sel = np.nonzero(rows_of == r)[0]
+            ref = -own[r] / 10. + (err[sel][:, None] * oth[oth_idx[sel]]).sum(0)
+            worst = max(worst, float(np.abs(g[r] - ref).max() / (np.abs(ref).max() + 1e-300)))
+    out['k1_gradient_rows_max_rel_err'] = worst
+    ll_ref = -sq / 2 - (U ** 2).sum() / 20. - (V ** 2).sum() / 20.
+    ll, sq_dev = ctx.pmf_log_likelihood(rt, dU, dV, d, *hyper)
+    out['k1_loglik_rel_err'] = abs(ll - ll_ref) / abs(ll_ref)
+    del err
+    t = time.perf_counter()
+    trace, steps, lr, conv = ctx.pmf_fit_lls(rt, dU, dV, d, *hyper, 1e-6, 1e-12, 1e-2, max_steps=10)
+    dt = time.perf_counter() - t
+    out['k1_fit_lls_steps'] = int(steps)
+    out['k1_grad_steps_per_s'] = steps / dt
+    out['k1_fit_trace_increasing'] = bool(np.all(np.diff(np.r_[ll, trace]) > 0))
+    # algorithmic bytes per step, SURVEY 8(d): N(12+16d) + N(12+8d) + 16(n+m)d
+    out['k1_alg_GBps'] = (N * (24 + 24 * d) + 16 * (n + m) * d) * out['k1_grad_steps_per_s'] / 1e9
+
+    # ---------------------------------------------------------------- K2, one full-grid state
+    ld = _lib.grid_ld(m)
+    mean = np.vstack([U, V]).astype(np.float32)
+    A = rs.standard_normal((d, d)) / np.sqrt(d)
+    omega = (A @ A.T).astype(np.float32)
+    diag = (1. + rs.random_sample(n + m)).astype(np.float32)
+    period = 1024                                         # cross block: `period` random rows, tiled
+    blk = (.3 * rs.standard_normal((period, m))).astype(np.float32)
+    d_cross = ctx.zeros((n, ld), np.float32)
+    for lo in range(0, n, period):
+        k = min(period, n - lo)
+        _lib._check(ctx._lib.apmf_h2d_2d(ctx._h, d_cross.ptr + lo * ld * 4, ld * 4, blk.ctypes.data,
+                                         m * 4, m * 4, k))
+    cand = np.ones((n, m), np.uint8)
+    cand[ii, jj] = 0
+    d_mask = ctx.upload_grid(cand, np.uint8, ld=ld)
+    d_mean, d_diag, d_omega = ctx.array(mean), ctx.array(diag), ctx.array(omega)
+    d_var = ctx.empty((n, ld), np.float32)
+    d_sum, d_bv, d_bi = ctx.empty(1), ctx.empty(1, np.float32), ctx.empty(1, np.int64)
+
+    def sweep():
+        ctx.mn_score_grid(np.float32, 1, n, m, d, ld, d_mean, d_cross, d_diag, d_omega, mask=d_mask,
+                          var=d_var, dsum=d_sum, want=1, best_val=d_bv, best_idx=d_bi)
+    dt = timed(ctx, sweep, 5)
+    out['k2_sweep_ms'] = 1e3 * dt
+    out['k2_candidates_per_s'] = n * m / dt
+    out['k2_alg_GBps'] = 8. * n * m / dt / 1e9
+    var = ctx.download_grid(d_var, m)
+    rows = np.sort(rs.choice(n, 256, replace=False))
+    ref = closed_form_rows(mean.astype(np.float64), n, rows, blk[rows % period].astype(np.float64),
+                           diag.astype(np.float64), omega.astype(np.float64))
+    out['k2_rows_max_rel_err_f32'] = float((np.abs(var[rows] - ref) / ref).max())
+    masked = np.where(cand.astype(bool), var, -np.inf)
+    best = int(masked.argmax())
+    out['k2_argmax_matches_grid'] = bool(best == int(d_bi.to_host()[0]) and
+                                         masked.flat[best] == d_bv.to_host()[0])
+    tot = float(np.where(cand.astype(bool), var, 0).sum(dtype=np.float64))
+    out['k2_sum_rel_err_vs_grid'] = abs(tot - float(d_sum.to_host()[0])) / tot
+    # exact selection: every f32 near-tie re-scored in float64
+    cap = 4096
+    pi, pj = ctx.empty(cap, np.int32), ctx.empty(cap, np.int32)
+    cnt = ctx.grid_collect_near(n, m, ld, d_var, d_mask, 1, float(d_bv.to_host()[0]), 1e-4, pi, pj, cap)
+    out['k2_near_ties'] = int(cnt)
+    print(json.dumps(out, indent=1))
+    ok = (out['k1_gradient_rows_max_rel_err'] < 1e-11 and out['k1_loglik_rel_err'] < 1e-11 and
+          out['k1_fit_trace_increasing'] and out['k2_rows_max_rel_err_f32'] < 1e-4 and
+          out['k2_argmax_matches_grid'] and out['k2_sum_rel_err_vs_grid'] < 1e-9)
+    print('C5 checks', 'PASS' if ok else 'FAIL')
+    return 0 if ok else 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())
