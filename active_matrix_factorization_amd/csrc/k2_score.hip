@@ -505,12 +505,22 @@ __global__ __launch_bounds__(256) void k_mn_grid(const GridDims a, const T *__re
 // a lane owns ONE item column for the whole walk and visits its rows in ascending order, so
 // the arg-extremum needs only a strict compare to keep the lowest flat index on ties.
 constexpr int MF_BCOLS = 128;   // columns per block (4 waves x 32)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory
+// (s_waitcnt vmcnt(0)): inside the tile loop that would drain the prefetched grid loads and the
+// streamed stores of every wave at every tile, i.e. serialise HBM latency with the matrix core.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 #ifndef APMF_MF_WAVES
 #define APMF_MF_WAVES 3   // waves per SIMD the register budget is held to (<= 168 VGPRs)
 #endif
-template <int D, bool RED, bool MEAN>
+template <int D, bool VAR, bool RED, bool MEAN>
 __global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridDims a, const float *__restrict__ p_cross,
                                                       const float *__restrict__ p_rowT,
                                                       const float *__restrict__ p_colpack,
@@ -555,7 +565,7 @@ __global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridD
     const bool cok = col0 < ld;                       // a whole wave is in or out
     const int col = col0 + c;
     const float t2 = p_state[2 * b], trO = p_state[2 * b + 1];
-    const bool do_var = p_var != nullptr;
+    static_assert(VAR || RED || MEAN, "nothing to compute");
 
     // B operand: this lane's item, k in [h KH, (h+1) KH); then the per-item scalars
     float bw[KH];
@@ -592,16 +602,19 @@ __global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridD
 #define MF_RL(i) (((i) & 3) + 8 * ((i) >> 2))
     const size_t state_base = (size_t)b * n * ld + col0;      // wave-uniform
     const unsigned lane_off = (unsigned)(4 * h * ld + c);
-#define MF_LOAD_TILE(dst, dmb, T)                                                               \
+    // FAST (compile-time): a full 32-row tile of an in-range wave - no guards and no branches,
+    // so every path issues the same memory operations and the wait-count bookkeeping of the
+    // compiler stays exact (a conditional load anywhere makes it wait for everything in flight).
+#define MF_LOAD_TILE(dst, dmb, T, FAST)                                                         \
     {                                                                                            \
         const int lr0 = (T0 + (T)) * 32;                                                         \
         const int lrem = min(32, n - lr0);                                                       \
         const float *lsrc = p_cross + state_base + (size_t)lr0 * ld;                             \
-        if (!cok) {                                                                              \
-            _Pragma("unroll") for (int i = 0; i < 16; i++) dst[i] = 0.f;                         \
-        } else if (lrem == 32) {                                                                 \
+        if (FAST) {                                                                              \
             _Pragma("unroll") for (int i = 0; i < 16; i++)                                       \
                 dst[i] = __builtin_nontemporal_load(lsrc + (size_t)MF_RL(i) * ld + lane_off);    \
+        } else if (!cok) {                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 16; i++) dst[i] = 0.f;                         \
         } else {                                                                                 \
             _Pragma("unroll") for (int i = 0; i < 16; i++)                                       \
                 dst[i] = (MF_RL(i) + 4 * h < lrem)                                               \
@@ -610,15 +623,20 @@ __global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridD
         }                                                                                        \
         if (RED) {                                                                               \
             /* candidate bits, pre-shifted by 4h: bit RL(i) <-> accumulator register i */        \
-            unsigned w = 0xFFFFFFFFu;                                                            \
-            if (p_maskT && cok) {                                                                \
-                const size_t g0 = (size_t)(lr0 >> 4);                                            \
-                const unsigned lo = p_maskT[g0 * ld + col];                                      \
-                const unsigned hi = (lrem > 16) ? p_maskT[(g0 + 1) * ld + col] : 0u;             \
-                w = lo | (hi << 16);                                                             \
+            const size_t g0 = (size_t)(lr0 >> 4);                                                \
+            if (FAST) {                                                                          \
+                const unsigned lo = p_maskT[g0 * ld + col], hi = p_maskT[(g0 + 1) * ld + col];   \
+                dmb = col < m ? ((lo | (hi << 16)) >> (4 * h)) : 0u;                             \
+            } else {                                                                             \
+                unsigned w = 0u;                                                                 \
+                if (cok && lrem > 0) {                                                           \
+                    const unsigned lo = p_maskT[g0 * ld + col];                                  \
+                    const unsigned hi = (lrem > 16) ? p_maskT[(g0 + 1) * ld + col] : 0u;         \
+                    w = lo | (hi << 16);                                                         \
+                }                                                                                \
+                const unsigned rowbits = lrem >= 32 ? 0xFFFFFFFFu : (lrem > 0 ? (1u << lrem) - 1u : 0u); \
+                dmb = (cok && col < m) ? ((w & rowbits) >> (4 * h)) : 0u;                        \
             }                                                                                    \
-            const unsigned rowbits = lrem >= 32 ? 0xFFFFFFFFu : ((1u << lrem) - 1u);             \
-            dmb = (cok && col < m) ? ((w & rowbits) >> (4 * h)) : 0u;                            \
         }                                                                                        \
     }
 
@@ -627,18 +645,37 @@ __global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridD
     float bestkey = -__builtin_inff();
     int bestcode = -1;
 
-    // one tile: prefetch the next tile's operands, run the matrix core on this one, finish it
-#define MF_TILE(T, cur, curmb, nxt, nxtmb, buf)                                                 \
+    // one tile: prefetch the next tile's operands (TN), run the matrix core on this one, finish it
+#define MF_TILE(T, TN, cur, curmb, nxt, nxtmb, buf, FAST)                                       \
     {                                                                                            \
         MF_FETCH(min((T) + 1, nT - 1));                                                          \
-        MF_LOAD_TILE(nxt, nxtmb, min((T) + 1, nT - 1));                                          \
+        __builtin_amdgcn_sched_barrier(0);   /* staged operands first: they are needed first */  \
+        MF_LOAD_TILE(nxt, nxtmb, TN, FAST);                                                      \
+        /* keep the loads up here: sunk next to their uses they would be waited for with */      \
+        /* everything younger already in flight, i.e. a full drain per tile              */      \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
         f32x16 acc, accm;                                                                        \
         _Pragma("unroll") for (int i = 0; i < 16; i++) { acc[i] = 0.f; accm[i] = 0.f; }          \
         const float *at = &sA[buf][(h * KH) * 32 + c];                                           \
-        _Pragma("unroll") for (int s = 0; s < KH; s++) {                                         \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[s * 32], bw[s], acc, 0, 0, 0);         \
-            if (MEAN) accm = __builtin_amdgcn_mfma_f32_32x32x2f32(at[(D + 2 + s) * 32], bw[s], accm, 0, 0, 0); \
+        /* A operands in batches of 8 LDS reads ahead of their 8 MFMAs (one wait per batch) */   \
+        _Pragma("unroll") for (int s0 = 0; s0 < KH; s0 += 8) {                                   \
+            float av[8], avm[8];                                                                 \
+            _Pragma("unroll") for (int q = 0; q < 8; q++) {                                      \
+                if (s0 + q < KH) {                                                               \
+                    av[q] = at[(s0 + q) * 32];                                                   \
+                    if (MEAN) avm[q] = at[(D + 2 + s0 + q) * 32];                                \
+                }                                                                                \
+            }                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 8; q++) {                                      \
+                if (s0 + q < KH) {                                                               \
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bw[s0 + q], acc, 0, 0, 0); \
+                    if (MEAN) accm = __builtin_amdgcn_mfma_f32_32x32x2f32(avm[q], bw[s0 + q], accm, 0, 0, 0); \
+                }                                                                                \
+            }                                                                                    \
         }                                                                                        \
+        /* the other LDS buffer was last read before the previous barrier: the staged next  */   \
+        /* tile can land now, while only this tile's younger grid loads are still in flight */   \
+        MF_COMMIT((buf) ^ 1);                                                                    \
         const int r0 = (T0 + (T)) * 32;                                                          \
         const int rem = min(32, n - r0);                                                         \
         const float *prow = &sA[buf][D * 32 + 4 * h];                                            \
@@ -652,15 +689,15 @@ __global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridD
         }                                                                                        \
         float *vdst = p_var + state_base + (size_t)r0 * ld;                                      \
         float *mdst = p_pmean + state_base + (size_t)r0 * ld;                                    \
-        if (cok && rem == 32) {                                                                  \
+        if (FAST) {                                                                              \
             _Pragma("unroll") for (int i = 0; i < 16; i++) {                                     \
-                if (do_var) __builtin_nontemporal_store(acc[i], vdst + (size_t)MF_RL(i) * ld + lane_off); \
+                if (VAR) __builtin_nontemporal_store(acc[i], vdst + (size_t)MF_RL(i) * ld + lane_off); \
                 if (MEAN) __builtin_nontemporal_store(accm[i], mdst + (size_t)MF_RL(i) * ld + lane_off); \
             }                                                                                    \
         } else if (cok) {                                                                        \
             _Pragma("unroll") for (int i = 0; i < 16; i++) {                                     \
                 if (MF_RL(i) + 4 * h < rem) {                                                    \
-                    if (do_var) __builtin_nontemporal_store(acc[i], vdst + (size_t)MF_RL(i) * ld + lane_off); \
+                    if (VAR) __builtin_nontemporal_store(acc[i], vdst + (size_t)MF_RL(i) * ld + lane_off); \
                     if (MEAN) __builtin_nontemporal_store(accm[i], mdst + (size_t)MF_RL(i) * ld + lane_off); \
                 }                                                                                \
             }                                                                                    \
@@ -679,20 +716,41 @@ __global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridD
             }                                                                                    \
             sum += (double)tsum;                                                                 \
         }                                                                                        \
-        MF_COMMIT((buf) ^ 1);                                                                    \
-        __syncthreads();                                                                         \
+        lds_barrier();                                                                           \
     }
 
+    // tiles [0, nfull) of this walk are full 32-row tiles of an in-range wave: branch-free pairs
+    // with ping-pong register sets; what is left (the state's last, partial tile; every tile of
+    // an out-of-range wave, which only has to keep the barriers) goes through the guarded form
+    const int nfull = cok ? max(0, min(nT, (n >> 5) - T0)) : 0;
     float svA[16], svB[16];
     unsigned mbA = 0u, mbB = 0u;
     MF_FETCH(0);
     MF_COMMIT(0);
-    MF_LOAD_TILE(svA, mbA, 0);
     __syncthreads();
+    int T = 0;
+    if (nfull > 0) {
+        MF_LOAD_TILE(svA, mbA, 0, 1);
 #pragma unroll 1
-    for (int T = 0; T < nT; T += 2) {
-        MF_TILE(T, svA, mbA, svB, mbB, 0);
-        if (T + 1 < nT) MF_TILE(T + 1, svB, mbB, svA, mbA, 1);
+        for (; T + 1 < nfull; T += 2) {
+            MF_TILE(T, T + 1, svA, mbA, svB, mbB, 0, 1);
+            MF_TILE(T + 1, min(T + 2, nfull - 1), svB, mbB, svA, mbA, 1, 1);
+        }
+        if (T < nfull) {
+            MF_TILE(T, T, svA, mbA, svB, mbB, 0, 1);
+            T++;
+        }
+    }
+    if (T < nT) {
+        MF_LOAD_TILE(svA, mbA, T, 0);
+#pragma unroll 1
+        for (; T < nT; T++) {
+            const int sbuf = T & 1;
+            MF_TILE(T, min(T + 1, nT - 1), svA, mbA, svB, mbB, sbuf, 0);
+#pragma unroll
+            for (int i = 0; i < 16; i++) svA[i] = svB[i];
+            mbA = mbB;
+        }
     }
     float bestv = sgn * bestkey;
     long long besti = -1;
@@ -733,15 +791,21 @@ __global__ __launch_bounds__(256, APMF_MF_WAVES) void k_mn_grid_mfma(const GridD
 template <int D>
 void launch_grid_mfma(const GridArgs<float> &a, hipStream_t st)
 {
-    const bool red = a.g.want != 0 || a.g.want_sum, mean = a.pmean != nullptr;
+    const bool red = a.g.want != 0 || a.g.want_sum, mean = a.pmean != nullptr, var = a.var != nullptr;
     dim3 grid((unsigned)((long long)a.g.B * a.g.nblk_x * a.g.nblk_y));
-#define APMF_MF(R, M)                                                                              \
-    hipLaunchKernelGGL((k_mn_grid_mfma<D, R, M>), grid, dim3(256), 0, st, a.g, a.cross, a.rowpack,  \
+#define APMF_MF(V, R, M)                                                                           \
+    hipLaunchKernelGGL((k_mn_grid_mfma<D, V, R, M>), grid, dim3(256), 0, st, a.g, a.cross, a.rowpack, \
                        a.colpack, a.state, a.maskT, a.var, a.pmean, a.part_sum, a.part_val, a.part_idx)
-    if (red && mean) APMF_MF(true, true);
-    else if (red) APMF_MF(true, false);
-    else if (mean) APMF_MF(false, true);
-    else APMF_MF(false, false);
+    if (var) {
+        if (red && mean) APMF_MF(true, true, true);
+        else if (red) APMF_MF(true, true, false);
+        else if (mean) APMF_MF(true, false, true);
+        else APMF_MF(true, false, false);
+    } else {
+        if (red && mean) APMF_MF(false, true, true);
+        else if (red) APMF_MF(false, true, false);
+        else APMF_MF(false, false, true);
+    }
 #undef APMF_MF
 }
 
@@ -957,6 +1021,14 @@ int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_
         hipLaunchKernelGGL(k_mask_pack, dim3((ld / 4 + 255) / 256, ngrp), dim3(256), 0, ctx->stream, n, ld,
                            d_mask, (uint16_t *)w2);
         APMF_CHECK_LAUNCH();
+        maskT = (const uint16_t *)w2;
+    } else if (mfma && (want != 0 || d_sum)) {
+        // the matrix-core sweep always reads candidate words (no branch in its tile loop):
+        // "everything is a candidate" is a table of ones
+        const int ngrp = (n + 15) / 16;
+        void *w2;
+        APMF_TRY(apmf_ws(ctx, 2, (size_t)ngrp * ld * sizeof(uint16_t) + 64, &w2));
+        APMF_CHECK_HIP(hipMemsetAsync(w2, 0xFF, (size_t)ngrp * ld * sizeof(uint16_t), ctx->stream));
         maskT = (const uint16_t *)w2;
     }
 

@@ -698,3 +698,19 @@ def test_rank64_paths(ctx):
     ptr, idx, rat = orc.csr_by_row(ratings, 0, n)
     ref = orc.gibbs_half_sweep(ptr[:51], idx, rat, V, alpha, mu, 2.0, 0., z[:50])
     np.testing.assert_allclose(out.to_host()[:50], ref, rtol=1e-8, atol=1e-10)
+
+
+def test_config5_shard_scale(ctx):
+    """BASELINE.json configs[4] (100 000 x 20 000, rank 64, 5e7 observed) at the size ONE of its
+    8 row shards has: 12 500 user rows x 20 000 items, 6.25e6 ratings.  Size-independent
+    properties only (tools/c5_scale.py: sampled gradient rows and the log-likelihood against
+    NumPy, sampled grid rows against the float64 closed form, fused sum / arg-max against the
+    written grid); the full single-GPU run of the whole configuration is the tool itself."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'c5_scale.py')
+    spec = importlib.util.spec_from_file_location('c5_scale', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out, ok = mod.run(n=12500, m=20000, d=64, N=6250000, ctx=ctx)
+    assert ok, out

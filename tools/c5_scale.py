@@ -44,17 +44,11 @@ def timed(ctx, fn, reps):
     return (time.perf_counter() - t) / reps
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--rows', type=int, default=100000)
-    ap.add_argument('--cols', type=int, default=20000)
-    ap.add_argument('--rank', type=int, default=64)
-    ap.add_argument('--ratings', type=int, default=50000000)
-    args = ap.parse_args()
-    n, m, d, N = args.rows, args.cols, args.rank, args.ratings
+def run(n=100000, m=20000, d=64, N=50000000, ctx=None):
+    """All checks at the given shape; returns (measurements dict, passed)."""
     out = {'n': n, 'm': m, 'd': d, 'N': N}
     rs = np.random.RandomState(5)
-    ctx = _lib.Context(0)
+    ctx = ctx or _lib.Context(0)
 
     # ---------------------------------------------------------------- ratings, factors
     t = time.perf_counter()
@@ -145,10 +139,21 @@ def main():
     pi, pj = ctx.empty(cap, np.int32), ctx.empty(cap, np.int32)
     cnt = ctx.grid_collect_near(n, m, ld, d_var, d_mask, 1, float(d_bv.to_host()[0]), 1e-4, pi, pj, cap)
     out['k2_near_ties'] = int(cnt)
-    print(json.dumps(out, indent=1))
     ok = (out['k1_gradient_rows_max_rel_err'] < 1e-11 and out['k1_loglik_rel_err'] < 1e-11 and
           out['k1_fit_trace_increasing'] and out['k2_rows_max_rel_err_f32'] < 1e-4 and
           out['k2_argmax_matches_grid'] and out['k2_sum_rel_err_vs_grid'] < 1e-9)
+    return out, bool(ok)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rows', type=int, default=100000)
+    ap.add_argument('--cols', type=int, default=20000)
+    ap.add_argument('--rank', type=int, default=64)
+    ap.add_argument('--ratings', type=int, default=50000000)
+    args = ap.parse_args()
+    out, ok = run(args.rows, args.cols, args.rank, args.ratings)
+    print(json.dumps(out, indent=1))
     print('C5 checks', 'PASS' if ok else 'FAIL')
     return 0 if ok else 1
 
