@@ -452,3 +452,67 @@ def test_mn_lookahead_golden(pkg):
     for key in ('exp_total_variance', 'exp_total_variance_byapprox', 'exp_approx_entropy', 'onestep_ge_3_5'):
         got = getattr(a, key)(cand)
         assert abs(got - g[key]) <= 2e-4 * abs(g[key]), (key, got, float(g[key]))
+
+
+# ------------------------------------------------------------------ the reference's own checks
+@pytest.mark.parametrize('subtract_mean', [False, True])
+def test_pmf_check_grad_like_reference_notebook(pkg, subtract_mean):
+    """python-pmf/check-grad.ipynb cell [5]: scipy.optimize.check_grad of log_likelihood against
+    gradient on random data; the notebook records 3.3e-7 (4.3e-7 with subtract_mean) for pmf_cy.
+    Same check, same construction, through the HIP kernels."""
+    from scipy.optimize import check_grad
+    seed(21)
+    n, m, d = 12, 9, 3
+    ii, jj = np.nonzero(np.random.rand(n, m) < .5)
+    ratings = np.c_[ii, jj, np.random.randint(1, 6, ii.size)].astype(float)
+    p = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings, latent_d=d, subtract_mean=subtract_mean)
+
+    def split(x):
+        return x[:n * d].reshape(n, d), x[n * d:].reshape(m, d)
+
+    def f(x):
+        return p.log_likelihood(*split(x))
+
+    def g(x):
+        p.users, p.items = split(x.copy())
+        gu, gv = p.gradient()
+        return np.r_[gu.ravel(), gv.ravel()]
+
+    x0 = np.random.rand((n + m) * d)
+    # forward differences with step sqrt(eps): the value is the truncation error, ~1e-6..1e-5 here
+    assert check_grad(f, g, x0) < 5e-5
+
+
+def test_moment_functions_monte_carlo_like_reference_tests(pkg):
+    """python-pmf/test_normal_exps.py:22-63: the moment functions of the drop-in modules within
+    2 % of a Monte-Carlo estimate (here seeded, 4e5 draws), for both parametrisations."""
+    import active_matrix_factorization_amd.normal_exps_cy as ne
+    import active_matrix_factorization_amd.matrix_normal_exps_cy as mne
+    rs = np.random.RandomState(4)
+    n, m, d = 2, 2, 2
+    K = (n + m) * d
+    a = rs.normal(size=(K, K))
+    cov = a @ a.T / K + np.eye(K) * .5
+    mean = rs.normal(size=K)
+    x = rs.multivariate_normal(mean, cov, 400000)
+    u = np.arange(n * d).reshape(n, d).T                  # u[k, i] = i d + k (active_pmf.py:141-142)
+    v = n * d + np.arange(m * d).reshape(m, d).T
+    i, j = 1, 0
+    def close(value, draws):     # within 2 % (the reference's bar) or 4 standard errors of the estimate
+        mc, se = draws.mean(), draws.std() / np.sqrt(draws.size)
+        assert abs(value - mc) <= max(.02 * abs(mc), 4 * se), (value, mc, se)
+
+    close(ne.exp_dotprod_sq(u, v, mean, cov, i, j), np.sum(x[:, u[:, i]] * x[:, v[:, j]], axis=1) ** 2)
+    close(ne.tripexpect(mean, cov, 0, 3, 5), x[:, 0] * x[:, 3] * x[:, 5])
+    close(ne.quadexpect(mean, cov, 0, 2, 5, 7), x[:, 0] * x[:, 2] * x[:, 5] * x[:, 7])
+    close(ne.exp_squared(mean, cov, 1, 6), x[:, 1] ** 2 * x[:, 6] ** 2)
+    close(ne.exp_a2bc(mean, cov, 2, 4, 7), x[:, 2] ** 2 * x[:, 4] * x[:, 7])
+    # matrix-normal: rows ~ cov_useritems, columns ~ cov_latents
+    a = rs.normal(size=(n + m, n + m))
+    R = a @ a.T / (n + m) + np.eye(n + m) * .5
+    b = rs.normal(size=(d, d))
+    Om = b @ b.T / d + np.eye(d) * .5
+    M = rs.normal(size=(n + m, d))
+    z = rs.normal(size=(400000, n + m, d))
+    X = M + np.linalg.cholesky(R) @ z @ np.linalg.cholesky(Om).T
+    close(mne.exp_dotprod_sq(n, M, R, Om, i, j), np.sum(X[:, i, :] * X[:, n + j, :], axis=1) ** 2)
