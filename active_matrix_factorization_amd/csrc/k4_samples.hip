@@ -6,12 +6,18 @@
 //   x_s = U_s[i] . V_s[j] + add
 // in registers; nothing of size S x n x m ever exists.  The contraction (2 d S flops per
 // candidate, S ~ 128) makes this the one compute-bound kernel of the path, and it is a batch
-// of small GEMMs: per sample a wave forms a 16-row x 32-column tile of U_s V_s' with
-// v_mfma_f64_16x16x4_f64 (the latent dimension zero-padded to a multiple of 4), both operands
-// gathered straight from the row-major sample arrays (lane l supplies row/column l & 15,
-// k = 4 q + (l >> 4): a 16 x d block per operand, every cache line of it fully used), and
-// folds the 8 values a lane receives (rows (l >> 4) + 4 reg, column l & 15 of each 16 x 16
-// tile) into its running sums.
+// of small GEMMs on the matrix cores (v_mfma_f64_16x16x4_f64, the latent dimension
+// zero-padded to a multiple of 4).
+// A block is 2 x 2 waves = a 32-row x 64-column tile of the grid; a wave owns 16 x 32 of it
+// (two 16 x 16 accumulators, 8 candidates per lane: the 7 registers of running statistics per
+// candidate are what bounds the tile).  Per sample the block's operands are two CONTIGUOUS
+// chunks of the row-major sample arrays (32 rows of U_s, 64 rows of V_s): they are copied
+// flat into LDS (double-buffered, the next sample's chunk in flight during this sample's
+// MFMAs) and the 4 waves read their MFMA operands from there (lane l: row / column l & 15,
+// k = 4 q + (l >> 4)).  Measured 943 x 1682, d = 15, S = 128: 0.40 ms (the 8 x 2 VALU micro-tile
+// kernel it replaces: 0.80 ms; per-wave operand gathers from global memory: 0.49 ms).  What is
+// left is the per-sample fold (about 7 f64 VALU operations per candidate), which does not overlap
+// with the 64-cycle f64 MFMAs of the same SIMD.
 // Variance is accumulated around the first sample (shifted sums), which matches numpy's
 // two-pass np.var to rounding.
 #include "common.h"
@@ -19,33 +25,82 @@
 namespace {
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
-constexpr int CT = 2;   // 16 x 16 tiles per wave, side by side
+constexpr int CT = 2;          // 16 x 16 tiles per wave, side by side
+constexpr int BR = 32;         // block tile rows  (2 waves)
+constexpr int BC = 32 * CT;    // block tile columns (2 waves x CT tiles)
+constexpr int MAXIT = 24;      // staging loads per thread: (BR + BC) * d / 256 <= 24 for d <= 64
 
-__global__ __launch_bounds__(256) void k_sample_stats(int S, int n, int m, int d, int ld,
+// workgroup barrier ordering LDS traffic only (see k2_score.hip: __syncthreads() would also
+// drain the global loads that are deliberately left in flight)
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// NIT = ceil((BR + BC) d / 256) staging fragments per thread.  LDS image of one sample: the
+// U chunk (BR x d, row-major) then the V chunk (BC x d).  For a power-of-two d (row stride a
+// multiple of the bank count) row r is stored rotated by r, which spreads a column over banks.
+// (NIT <= 8 is held to 128 VGPRs = 4 blocks per CU: at 943 x 1682 the 810 blocks then run as one wave
+// of blocks instead of two)
+template <int NIT>
+__global__ __launch_bounds__(256, NIT <= 8 ? 4 : 2) void k_sample_stats(int S, int n, int m, int d, int ld,
                                                       const double *__restrict__ Us,
                                                       const double *__restrict__ Vs, double add,
                                                       double cutoff, double *__restrict__ o_mean,
                                                       double *__restrict__ o_var,
                                                       double *__restrict__ o_prob)
 {
+    extern __shared__ __attribute__((aligned(16))) double sm[];   // 2 x (BR + BC) x d
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
+    const int wr = wave >> 1, wc = wave & 1;
     const int ri = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.y * 16;
-    const int col0 = (blockIdx.x * 4 + wave) * (16 * CT);
-    if (col0 >= ld) return;   // wave-uniform
+    const int row0 = blockIdx.y * BR, col0 = blockIdx.x * BC;
+    const int tile_el = (BR + BC) * d;
+    const bool pow2 = (d & (d - 1)) == 0;
+    const int dmask = d - 1;
 
-    // operand addresses are clamped into range and the value zeroed afterwards: every lane
-    // issues every load
-    const int arow = min(row0 + ri, n - 1);
-    const bool arow_ok = row0 + ri < n;
-    int bcol[CT];
-    bool bcol_ok[CT];
+    // staging: flat element e = it * 256 + thread of the image; the plan (source chunk, range
+    // check, LDS slot) is a handful of integer operations, recomputed per sample rather than
+    // kept in registers (the running statistics need them)
+    const int u_valid = min(BR, n - row0) * d;              // elements of the U chunk in range
+    const int v_valid = max(0, min(BC, m - col0)) * d;
+    const int log2d = 31 - __builtin_clz(d);
+    double stg[NIT];
+    auto fetch = [&](int s) {
+        const double *ub = Us + ((size_t)s * n + row0) * d;
+        const double *vb = Vs + ((size_t)s * m + col0) * d;
 #pragma unroll
-    for (int t = 0; t < CT; t++) {
-        bcol[t] = min(col0 + 16 * t + ri, m - 1);
-        bcol_ok[t] = col0 + 16 * t + ri < m;
-    }
+        for (int it = 0; it < NIT; it++) {
+            const int e = it * 256 + (int)threadIdx.x;
+            const bool isv = e >= BR * d;
+            const int ce = isv ? e - BR * d : e;
+            const bool ok = ce < (isv ? v_valid : u_valid);
+            const double x = (isv ? vb : ub)[ok ? ce : 0];
+            stg[it] = ok ? x : 0.;
+        }
+    };
+    auto commit = [&](int buf) {
+        double *dst = sm + (size_t)buf * tile_el;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int e = it * 256 + (int)threadIdx.x;
+            int slot = e;
+            if (pow2) {
+                const int r = e >> log2d, k = e & dmask;
+                slot = (r << log2d) + ((k + r) & dmask);
+            }
+            if (e < tile_el) dst[slot] = stg[it];
+        }
+    };
+
+    // operand slots of this lane within an LDS image: U row (16 wr + ri), V rows (32 wc + 16 t + ri)
+    const int arow = 16 * wr + ri;
+    int brow[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) brow[t] = BR + 32 * wc + 16 * t + ri;
 
     double c[CT][4], s1[CT][4], s2[CT][4];
     int cnt[CT][4];
@@ -54,75 +109,59 @@ __global__ __launch_bounds__(256) void k_sample_stats(int S, int n, int m, int d
 #pragma unroll
         for (int r = 0; r < 4; r++) { c[t][r] = 0.; s1[t][r] = 0.; s2[t][r] = 0.; cnt[t][r] = 0; }
 
-    // The walk over (sample, chunk of 16 latent components) is software-pipelined: the
-    // operands of the next chunk are in flight while the matrix core works on this one
-    // (without it every sample costs a full L2 round trip: the kernel was latency-bound).
-    const int nchunk = (d + 15) >> 4;
-    auto load_chunk = [&](int s, int ch, double (&av)[4], double (&bv)[CT][4]) {
-        const double *us = Us + ((size_t)s * n + arow) * d;
-        const double *vs = Vs + (size_t)s * m * d;
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    const int nq = (d + 3) >> 2;
+    for (int s = 0; s < S; s++) {
+        const int buf = s & 1;
+        fetch(min(s + 1, S - 1));            // the last sample re-reads itself: no branch
+        const double *img = sm + (size_t)buf * tile_el;
+        f64x4 acc[CT];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int k = 16 * ch + 4 * q + kq;
-            const int kc = min(k, d - 1);
+        for (int t = 0; t < CT; t++) acc[t] = (f64x4){add, add, add, add};   // x_s = u.v + add
+        for (int q = 0; q < nq; q++) {
+            const int k = 4 * q + kq;
             const bool kok = k < d;
-            const double x = us[kc];
-            av[q] = (kok && arow_ok) ? x : 0.;
+            const int kc = kok ? k : 0;
+            const int ka = pow2 ? ((kc + arow) & dmask) : kc;
+            double av = img[arow * d + ka];
+            av = kok ? av : 0.;
 #pragma unroll
             for (int t = 0; t < CT; t++) {
-                const double y = vs[(size_t)bcol[t] * d + kc];
-                bv[t][q] = (kok && bcol_ok[t]) ? y : 0.;
+                const int kb = pow2 ? ((kc + brow[t]) & dmask) : kc;
+                double bv = img[brow[t] * d + kb];
+                bv = kok ? bv : 0.;
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
             }
         }
-    };
-    double ca[4], cb[CT][4], na[4], nb[CT][4];
-    load_chunk(0, 0, ca, cb);
-    f64x4 acc[CT];
-#pragma unroll
-    for (int t = 0; t < CT; t++) acc[t] = (f64x4){0., 0., 0., 0.};
-    const int total = S * nchunk;
-    int s = 0, ch = 0;
-    for (int it = 0; it < total; it++) {
-        int ns = s, nch = ch + 1;
-        if (nch == nchunk) { nch = 0; ns = s + 1; }
-        const bool more = it + 1 < total;          // the last step re-reads its own operands
-        load_chunk(more ? ns : s, more ? nch : ch, na, nb);
-#pragma unroll
-        for (int q = 0; q < 4; q++)
+        commit(buf ^ 1);
+        if (s == 0) {            // the shift of the running sums is the first sample
 #pragma unroll
             for (int t = 0; t < CT; t++)
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[q], cb[t][q], acc[t], 0, 0, 0);
-        if (ch == nchunk - 1) {
 #pragma unroll
-            for (int t = 0; t < CT; t++) {
+                for (int r = 0; r < 4; r++) c[t][r] = acc[t][r];
+        }
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double xv = acc[t][r] + add;
-                    c[t][r] = (s == 0) ? xv : c[t][r];
-                    const double dlt = xv - c[t][r];
-                    s1[t][r] += dlt;
-                    s2[t][r] = fma(dlt, dlt, s2[t][r]);
-                    cnt[t][r] += (xv >= cutoff) ? 1 : 0;
-                }
-                acc[t] = (f64x4){0., 0., 0., 0.};
+        for (int t = 0; t < CT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double xv = acc[t][r];
+                const double dlt = xv - c[t][r];
+                s1[t][r] += dlt;
+                s2[t][r] = fma(dlt, dlt, s2[t][r]);
+                cnt[t][r] += (xv >= cutoff) ? 1 : 0;
             }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            ca[q] = na[q];
-#pragma unroll
-            for (int t = 0; t < CT; t++) cb[t][q] = nb[t][q];
-        }
-        s = ns;
-        ch = nch;
+        lds_barrier();
     }
     const double invS = 1. / (double)S;
 #pragma unroll
     for (int t = 0; t < CT; t++) {
-        const int col = col0 + 16 * t + ri;     // < ld: ld is a multiple of 64
+        const int col = col0 + 32 * wc + 16 * t + ri;
+        if (col >= ld) continue;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int row = row0 + kq + 4 * r;
+            const int row = row0 + 16 * wr + kq + 4 * r;
             if (row >= n) continue;
             const size_t o = (size_t)row * ld + col;
             const double md = s1[t][r] * invS;
@@ -147,12 +186,27 @@ extern "C" int apmf_sample_stats_f64(apmf_ctx *ctx, int S, int n, int m, int d, 
     APMF_REQUIRE(ld >= m && ld % APMF_GRID_ALIGN == 0, "ld=%d must be >= m and a multiple of %d", ld,
                  APMF_GRID_ALIGN);
     if (!d_mean && !d_var && !d_prob) return APMF_OK;
-    dim3 grid((ld + 64 * CT - 1) / (64 * CT), (n + 15) / 16);
-    {
-        ProfScope prof(ctx);
-        hipLaunchKernelGGL(k_sample_stats, grid, dim3(256), 0, ctx->stream, S, n, m, d, ld, d_Us, d_Vs, add,
-                           cutoff, d_mean, d_var, d_prob);
+    APMF_REQUIRE(d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
+    dim3 grid((ld + BC - 1) / BC, (n + BR - 1) / BR);
+    const size_t smem = 2 * (size_t)(BR + BC) * d * sizeof(double);
+    const int nit = ((BR + BC) * d + 255) / 256;
+#define APMF_K4(NIT)                                                                              \
+    {                                                                                              \
+        if (smem > 64 * 1024)                                                                      \
+            APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_sample_stats<NIT>,                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        ProfScope prof(ctx);                                                                       \
+        hipLaunchKernelGGL((k_sample_stats<NIT>), grid, dim3(256), smem, ctx->stream, S, n, m, d, ld, d_Us, \
+                           d_Vs, add, cutoff, d_mean, d_var, d_prob);                              \
     }
+    if (nit <= 2) APMF_K4(2)
+    else if (nit <= 4) APMF_K4(4)
+    else if (nit <= 6) APMF_K4(6)
+    else if (nit <= 8) APMF_K4(8)
+    else if (nit <= 12) APMF_K4(12)
+    else if (nit <= 16) APMF_K4(16)
+    else APMF_K4(MAXIT)
+#undef APMF_K4
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }

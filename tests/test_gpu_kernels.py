@@ -575,6 +575,28 @@ def test_sample_stats_golden(ctx, name):
     np.testing.assert_array_equal(ctx.download_grid(prob, m), g['prob_ge_full'])
 
 
+@pytest.mark.parametrize('shape', [(1, 1, 1, 1), (3, 5, 70, 2), (8, 33, 65, 5), (16, 47, 130, 15), (5, 32, 64, 16),
+                                   (4, 70, 31, 17), (3, 20, 40, 33), (6, 95, 129, 64)])
+def test_sample_stats_shapes_vs_oracle(ctx, shape):
+    """K4 over every staging bucket (d = 1 .. 64, power-of-two d included: rotated LDS rows),
+    ragged tiles and S = 1, against the oracle's sample-by-sample restatement."""
+    S, n, m, d = shape
+    rs = np.random.RandomState(S + n + m + d)
+    Us, Vs = rs.normal(size=(S, n, d)), rs.normal(size=(S, m, d))
+    from active_matrix_factorization_amd._lib import grid_ld
+    ld = grid_ld(m)
+    mean, var, prob = ctx.empty((n, ld)), ctx.empty((n, ld)), ctx.empty((n, ld))
+    ctx.sample_stats(S, n, m, d, ld, ctx.array(Us), ctx.array(Vs), 1.25, 1.5, mean=mean, var=var, prob=prob)
+    om, ov, op = orc.sample_stats(Us, Vs, 1.25, 1.5)
+    scale = np.abs(om) + np.sqrt(ov) + 1.
+    assert np.all(np.abs(ctx.download_grid(mean, m) - om) <= 1e-12 * scale)
+    assert np.all(np.abs(ctx.download_grid(var, m) - ov) <= 1e-9 * (ov + 1e-3 * scale ** 2))
+    # exceedance counts: exact except where a prediction sits within rounding of the cutoff
+    x = np.einsum('sik,sjk->sij', Us, Vs) + 1.25
+    safe = np.all(np.abs(x - 1.5) > 1e-9, axis=0)
+    assert np.array_equal(ctx.download_grid(prob, m)[safe], op[safe])
+
+
 # ---------------------------------------------------------------------------- dense (rocSOLVER)
 @pytest.mark.parametrize('N', [3, 17, 64, 200])
 def test_dense_project_psd_and_inverse(ctx, N):
