@@ -81,6 +81,15 @@ __global__ __launch_bounds__(256) void k_logabsdet_lu(const double *__restrict__
 
 int grid_for(size_t count) { return (int)((count + 255) / 256); }
 
+// A[i][i] -= min_eig + 1e-10 * max(|A[i][i]|, |min_eig|)  (scratch[0..N) is free to use)
+__global__ __launch_bounds__(256) void k_shift_diag(double *A, int N, double min_eig, double *scratch)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double a = A[(size_t)i * N + i];
+    A[(size_t)i * N + i] = a - (min_eig + 1e-10 * fmax(fabs(a), fabs(min_eig)));
+}
+
 } // namespace
 
 extern "C" {
@@ -98,10 +107,24 @@ int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, 
     int *info = (int *)(E + N);
     hipLaunchKernelGGL(k_symmetrize, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_mat, N);
     APMF_CHECK_LAUNCH();
-    APMF_CHECK_HIP(hipMemcpyAsync(V, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    APMF_CHECK_ROC(rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, N, V, N, evals, E, info));
     double wmin;
     int hinfo;
+    // Fast path.  The reference only rebuilds the matrix when its smallest eigenvalue is below
+    // min_eig; during a fit that is the exception.  "All eigenvalues > min_eig + delta" is
+    // certified by a Cholesky factorisation of the shifted matrix (a few % of the cost of the
+    // eigendecomposition); delta keeps the certificate clear of the rounding of either test.
+    // On failure nothing is concluded and the eigendecomposition decides, as before.
+    APMF_CHECK_HIP(hipMemcpyAsync(V, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_shift_diag, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, V, N, min_eig, evals);
+    APMF_CHECK_LAUNCH();
+    APMF_CHECK_ROC(rocsolver_dpotrf(h, rocblas_fill_lower, N, V, N, info));
+    APMF_TRY(apmf_d2h(ctx, &hinfo, info, sizeof(int)));
+    if (hinfo == 0) {
+        if (h_projected) *h_projected = 0;
+        return APMF_OK;             // the symmetrised input is returned unchanged
+    }
+    APMF_CHECK_HIP(hipMemcpyAsync(V, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    APMF_CHECK_ROC(rocsolver_dsyevd(h, rocblas_evect_original, rocblas_fill_lower, N, V, N, evals, E, info));
     APMF_TRY(apmf_d2h(ctx, &wmin, evals, sizeof(double)));   // ascending: evals[0] is the minimum
     APMF_TRY(apmf_d2h(ctx, &hinfo, info, sizeof(int)));
     if (hinfo != 0) {

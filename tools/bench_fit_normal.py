@@ -8,9 +8,17 @@ import bench
 from active_matrix_factorization_amd import mn_active_pmf, matrix_normal_exps_cy as mnx
 from active_matrix_factorization_amd._active_base import project_psd
 
-ratings, _ = bench.synth_ratings(0)
+# SHAPE="n,m,d,N" (default: the MovieLens shape of bench.py); e.g. SHAPE=94,425,5,500 = configs[3]
+shape = os.environ.get('SHAPE')
 np.random.seed(1)
-a = mn_active_pmf.MNActivePMF(ratings, latent_d=10)
+if shape:
+    n_, m_, d_, N_ = (int(x) for x in shape.split(','))
+    flat = np.random.choice(n_ * m_, N_, replace=False)
+    ratings = np.c_[flat // m_, flat % m_, np.random.randint(1, 6, N_)].astype(float)
+else:
+    d_ = 10
+    ratings, _ = bench.synth_ratings(0)
+a = mn_active_pmf.MNActivePMF(ratings, latent_d=d_)
 a.do_fit()
 a.initialize_approx()
 out = {}
@@ -25,6 +33,8 @@ def _counting(*args, **kw):
     return _orig(*args, **kw)
 a.kl_divergence = _counting
 it = a.fit_normal_kls()
-t0 = time.perf_counter(); kls = [next(it) for _ in range(3)]; out['three_accepted_steps_s'] = time.perf_counter() - t0
-out['kls'] = kls; out['kl_evaluations_in_those_steps'] = trials[0]
+nsteps = int(os.environ.get('STEPS', 3))
+t0 = time.perf_counter(); kls = [next(it) for _ in range(nsteps)]; out['accepted_steps'] = nsteps; out['accepted_steps_s'] = time.perf_counter() - t0
+out['kls'] = kls[:3]; out['kl_evaluations_in_those_steps'] = trials[0]
+out['s_per_trial'] = out['accepted_steps_s'] / max(trials[0], 1)
 print(json.dumps(out, indent=1))
