@@ -24,6 +24,9 @@ struct apmf_ctx {
     // optional event pairs around the dominant kernels (apmf_profile_begin/end)
     hipEvent_t *prof_ev;   // 2 * prof_cap events
     int prof_cap, prof_n;
+    // size-bucketed cache of freed device blocks (ctx.hip): the Python classes allocate and
+    // release many same-sized arrays per step, and hipMalloc / hipFree synchronise the device
+    struct apmf_mempool *pool;
 };
 
 // bracket a kernel launch with events when profiling is on

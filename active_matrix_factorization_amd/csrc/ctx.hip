@@ -1,6 +1,8 @@
 // ctx.hip - context, memory and stream plumbing of the C-ABI (include/apmf.h).
 #include <stdarg.h>
 #include <new>
+#include <unordered_map>
+#include <vector>
 
 #include "common.h"
 
@@ -13,6 +15,34 @@ void apmf_set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- cache of released device blocks ------------------------------------------------
+struct apmf_mempool {
+    std::unordered_map<void *, size_t> live;                      // block -> rounded size
+    std::unordered_map<size_t, std::vector<void *>> free_by_size;
+    size_t cached = 0;
+};
+
+namespace {
+
+constexpr size_t POOL_CAP_BYTES = (size_t)16 << 30;   // of 288 GB
+
+size_t pool_round(size_t bytes)
+{
+    const size_t q = bytes <= ((size_t)1 << 20) ? 512 : ((size_t)1 << 16);
+    return (bytes + q - 1) / q * q;
+}
+
+void pool_release(apmf_ctx *ctx)
+{
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool->free_by_size)
+        for (void *p : kv.second) (void)hipFree(p);
+    ctx->pool->free_by_size.clear();
+    ctx->pool->cached = 0;
+}
+
+} // namespace
 
 extern "C" {
 
@@ -68,6 +98,8 @@ int apmf_ctx_create(int device, apmf_ctx **out)
         return APMF_EHIP;
     }
     c->stream = c->own;
+    c->pool = new (std::nothrow) apmf_mempool();
+    if (!c->pool) { (void)hipStreamDestroy(c->own); delete c; apmf_set_error("out of host memory"); return APMF_ENOMEM; }
     *out = c;
     return APMF_OK;
 }
@@ -84,6 +116,8 @@ int apmf_ctx_destroy(apmf_ctx *ctx)
         for (int i = 0; i < 2 * ctx->prof_cap; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
         delete[] ctx->prof_ev;
     }
+    pool_release(ctx);
+    delete ctx->pool;
     (void)hipStreamDestroy(ctx->own);
     delete ctx;
     return APMF_OK;
@@ -92,6 +126,8 @@ int apmf_ctx_destroy(apmf_ctx *ctx)
 int apmf_ctx_set_stream(apmf_ctx *ctx, void *hip_stream)
 {
     APMF_REQUIRE(ctx, "ctx is NULL");
+    // cached blocks are reused in stream order: finish the old stream before switching
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own;
     return APMF_OK;
 }
@@ -145,7 +181,31 @@ int apmf_malloc(apmf_ctx *ctx, size_t bytes, void **d_out)
     *d_out = nullptr;
     if (bytes == 0) return APMF_OK;
     APMF_CHECK_HIP(hipSetDevice(ctx->device));
-    APMF_CHECK_HIP(hipMalloc(d_out, bytes));
+    apmf_mempool *pool = ctx->pool;
+    const size_t r = pool_round(bytes);
+    auto it = pool->free_by_size.find(r);
+    if (it != pool->free_by_size.end() && !it->second.empty()) {
+        // Reuse is ordered by the stream: everything that touched the block before it was
+        // released was enqueued on ctx->stream, and so is everything that will touch it now.
+        *d_out = it->second.back();
+        it->second.pop_back();
+        pool->cached -= r;
+        pool->live[*d_out] = r;
+        return APMF_OK;
+    }
+    hipError_t e = hipMalloc(d_out, r);
+    if (e != hipSuccess) {      // give the cache back to the driver and try once more
+        (void)hipGetLastError();
+        pool_release(ctx);
+        e = hipMalloc(d_out, r);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *d_out = nullptr;
+        apmf_set_error("hipMalloc of %zu bytes failed: %s", r, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? APMF_ENOMEM : APMF_EHIP;
+    }
+    pool->live[*d_out] = r;
     return APMF_OK;
 }
 
@@ -153,6 +213,17 @@ int apmf_free(apmf_ctx *ctx, void *d_ptr)
 {
     APMF_REQUIRE(ctx, "ctx is NULL");
     if (!d_ptr) return APMF_OK;
+    apmf_mempool *pool = ctx->pool;
+    auto it = pool->live.find(d_ptr);
+    if (it != pool->live.end()) {
+        const size_t r = it->second;
+        pool->live.erase(it);
+        if (pool->cached + r <= POOL_CAP_BYTES) {
+            pool->free_by_size[r].push_back(d_ptr);
+            pool->cached += r;
+            return APMF_OK;
+        }
+    }
     APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     APMF_CHECK_HIP(hipFree(d_ptr));
     return APMF_OK;

@@ -38,3 +38,26 @@ t0 = time.perf_counter(); kls = [next(it) for _ in range(nsteps)]; out['accepted
 out['kls'] = kls[:3]; out['kl_evaluations_in_those_steps'] = trials[0]
 out['s_per_trial'] = out['accepted_steps_s'] / max(trials[0], 1)
 print(json.dumps(out, indent=1))
+
+if os.environ.get('FULL'):
+    # the whole fit: how often the spectrum really had to be clipped, time per phase
+    from active_matrix_factorization_amd import _lib as _l, _active_base as _ab
+    ctx = _l.default_context()
+    stats = {'psd_calls': 0, 'psd_clipped': 0, 'psd_s': 0., 'grad_s': 0., 'kl_s': 0., 'grad_calls': 0}
+    _pp = ctx.dense_project_psd
+    def _psd(*args, **kw):
+        t = time.perf_counter(); r = _pp(*args, **kw); stats['psd_s'] += time.perf_counter() - t
+        stats['psd_calls'] += 1; stats['psd_clipped'] += bool(r); return r
+    ctx.dense_project_psd = _psd
+    _g = mnx.matrixnormal_gradient
+    def _grad(x):
+        t = time.perf_counter(); r = _g(x); stats['grad_s'] += time.perf_counter() - t; stats['grad_calls'] += 1; return r
+    mn_active_pmf.matrixnormal_gradient = _grad
+    _k = _orig
+    def _kl(*args, **kw):
+        t = time.perf_counter(); r = _k(*args, **kw); stats['kl_s'] += time.perf_counter() - t; trials[0] += 1; return r
+    a.kl_divergence = _kl
+    trials[0] = 0
+    t0 = time.perf_counter(); n_acc = sum(1 for _ in a.fit_normal_kls()); stats['total_s'] = time.perf_counter() - t0
+    stats['accepted_after_warmup'] = n_acc; stats['trials'] = trials[0]
+    print(json.dumps(stats, indent=1))
