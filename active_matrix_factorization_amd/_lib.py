@@ -89,6 +89,8 @@ _DENSE_SIGS = {
     'apmf_dense_inv_logdet': (_i, [_vp, _vp, _i, _vp, C.POINTER(_dbl)]),
     'apmf_mn_kl_value': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, C.POINTER(_dbl)]),
     'apmf_mn_kl_gradient': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
+    'apmf_mn_fit_normal': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.POINTER(_dbl),
+                                C.POINTER(_dbl), _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
 }
 DENSE_LIB_PATH = os.path.join(_HERE, 'libapmf_dense.so')
 
@@ -437,6 +439,20 @@ class Context(object):
         _check(load_dense().apmf_mn_kl_gradient(self._h, rt._h, d, _ptr(mean), _ptr(cov_ui),
                                                 _ptr(cov_lat), sig, sig_u, sig_v, _ptr(g_mean),
                                                 _ptr(g_cov_ui), _ptr(g_cov_lat)))
+
+    def mn_fit_normal(self, rt, d, mean, cov_ui, cov_lat, sig, sig_u, sig_v, min_eig, lr, old_kl=None,
+                      max_steps=-1, max_trace=1 << 16):
+        """Device-resident fit_normal_kls steps; returns (kl_trace, steps, lr, converged, old_kl)."""
+        trace = np.empty(max(max_trace, 1), np.float64)
+        lr_io = _dbl(lr)
+        kl_io = _dbl(float('nan') if old_kl is None else old_kl)
+        steps, conv = _i64(0), _i(0)
+        _check(load_dense().apmf_mn_fit_normal(self._h, rt._h, d, _ptr(mean), _ptr(cov_ui), _ptr(cov_lat),
+                                               sig, sig_u, sig_v, float(min_eig), C.byref(lr_io),
+                                               C.byref(kl_io), max_steps, trace.ctypes.data, max_trace,
+                                               C.byref(steps), C.byref(conv)))
+        return (trace[:min(steps.value, max_trace)].copy(), steps.value, lr_io.value, bool(conv.value),
+                kl_io.value)
 
     # -- K3 / K4 -----------------------------------------------------------------------
     def gibbs_half_sweep(self, rt, side, oth, d, alpha, mu, beta, mean_sub, z, out):

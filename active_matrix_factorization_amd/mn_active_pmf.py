@@ -72,18 +72,37 @@ class MNActivePMF(_ActiveBase):
                                 self.sigma_sq, self.sigma_u_sq, self.sigma_v_sq,
                                 _device_ratings=self._device_ratings()[1])
 
+    def _fit_normal_device(self, max_steps):
+        """fit_normal_kls with the approximation resident on the device (apmf_mn_fit_normal):
+        gradient, trial point, both projections, KL and the accept / reject decision of the
+        learning-rate search run without the (n+m)^2 covariance crossing PCIe; yields
+        (kl_trace, converged) per call, the host arrays re-bound after every call like the
+        reference re-binds them after every accepted step (mn_active_pmf.py:242-288)."""
+        self._require_approx(self.mean, self.cov_useritems, self.cov_latents)
+        ctx, rt = self._device_ratings()
+        dm = ctx.array(self.mean, np.float64)
+        dcu = ctx.array(self.cov_useritems, np.float64)
+        dcl = ctx.array(self.cov_latents, np.float64)
+        lr, old_kl, converged = self.normal_learning_rate, None, False
+        while not converged:
+            trace, steps, lr, converged, old_kl = ctx.mn_fit_normal(
+                rt, self.latent_d, dm, dcu, dcl, float(self.sigma_sq), float(self.sigma_u_sq),
+                float(self.sigma_v_sq), self.min_eig, lr, old_kl, max_steps=max_steps)
+            if steps:
+                self.mean, self.cov_useritems, self.cov_latents = dm.to_host(), dcu.to_host(), dcl.to_host()
+            yield trace, converged
+
     def fit_normal_kls(self):
         '''Projected gradient descent on the KL, yielding it after each accepted step
         (mn_active_pmf.py:242-288).'''
-        def step(cand):
-            self.mean, self.cov_useritems, self.cov_latents = cand
+        for trace, _ in self._fit_normal_device(max_steps=1):
+            for kl in trace:
+                yield kl
 
-        def project(k, x):
-            return x if k == 0 else project_psd(x, min_eig=self.min_eig, destroy=True)
-
-        return self._descend(lambda: (self.mean, self.cov_useritems, self.cov_latents),
-                             lambda: matrixnormal_gradient(self), step, project,
-                             self.kl_divergence)
+    def fit_normal(self):
+        '''The whole fit in one device call (same steps as exhausting fit_normal_kls).'''
+        for _ in self._fit_normal_device(max_steps=-1):
+            pass
 
     def mean_meandiff(self):
         '''Mean |approximation mean - MAP value|.'''

@@ -259,6 +259,19 @@ int apmf_mn_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const doubl
                         double sigma_u_sq, double sigma_v_sq, double *d_g_mean,
                         double *d_g_cov_useritems, double *d_g_cov_latents);
 
+/* fit_normal_kls() / fit_normal(), mn_active_pmf.py:236-288, with the approximation resident on
+ * the device: projected gradient descent on the KL with the reference's learning-rate search
+ * (x1.25 on an improving trial, x0.5 otherwise; converged when the KL improves by < .005 or
+ * lr < 1e-10).  d_mean / d_cov_useritems / d_cov_latents are updated in place.  *h_lr and
+ * *h_old_kl carry the search state between calls (pass NaN as *h_old_kl the first time):
+ * max_steps = 1 per `yield` of the generator, -1 for the whole fit.  The KL after every
+ * accepted step goes to h_kl_trace (first trace_cap entries). */
+int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_mean,
+                       double *d_cov_useritems, double *d_cov_latents, double sigma_sq,
+                       double sigma_u_sq, double sigma_v_sq, double min_eig, double *h_lr,
+                       double *h_old_kl, int64_t max_steps, double *h_kl_trace, int64_t trace_cap,
+                       int64_t *h_steps, int *h_converged);
+
 #ifdef __cplusplus
 }
 #endif
