@@ -8,15 +8,19 @@ _get_key_vals, get_key_evals), the one-step lookahead integrator and the experim
 What differs - how a pool of candidates is scored on the GPU and how the approximation is
 fitted - is supplied by the subclass.
 
-GPU note ("fork + HIP"): criteria are evaluated in the calling process.
-A `worker_pool` / `procs` argument is accepted for signature compatibility and ignored -
-a HIP context does not survive fork(), and one batched kernel launch replaces the whole
-map over the pool anyway.
+GPU note ("fork + HIP"): criteria are evaluated in the calling process -
+a HIP context does not survive fork().  Pool-scoring criteria are one batched kernel launch;
+the lookahead criteria (the ones the reference hands to its process pool) are mapped over a
+small pool of threads, each with its own Context: `procs` is the number of threads (default
+APMF_LOOKAHEAD_THREADS or 8; 0 or 1 = sequential), `worker_pool` is accepted and ignored.
 """
+import concurrent.futures
 import itertools
 import math
 import operator
+import os
 import random
+import threading
 import warnings
 from copy import deepcopy
 
@@ -53,6 +57,49 @@ def project_psd(mat, min_eig=0, destroy=False):
 
 def strictmap(*args, **kwargs):
     return list(map(*args, **kwargs))
+
+
+# -- concurrent lookahead -------------------------------------------------------------------
+# The reference farms the lookahead criteria (spawn_processes = True) out to a forked process
+# pool.  A HIP context does not survive fork(), but every hypothesis (candidate, rating value)
+# is an independent deep copy whose re-fit is one long C-ABI call that releases the GIL, and a
+# single variational re-fit keeps only a few CUs busy: a small pool of THREADS, each with its
+# own Context (= own stream), overlaps them on the GPU.  Results are returned in input order
+# and are identical to the sequential ones.
+_workers = None
+_worker_state = threading.local()
+
+
+def lookahead_threads(procs=None):
+    if procs is not None and procs >= 0:
+        return int(procs)
+    return int(os.environ.get('APMF_LOOKAHEAD_THREADS', '8'))
+
+
+def _parallel_map(fn, items, procs=None):
+    """[fn(x) for x in items], concurrently when worthwhile; never nested."""
+    global _workers
+    items = list(items)
+    width = min(lookahead_threads(procs), len(items))
+    if width <= 1 or getattr(_worker_state, 'inside', False):
+        return [fn(x) for x in items]
+    if _workers is None:
+        _workers = concurrent.futures.ThreadPoolExecutor(max_workers=max(lookahead_threads(), 1),
+                                                         thread_name_prefix='apmf-lookahead')
+
+    def run(x):
+        _worker_state.inside = True
+        try:
+            return fn(x)
+        finally:
+            _worker_state.inside = False
+
+    gate = threading.Semaphore(width)
+
+    def gated(x):
+        with gate:
+            return run(x)
+    return list(_workers.map(gated, items))
 
 
 class _Evaluator(object):
@@ -351,7 +398,7 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
 
         points = self.rating_values
         if discretize and points:
-            evals = np.array([calculate_fn(v) for v in points])
+            evals = np.array(_parallel_map(calculate_fn, points))
             if discretize == 'simps':
                 pdfs = stats.norm.pdf(points, loc=mean, scale=std)
                 import scipy.integrate
@@ -402,6 +449,10 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             if not pool:
                 return []
             return list(np.asarray(getattr(self, impl)(pi, pj), dtype=np.float64))
+        if getattr(key, 'spawn_processes', False) and len(pool) > 1:
+            # one hypothesis chain per worker; each works on its own deep copy (the shared model's
+            # device context belongs to the calling thread)
+            return _parallel_map(lambda ij: key(deepcopy(self), ij), pool, procs)
         return [key(self, ij) for ij in pool]
 
     def get_key_evals(self, pool=None, key=None, procs=None, worker_pool=None):

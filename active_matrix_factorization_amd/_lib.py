@@ -480,10 +480,21 @@ class Context(object):
 _default_ctx = {}
 
 
-def default_context(device=0):
-    """Per-process, per-device Context, created lazily (never before a fork: a HIP context
-    does not survive it)."""
-    key = (os.getpid(), int(device))
+def default_device():
+    """Device the Python classes use when none is named: APMF_DEVICE, else LOCAL_RANK (one
+    process per GPU under torch.distributed.run), else 0 - modulo the visible devices."""
+    want = int(os.environ.get('APMF_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    return want % max(device_count(), 1)
+
+
+def default_context(device=None):
+    """Per-process, per-THREAD, per-device Context, created lazily (never before a fork: a HIP
+    context does not survive it).  A Context is one stream plus its
+    workspaces and must not be driven from two threads at once; giving every thread its own
+    is what lets the lookahead hypotheses be re-fitted concurrently (_active_base.py)."""
+    if device is None:
+        device = default_device()
+    key = (os.getpid(), threading.get_ident(), int(device))
     ctx = _default_ctx.get(key)
     if ctx is None:
         ctx = Context(device)

@@ -27,6 +27,12 @@ struct apmf_ctx {
     // size-bucketed cache of freed device blocks (ctx.hip): the Python classes allocate and
     // release many same-sized arrays per step, and hipMalloc / hipFree synchronise the device
     struct apmf_mempool *pool;
+    // rocBLAS handle of libapmf_dense.so (one per context: contexts may live on different
+    // threads), with the function that destroys it - libapmf_hip.so itself has no BLAS dependency
+    void *blas;
+    void (*blas_destroy)(void *);
+    // 4 KB of pinned host memory for small read-backs (apmf_d2h)
+    void *rd_pin;
 };
 
 // bracket a kernel launch with events when profiling is on

@@ -1,5 +1,6 @@
 // ctx.hip - context, memory and stream plumbing of the C-ABI (include/apmf.h).
 #include <stdarg.h>
+#include <mutex>
 #include <new>
 #include <unordered_map>
 #include <vector>
@@ -21,11 +22,24 @@ struct apmf_mempool {
     std::unordered_map<void *, size_t> live;                      // block -> rounded size
     std::unordered_map<size_t, std::vector<void *>> free_by_size;
     size_t cached = 0;
+    // a block may be released from another thread than the one driving the context (Python's
+    // garbage collector runs wherever it is triggered)
+    std::mutex mu;
 };
 
 namespace {
 
 constexpr size_t POOL_CAP_BYTES = (size_t)16 << 30;   // of 288 GB
+
+// APMF_POISON=1 (debugging / the test-suite): every block handed out, fresh or recycled, and every
+// workspace request is filled with 0xFF bytes (NaN as float or double, -1 as int) first, so that a
+// kernel reading memory it was supposed to have written itself shows up as NaNs instead of as a
+// result that depends on what ran before.
+bool poison_on()
+{
+    static const bool on = getenv("APMF_POISON") != nullptr && getenv("APMF_POISON")[0] == '1';
+    return on;
+}
 
 size_t pool_round(size_t bytes)
 {
@@ -33,6 +47,7 @@ size_t pool_round(size_t bytes)
     return (bytes + q - 1) / q * q;
 }
 
+// caller holds pool->mu (or owns the context exclusively)
 void pool_release(apmf_ctx *ctx)
 {
     (void)hipStreamSynchronize(ctx->stream);
@@ -98,6 +113,7 @@ int apmf_ctx_create(int device, apmf_ctx **out)
         return APMF_EHIP;
     }
     c->stream = c->own;
+    (void)hipHostMalloc(&c->rd_pin, 4096, hipHostMallocDefault);   // optional: NULL falls back to pageable
     c->pool = new (std::nothrow) apmf_mempool();
     if (!c->pool) { (void)hipStreamDestroy(c->own); delete c; apmf_set_error("out of host memory"); return APMF_ENOMEM; }
     *out = c;
@@ -112,10 +128,12 @@ int apmf_ctx_destroy(apmf_ctx *ctx)
     for (int i = 0; i < 4; i++)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->rd_pin) (void)hipHostFree(ctx->rd_pin);
     if (ctx->prof_ev) {
         for (int i = 0; i < 2 * ctx->prof_cap; i++) (void)hipEventDestroy(ctx->prof_ev[i]);
         delete[] ctx->prof_ev;
     }
+    if (ctx->blas && ctx->blas_destroy) ctx->blas_destroy(ctx->blas);
     pool_release(ctx);
     delete ctx->pool;
     (void)hipStreamDestroy(ctx->own);
@@ -182,6 +200,7 @@ int apmf_malloc(apmf_ctx *ctx, size_t bytes, void **d_out)
     if (bytes == 0) return APMF_OK;
     APMF_CHECK_HIP(hipSetDevice(ctx->device));
     apmf_mempool *pool = ctx->pool;
+    std::lock_guard<std::mutex> lock(pool->mu);
     const size_t r = pool_round(bytes);
     auto it = pool->free_by_size.find(r);
     if (it != pool->free_by_size.end() && !it->second.empty()) {
@@ -191,6 +210,7 @@ int apmf_malloc(apmf_ctx *ctx, size_t bytes, void **d_out)
         it->second.pop_back();
         pool->cached -= r;
         pool->live[*d_out] = r;
+        if (poison_on()) APMF_CHECK_HIP(hipMemsetAsync(*d_out, 0xFF, r, ctx->stream));
         return APMF_OK;
     }
     hipError_t e = hipMalloc(d_out, r);
@@ -206,6 +226,7 @@ int apmf_malloc(apmf_ctx *ctx, size_t bytes, void **d_out)
         return e == hipErrorOutOfMemory ? APMF_ENOMEM : APMF_EHIP;
     }
     pool->live[*d_out] = r;
+    if (poison_on()) APMF_CHECK_HIP(hipMemsetAsync(*d_out, 0xFF, r, ctx->stream));
     return APMF_OK;
 }
 
@@ -214,6 +235,7 @@ int apmf_free(apmf_ctx *ctx, void *d_ptr)
     APMF_REQUIRE(ctx, "ctx is NULL");
     if (!d_ptr) return APMF_OK;
     apmf_mempool *pool = ctx->pool;
+    std::lock_guard<std::mutex> lock(pool->mu);
     auto it = pool->live.find(d_ptr);
     if (it != pool->live.end()) {
         const size_t r = it->second;
@@ -254,6 +276,14 @@ int apmf_d2h(apmf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
     APMF_REQUIRE(ctx, "ctx is NULL");
     if (bytes == 0) return APMF_OK;
     APMF_REQUIRE(h_dst && d_src, "NULL pointer");
+    if (bytes <= 4096 && ctx->rd_pin) {
+        // small read-backs (flags, scalars: several per trial of the searches) land in the
+        // context's own pinned buffer: no staging of a pageable destination by the runtime
+        APMF_CHECK_HIP(hipMemcpyAsync(ctx->rd_pin, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(h_dst, ctx->rd_pin, bytes);
+        return APMF_OK;
+    }
     APMF_CHECK_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return APMF_OK;
@@ -307,6 +337,7 @@ int apmf_ws(apmf_ctx *ctx, int slot, size_t bytes, void **out)
         ctx->ws_bytes[slot] = want;
     }
     *out = ctx->ws[slot];
+    if (poison_on()) APMF_CHECK_HIP(hipMemsetAsync(ctx->ws[slot], 0xFF, bytes, ctx->stream));
     return APMF_OK;
 }
 

@@ -6,6 +6,8 @@
 // These are plain LAPACK-shaped operations, so they go to rocSOLVER / rocBLAS (syevd, getrf,
 // getri, gemm); the element-wise glue (symmetrise, spectrum clip, mirror) is HIP.  Kept in a
 // library of its own so that libapmf_hip.so has no BLAS dependency; loaded lazily.
+#include <algorithm>
+
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
@@ -13,21 +15,29 @@
 
 namespace {
 
-rocblas_handle g_handle = nullptr;
+void destroy_handle(void *h) { (void)rocblas_destroy_handle((rocblas_handle)h); }
 
+// one rocBLAS handle per context, created on first use, bound to the context's stream
 int handle_for(apmf_ctx *ctx, rocblas_handle *out)
 {
-    if (!g_handle) {
-        if (rocblas_create_handle(&g_handle) != rocblas_status_success) {
+    if (!ctx->blas) {
+        (void)hipSetDevice(ctx->device);
+        rocblas_handle h = nullptr;
+        if (rocblas_create_handle(&h) != rocblas_status_success) {
             apmf_set_error("rocblas_create_handle failed");
             return APMF_EHIP;
         }
+        // bit-reproducible results: the accept / reject searches built on these routines
+        // amplify a last-place difference into a different trajectory
+        (void)rocblas_set_atomics_mode(h, rocblas_atomics_not_allowed);
+        ctx->blas = h;
+        ctx->blas_destroy = destroy_handle;
     }
-    if (rocblas_set_stream(g_handle, ctx->stream) != rocblas_status_success) {
+    if (rocblas_set_stream((rocblas_handle)ctx->blas, ctx->stream) != rocblas_status_success) {
         apmf_set_error("rocblas_set_stream failed");
         return APMF_EHIP;
     }
-    *out = g_handle;
+    *out = (rocblas_handle)ctx->blas;
     return APMF_OK;
 }
 
@@ -120,13 +130,13 @@ __global__ __launch_bounds__(256) void k_logdet_chol(const double *__restrict__ 
     if (threadIdx.x == 0) *out = 2. * sh[0];
 }
 
-// the triangle potri wrote (memory index c * N + r, r >= c) mirrored into the other one
+// the row-major lower triangle (i > j at i * N + j) mirrored into the upper one
 __global__ __launch_bounds__(256) void k_mirror_triangle(double *__restrict__ A, int N)
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (size_t)N * N) return;
-    const int c = (int)(t / N), r = (int)(t % N);
-    if (r > c) A[(size_t)r * N + c] = A[t];
+    const int i = (int)(t / N), j = (int)(t % N);
+    if (i > j) A[(size_t)j * N + i] = A[t];
 }
 
 // N <= 32, one wave: Cholesky in LDS of A (shifted down on the diagonal when `shift` is set:
@@ -198,6 +208,145 @@ __global__ __launch_bounds__(64) void k_small_spd(const double *__restrict__ A, 
     }
 }
 
+// ---- blocked Cholesky of our own ---------------------------------------------------------
+// rocSOLVER's potrf is not bit-reproducible when the GPU is shared (another stream or process
+// running): the same input gave last-place different factors, and the accept / reject
+// searches built on it amplify that into different trajectories.  This one is a plain
+// right-looking blocked factorisation with fixed summation orders and no atomics:
+//   per panel of CH_NB columns: factor the diagonal block (one wave, LDS), solve the rows
+//   below it against that block (one thread per row), update the trailing lower triangle
+//   (64 x 64 tiles, the panel staged through LDS).
+// A is row-major; only its lower triangle (i >= j) is read, and L overwrites it.
+constexpr int CH_NB = 64;
+
+// diagonal block k..k+nb: L_kk in place; *info = k + j + 1 at the first non-positive pivot
+__global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ A, int N, int k, int *__restrict__ info)
+{
+    __shared__ double L[CH_NB][CH_NB + 1];
+    const int t = threadIdx.x;
+    const int nb = min(CH_NB, N - k);
+    if (*info != 0) return;          // an earlier panel already failed
+    for (int e = t; e < nb * nb; e += 64) {
+        const int i = e / nb, j = e % nb;
+        L[i][j] = j <= i ? A[(size_t)(k + i) * N + k + j] : 0.;
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; j++) {
+        const double djj = L[j][j];
+        __syncthreads();
+        if (!(djj > 0.)) {
+            if (t == 0) *info = k + j + 1;
+            return;
+        }
+        const double rj = sqrt(djj);
+        if (t == j) L[j][j] = rj;
+        if (t > j && t < nb) L[t][j] /= rj;
+        __syncthreads();
+        if (t > j && t < nb) {
+            const double lij = L[t][j];
+            for (int c = j + 1; c <= t; c++) L[t][c] -= lij * L[c][j];
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < nb * nb; e += 64) {
+        const int i = e / nb, j = e % nb;
+        if (j <= i) A[(size_t)(k + i) * N + k + j] = L[i][j];
+    }
+}
+
+// rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T   (one thread per row)
+__global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ A, int N, int k, const int *__restrict__ info)
+{
+    __shared__ double L[CH_NB][CH_NB + 1];
+    const int t = threadIdx.x;
+    const int nb = min(CH_NB, N - k);
+    if (*info != 0) return;
+    for (int e = t; e < nb * nb; e += 64) {
+        const int i = e / nb, j = e % nb;
+        L[i][j] = j <= i ? A[(size_t)(k + i) * N + k + j] : 0.;
+    }
+    __syncthreads();
+    const int r = k + nb + blockIdx.x * 64 + t;
+    if (r >= N) return;
+    double *row = A + (size_t)r * N + k;
+    double x[CH_NB];
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++) x[j] = j < nb ? row[j] : 0.;
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++) {
+        if (j < nb) {
+            double v = x[j];
+#pragma unroll
+            for (int c = 0; c < j; c++) v -= x[c] * L[j][c];
+            x[j] = v / L[j][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++)
+        if (j < nb) row[j] = x[j];
+}
+
+// trailing update: for i >= j >= k + nb:  A[i][j] -= sum_t P[i][t] P[j][t],  P = A[:, k..k+nb)
+// one 64 x 64 tile per block (tiles on or below the diagonal), 4 x 4 outputs per thread
+__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int N, int k, const int *__restrict__ info)
+{
+    __shared__ double Pi[64][CH_NB + 1], Pj[64][CH_NB + 1];
+    if (*info != 0) return;
+    const int nb = min(CH_NB, N - k);
+    const int base = k + nb;
+    // triangular tile index -> (ti >= tj)
+    int ti = (int)((sqrt(8. * blockIdx.x + 1.) - 1.) / 2.);
+    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
+    while (ti * (ti + 1) / 2 > (int)blockIdx.x) ti--;
+    const int tj = blockIdx.x - ti * (ti + 1) / 2;
+    const int i0 = base + ti * 64, j0 = base + tj * 64;
+    for (int e = threadIdx.x; e < 64 * nb; e += 256) {
+        const int r = e / nb, c = e % nb;
+        Pi[r][c] = i0 + r < N ? A[(size_t)(i0 + r) * N + k + c] : 0.;
+        Pj[r][c] = j0 + r < N ? A[(size_t)(j0 + r) * N + k + c] : 0.;
+    }
+    __syncthreads();
+    const int tr = (threadIdx.x >> 4) * 4, tc = (threadIdx.x & 15) * 4;
+    double acc[4][4] = {};
+    for (int c = 0; c < nb; c++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = Pi[tr + u][c]; b[u] = Pj[tc + u][c]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int i = i0 + tr + u, j = j0 + tc + v;
+            if (i < N && j <= i) A[(size_t)i * N + j] -= acc[u][v];
+        }
+}
+
+// Cholesky of the lower triangle of the row-major N x N matrix A, in place; d_info (device int,
+// zeroed here) receives 0 or the 1-based index of the first non-positive pivot
+int chol_lower(apmf_ctx *ctx, double *A, int N, int *d_info)
+{
+    APMF_CHECK_HIP(hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
+    for (int k = 0; k < N; k += CH_NB) {
+        const int nb = std::min(CH_NB, N - k);
+        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, ctx->stream, A, N, k, d_info);
+        const int rest = N - k - nb;
+        if (rest > 0) {
+            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64), dim3(64), 0, ctx->stream, A, N, k,
+                               (const int *)d_info);
+            const int tiles = (rest + 63) / 64;
+            hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, ctx->stream, A, N, k,
+                               (const int *)d_info);
+        }
+    }
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -237,7 +386,7 @@ int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, 
     APMF_CHECK_HIP(hipMemcpyAsync(V, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_shift_diag, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, V, N, min_eig, evals);
     APMF_CHECK_LAUNCH();
-    APMF_CHECK_ROC(rocsolver_dpotrf(h, rocblas_fill_lower, N, V, N, info));
+    APMF_TRY(chol_lower(ctx, V, N, info));
     APMF_TRY(apmf_d2h(ctx, &hinfo, info, sizeof(int)));
     if (hinfo == 0) {
         if (h_projected) *h_projected = 0;
@@ -295,7 +444,7 @@ int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_i
         hipLaunchKernelGGL(k_check_symmetric, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_mat, N, info + 1);
         APMF_CHECK_LAUNCH();
         APMF_CHECK_HIP(hipMemcpyAsync(LU, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        APMF_CHECK_ROC(rocsolver_dpotrf(h, rocblas_fill_lower, N, LU, N, info));
+        APMF_TRY(chol_lower(ctx, LU, N, info));
         int hi[2];
         APMF_TRY(apmf_d2h(ctx, hi, info, sizeof(hi)));
         if (hi[0] == 0 && hi[1] == 0) {
@@ -305,7 +454,8 @@ int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_i
                 APMF_TRY(apmf_d2h(ctx, h_logdet, scal, sizeof(double)));
             }
             if (d_inv) {
-                APMF_CHECK_ROC(rocsolver_dpotri(h, rocblas_fill_lower, N, LU, N, info));
+                // row-major lower L = column-major upper U with A = U'U
+                APMF_CHECK_ROC(rocsolver_dpotri(h, rocblas_fill_upper, N, LU, N, info));
                 hipLaunchKernelGGL(k_mirror_triangle, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, LU, N);
                 APMF_CHECK_LAUNCH();
             }

@@ -516,3 +516,22 @@ def test_moment_functions_monte_carlo_like_reference_tests(pkg):
     z = rs.normal(size=(400000, n + m, d))
     X = M + np.linalg.cholesky(R) @ z @ np.linalg.cholesky(Om).T
     close(mne.exp_dotprod_sq(n, M, R, Om, i, j), np.sum(X[:, i, :] * X[:, n + j, :], axis=1) ** 2)
+
+
+def test_lookahead_threads_equal_sequential(pkg):
+    """The lookahead criteria are mapped over a pool of threads, one Context (stream) each, where
+    the reference uses a process pool: same values, same order, as the sequential map."""
+    g = load_golden('lookahead_c1_mn')
+    a = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5),
+                           discrete_expectations=True)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+    pool = sorted(a.unrated)[:6]
+    key = pkg.mn.KEY_FUNCS['total-variance']
+    seq = a._get_key_vals(pool, key, procs=1)
+    par = a._get_key_vals(pool, key, procs=6)
+    assert seq == par
+    assert a.pick_query_point(pool=pool, key=key, procs=1) == a.pick_query_point(pool=pool, key=key, procs=4)
+    # a single candidate: the rating values are what is mapped
+    one = a.exp_total_variance(pool[2])
+    assert one == seq[2]

@@ -86,14 +86,18 @@ def main():
     out['picks'] = [list(map(int, s_[2])) for s_ in steps_res[1:]]
     say('query loop done')
 
-    # one lookahead criterion over a 2-candidate pool (each candidate: 5 hypothesised ratings,
+    # one lookahead criterion over a 4-candidate pool (each candidate: 5 hypothesised ratings,
     # each with a variational refit and a full-grid total-variance sweep)
-    pool = list(apmf.unrated)[:2]
-    t = time.perf_counter()
-    with redirect_stdout(log):
-        pick = apmf.pick_query_point(pool=pool, key=mn.KEY_FUNCS['total-variance'])
-    out['lookahead_2cand_s'] = time.perf_counter() - t
-    out['lookahead_pick'] = list(map(int, pick))
+    pool = sorted(apmf.unrated)[:2]
+    key = mn.KEY_FUNCS['total-variance']
+    for label, procs in (('threads', None), ('sequential', 1), ('sequential_again', 1)):
+        t = time.perf_counter()
+        with redirect_stdout(log):
+            vals = apmf._get_key_vals(pool, key, procs=procs)
+        out['lookahead_2cand_%s_s' % label] = time.perf_counter() - t
+        out['lookahead_2cand_%s_vals' % label] = [float(x) for x in vals]
+        say('lookahead %s done' % label)
+    out['lookahead_pool'] = [list(map(int, ij)) for ij in pool]
     stop.set()
     print(json.dumps(out, indent=1))
 
