@@ -219,52 +219,70 @@ __global__ __launch_bounds__(64) void k_small_spd(const double *__restrict__ A, 
 // A is row-major; only its lower triangle (i >= j) is read, and L overwrites it.
 constexpr int CH_NB = 64;
 
-// diagonal block k..k+nb: L_kk in place; *info = k + j + 1 at the first non-positive pivot
-__global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ A, int N, int k, int *__restrict__ info)
+// lane `src` 's value of a wave-resident double, as a wave-uniform value
+__device__ __forceinline__ double lane_value(double v, int src)
 {
-    __shared__ double L[CH_NB][CH_NB + 1];
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Diagonal block k..k+nb, one wave, everything in registers: lane t holds row t of the block
+// (64 doubles) and other lanes' entries arrive by v_readlane - the LDS version of this kernel
+// spent 113 us per block waiting on dependent LDS round trips, this one ~20.  Writes L_kk in
+// place and L_kk^-1 (64 x 64, row-major, zero above the diagonal) to `linv` for the panel
+// solve.  A short last block is padded with the identity.  *info = k + j + 1 at the first
+// non-positive pivot.
+__global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ A, int N, int k, int *__restrict__ info,
+                                                  double *__restrict__ linv)
+{
     const int t = threadIdx.x;
     const int nb = min(CH_NB, N - k);
     if (*info != 0) return;          // an earlier panel already failed
-    for (int e = t; e < nb * nb; e += 64) {
-        const int i = e / nb, j = e % nb;
-        L[i][j] = j <= i ? A[(size_t)(k + i) * N + k + j] : 0.;
-    }
-    __syncthreads();
-    for (int j = 0; j < nb; j++) {
-        const double djj = L[j][j];
-        __syncthreads();
-        if (!(djj > 0.)) {
+    double r[CH_NB];
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++)
+        r[c] = (t < nb && c <= t) ? A[(size_t)(k + t) * N + k + c] : (c == t ? 1. : 0.);
+    // right-looking factorisation; entries above the diagonal hold don't-care values
+#pragma unroll
+    for (int j = 0; j < CH_NB; j++) {
+        const double pj = lane_value(r[j], j);
+        if (!(pj > 0.)) {            // wave-uniform
             if (t == 0) *info = k + j + 1;
             return;
         }
-        const double rj = sqrt(djj);
-        if (t == j) L[j][j] = rj;
-        if (t > j && t < nb) L[t][j] /= rj;
-        __syncthreads();
-        if (t > j && t < nb) {
-            const double lij = L[t][j];
-            for (int c = j + 1; c <= t; c++) L[t][c] -= lij * L[c][j];
-        }
-        __syncthreads();
+        const double rj = sqrt(pj);
+        r[j] = t == j ? rj : r[j] / rj;
+#pragma unroll
+        for (int c = j + 1; c < CH_NB; c++) r[c] -= r[j] * lane_value(r[j], c);
     }
-    for (int e = t; e < nb * nb; e += 64) {
-        const int i = e / nb, j = e % nb;
-        if (j <= i) A[(size_t)(k + i) * N + k + j] = L[i][j];
+#pragma unroll
+    for (int c = 0; c < CH_NB; c++)
+        if (t < nb && c <= t) A[(size_t)(k + t) * N + k + c] = r[c];
+    // X = L^-1: lane c owns column c, X[i][c] = (delta_ic - sum_{m=c}^{i-1} L[i][m] X[m][c]) / L[i][i]
+    double x[CH_NB];
+#pragma unroll
+    for (int i = 0; i < CH_NB; i++) {
+        double v = i == t ? 1. : 0.;
+#pragma unroll
+        for (int m = 0; m < i; m++) v -= lane_value(r[m], i) * x[m];   // x[m] = 0 for m < c
+        x[i] = i < t ? 0. : v / lane_value(r[i], i);
     }
+#pragma unroll
+    for (int i = 0; i < CH_NB; i++) linv[i * CH_NB + t] = x[i];
 }
 
-// rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T   (one thread per row)
-__global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ A, int N, int k, const int *__restrict__ info)
+// rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T = (row) x (L_kk^-1)'  (one thread per row;
+// the 64 products per row are independent sums, unlike a forward substitution)
+__global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ A, int N, int k, const int *__restrict__ info,
+                                                   const double *__restrict__ linv)
 {
-    __shared__ double L[CH_NB][CH_NB + 1];
+    __shared__ double X[CH_NB][CH_NB + 1];
     const int t = threadIdx.x;
     const int nb = min(CH_NB, N - k);
     if (*info != 0) return;
-    for (int e = t; e < nb * nb; e += 64) {
-        const int i = e / nb, j = e % nb;
-        L[i][j] = j <= i ? A[(size_t)(k + i) * N + k + j] : 0.;
-    }
+    for (int e = t; e < CH_NB * CH_NB; e += 64) X[e / CH_NB][e % CH_NB] = linv[e];
     __syncthreads();
     const int r = k + nb + blockIdx.x * 64 + t;
     if (r >= N) return;
@@ -275,15 +293,12 @@ __global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ A, int N
 #pragma unroll
     for (int j = 0; j < CH_NB; j++) {
         if (j < nb) {
-            double v = x[j];
+            double v = 0.;
 #pragma unroll
-            for (int c = 0; c < j; c++) v -= x[c] * L[j][c];
-            x[j] = v / L[j][j];
+            for (int c = 0; c <= j; c++) v += x[c] * X[j][c];
+            row[j] = v;
         }
     }
-#pragma unroll
-    for (int j = 0; j < CH_NB; j++)
-        if (j < nb) row[j] = x[j];
 }
 
 // trailing update: for i >= j >= k + nb:  A[i][j] -= sum_t P[i][t] P[j][t],  P = A[:, k..k+nb)
@@ -328,16 +343,16 @@ __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int
 
 // Cholesky of the lower triangle of the row-major N x N matrix A, in place; d_info (device int,
 // zeroed here) receives 0 or the 1-based index of the first non-positive pivot
-int chol_lower(apmf_ctx *ctx, double *A, int N, int *d_info)
+int chol_lower(apmf_ctx *ctx, double *A, int N, int *d_info, double *d_linv /* CH_NB^2 doubles */)
 {
     APMF_CHECK_HIP(hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
     for (int k = 0; k < N; k += CH_NB) {
         const int nb = std::min(CH_NB, N - k);
-        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, ctx->stream, A, N, k, d_info);
+        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, ctx->stream, A, N, k, d_info, d_linv);
         const int rest = N - k - nb;
         if (rest > 0) {
             hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64), dim3(64), 0, ctx->stream, A, N, k,
-                               (const int *)d_info);
+                               (const int *)d_info, (const double *)d_linv);
             const int tiles = (rest + 63) / 64;
             hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, ctx->stream, A, N, k,
                                (const int *)d_info);
@@ -359,9 +374,10 @@ int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, 
     APMF_TRY(handle_for(ctx, &h));
     const size_t nn = (size_t)N * N;
     void *w;
-    APMF_TRY(apmf_ws(ctx, 3, (2 * nn + 2 * (size_t)N) * sizeof(double) + 64, &w));
+    APMF_TRY(apmf_ws(ctx, 3, (2 * nn + 2 * (size_t)N + 8 + CH_NB * CH_NB) * sizeof(double) + 64, &w));
     double *V = (double *)w, *Vs = V + nn, *evals = Vs + nn, *E = evals + N;
     int *info = (int *)(E + N);
+    double *linv = E + N + 8;      // scratch of the blocked Cholesky
     hipLaunchKernelGGL(k_symmetrize, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_mat, N);
     APMF_CHECK_LAUNCH();
     double wmin;
@@ -386,7 +402,7 @@ int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, 
     APMF_CHECK_HIP(hipMemcpyAsync(V, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(k_shift_diag, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, V, N, min_eig, evals);
     APMF_CHECK_LAUNCH();
-    APMF_TRY(chol_lower(ctx, V, N, info));
+    APMF_TRY(chol_lower(ctx, V, N, info, linv));
     APMF_TRY(apmf_d2h(ctx, &hinfo, info, sizeof(int)));
     if (hinfo == 0) {
         if (h_projected) *h_projected = 0;
@@ -422,7 +438,9 @@ int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_i
     APMF_TRY(handle_for(ctx, &h));
     const size_t nn = (size_t)N * N;
     void *w;
-    APMF_TRY(apmf_ws(ctx, 3, (nn + 8) * sizeof(double) + ((size_t)N + 16) * sizeof(int) + 64, &w));
+    const size_t linv_off = ((nn + 8) * sizeof(double) + ((size_t)N + 16) * sizeof(int) + 15) / 16 * 16;
+    APMF_TRY(apmf_ws(ctx, 3, linv_off + CH_NB * CH_NB * sizeof(double) + 64, &w));
+    double *linv = (double *)((char *)w + linv_off);   // scratch of the blocked Cholesky
     double *LU = d_inv ? d_inv : (double *)w;
     double *scal = (double *)w + nn;
     int *info = (int *)(scal + 4);
@@ -444,7 +462,7 @@ int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_i
         hipLaunchKernelGGL(k_check_symmetric, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_mat, N, info + 1);
         APMF_CHECK_LAUNCH();
         APMF_CHECK_HIP(hipMemcpyAsync(LU, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        APMF_TRY(chol_lower(ctx, LU, N, info));
+        APMF_TRY(chol_lower(ctx, LU, N, info, linv));
         int hi[2];
         APMF_TRY(apmf_d2h(ctx, hi, info, sizeof(hi)));
         if (hi[0] == 0 && hi[1] == 0) {
