@@ -10,9 +10,9 @@ fitted - is supplied by the subclass.
 
 GPU note ("fork + HIP"): criteria are evaluated in the calling process -
 a HIP context does not survive fork().  Pool-scoring criteria are one batched kernel launch;
-the lookahead criteria (the ones the reference hands to its process pool) are mapped over a
-small pool of threads, each with its own Context: `procs` is the number of threads (default
-APMF_LOOKAHEAD_THREADS or 8; 0 or 1 = sequential), `worker_pool` is accepted and ignored.
+the lookahead criteria (the ones the reference hands to its process pool) are mapped
+sequentially by default, or over a pool of threads, each with its own Context, when `procs` > 1
+(or APMF_LOOKAHEAD_THREADS) asks for it; `worker_pool` is accepted and ignored.
 """
 import concurrent.futures
 import itertools
@@ -59,13 +59,16 @@ def strictmap(*args, **kwargs):
     return list(map(*args, **kwargs))
 
 
-# -- concurrent lookahead -------------------------------------------------------------------
+# -- concurrent lookahead (opt-in) ------------------------------------------------------------
 # The reference farms the lookahead criteria (spawn_processes = True) out to a forked process
 # pool.  A HIP context does not survive fork(), but every hypothesis (candidate, rating value)
-# is an independent deep copy whose re-fit is one long C-ABI call that releases the GIL, and a
-# single variational re-fit keeps only a few CUs busy: a small pool of THREADS, each with its
-# own Context (= own stream), overlaps them on the GPU.  Results are returned in input order
-# and are identical to the sequential ones.
+# is an independent deep copy whose re-fit is one long C-ABI call that releases the GIL, so the
+# map can run on a pool of THREADS, each with its own Context (= own stream).  Results come
+# back in input order and are bit-identical to the sequential ones (tested).  Measured on one
+# MI355X it does not pay: a re-fit is a chain of ~100 tiny launches per step and several host
+# threads mostly queue up behind the runtime, 27.5 s threaded vs 24.1 s sequential for 10
+# hypotheses at 94 x 425 - so the default is sequential; `procs` > 1 or
+# APMF_LOOKAHEAD_THREADS turns the pool on.
 _workers = None
 _worker_state = threading.local()
 
@@ -73,19 +76,18 @@ _worker_state = threading.local()
 def lookahead_threads(procs=None):
     if procs is not None and procs >= 0:
         return int(procs)
-    return int(os.environ.get('APMF_LOOKAHEAD_THREADS', '8'))
+    return int(os.environ.get('APMF_LOOKAHEAD_THREADS', '1'))
 
 
 def _parallel_map(fn, items, procs=None):
     """[fn(x) for x in items], concurrently when worthwhile; never nested."""
     global _workers
     items = list(items)
-    width = min(lookahead_threads(procs), len(items))
+    width = min(lookahead_threads(procs), len(items), 16)
     if width <= 1 or getattr(_worker_state, 'inside', False):
         return [fn(x) for x in items]
     if _workers is None:
-        _workers = concurrent.futures.ThreadPoolExecutor(max_workers=max(lookahead_threads(), 1),
-                                                         thread_name_prefix='apmf-lookahead')
+        _workers = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix='apmf-lookahead')
 
     def run(x):
         _worker_state.inside = True
@@ -449,7 +451,7 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             if not pool:
                 return []
             return list(np.asarray(getattr(self, impl)(pi, pj), dtype=np.float64))
-        if getattr(key, 'spawn_processes', False) and len(pool) > 1:
+        if getattr(key, 'spawn_processes', False) and len(pool) > 1 and lookahead_threads(procs) > 1:
             # one hypothesis chain per worker; each works on its own deep copy (the shared model's
             # device context belongs to the calling thread)
             return _parallel_map(lambda ij: key(deepcopy(self), ij), pool, procs)
