@@ -89,6 +89,7 @@ _DENSE_SIGS = {
     'apmf_dense_inv_logdet': (_i, [_vp, _vp, _i, _vp, C.POINTER(_dbl)]),
     'apmf_mn_kl_value': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, C.POINTER(_dbl)]),
     'apmf_mn_kl_gradient': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
+    'apmf_full_kl_gradient': (_i, [_vp, _vp, _i, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp]),
     'apmf_mn_fit_normal': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.POINTER(_dbl),
                                 C.POINTER(_dbl), _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
 }
@@ -439,6 +440,10 @@ class Context(object):
         _check(load_dense().apmf_mn_kl_gradient(self._h, rt._h, d, _ptr(mean), _ptr(cov_ui),
                                                 _ptr(cov_lat), sig, sig_u, sig_v, _ptr(g_mean),
                                                 _ptr(g_cov_ui), _ptr(g_cov_lat)))
+
+    def full_kl_gradient(self, rt, d, mean, cov, sig, sig_u, sig_v, g_mean, g_cov):
+        _check(load_dense().apmf_full_kl_gradient(self._h, rt._h, d, _ptr(mean), _ptr(cov), sig, sig_u, sig_v,
+                                                  _ptr(g_mean), _ptr(g_cov)))
 
     def mn_fit_normal(self, rt, d, mean, cov_ui, cov_lat, sig, sig_u, sig_v, min_eig, lr, old_kl=None,
                       max_steps=-1, max_trace=1 << 16):

@@ -445,6 +445,134 @@ __global__ __launch_bounds__(256) void k_trial_point(size_t count, const double 
     out[i] = __dsub_rn(x[i], __dmul_rn(lr, g[i]));
 }
 
+// ---- full-covariance variational fit: gradient of the KL w.r.t. (mean, cov) ----------------
+// normal_exps_cy.pyx:140-303 (ActivePMF.fit_normal).  The latent vector is stacked, u[k, i] =
+// i d + k, v[k, j] = n d + j d + k (active_pmf.py:141-142), so a rating (i, j) touches the
+// d x d blocks UU = cov[U_i, U_i], UV = cov[U_i, V_j], VV = cov[V_j, V_j].  One wave per user
+// row (SIDE 0) accumulates the mean gradient of U_i and the UU block over the user's ratings in
+// storage order and writes the per-rating UV / VU blocks; one wave per item row (SIDE 1) does
+// the same for V_j and VV.  No atomics.  The reference's arithmetic is kept, including the
+// summed increments of _cov_4exp_grad_clcl (:188-197) and of sum_tripexpect_ccl (:239-249)
+// that its own notebook flags as a bug.
+constexpr int FG_D = 32;   // largest latent_d of the full-covariance path (K = (n+m) d is the limit anyway)
+
+template <int SIDE>
+__global__ __launch_bounds__(64) void k_full_grad_rows(int n, int m, int d, const int64_t *__restrict__ ptr,
+                                                       const int32_t *__restrict__ idx,
+                                                       const double *__restrict__ val,
+                                                       const double *__restrict__ mean,
+                                                       const double *__restrict__ cov, double inv_sig,
+                                                       double *__restrict__ gmean, double *__restrict__ gcov)
+{
+    __shared__ double Cuu[FG_D][FG_D + 1], Cuv[FG_D][FG_D + 1], Cvv[FG_D][FG_D + 1], OWN[FG_D][FG_D + 1];
+    __shared__ double sa[FG_D], sb[FG_D], se[FG_D], s1[FG_D], s2[FG_D], sA[FG_D], sB[FG_D], sC[FG_D], sD[FG_D];
+    const int x = threadIdx.x;
+    const int row = blockIdx.x;
+    const size_t K = (size_t)(n + m) * d;
+    const int64_t beg = ptr[row], end = ptr[row + 1];
+    for (int e = x; e < d * d; e += 64) OWN[e / d][e % d] = 0.;
+    double gm = 0.;
+    for (int64_t t = beg; t < end; t++) {
+        const int i = SIDE == 0 ? row : idx[t], j = SIDE == 0 ? idx[t] : row;
+        const double r = val[t];
+        const size_t ub = (size_t)i * d, vb = (size_t)n * d + (size_t)j * d;
+        __syncthreads();
+        if (x < d) { sa[x] = mean[ub + x]; sb[x] = mean[vb + x]; }
+        for (int e = x; e < d * d; e += 64) {
+            const int p = e / d, q = e % d;
+            Cuu[p][q] = cov[(ub + p) * K + ub + q];
+            Cuv[p][q] = cov[(ub + p) * K + vb + q];
+            Cvv[p][q] = cov[(vb + p) * K + vb + q];
+        }
+        __syncthreads();
+        double a = 0, b = 0, pxy = 0, cuv = 0, cuu = 0, cvv = 0, e_x = 0;
+        if (x < d) {
+            a = sa[x]; b = sb[x]; pxy = a * b; cuv = Cuv[x][x]; cuu = Cuu[x][x]; cvv = Cvv[x][x];
+            e_x = pxy + cuv;
+            se[x] = e_x;
+        }
+        __syncthreads();
+        double gmu = 0.;
+        if (x < d) {
+            double Kx = 0., S1 = 0., S2 = 0., Svv = 0., Suu = 0., Svu = 0., Suv = 0.;
+            for (int y = x + 1; y < d; y++) {
+                const double ay = sa[y], by = sb[y], ey = se[y];
+                if (SIDE == 0) Kx += b * ey + ay * Cvv[x][y] + by * Cuv[y][x];
+                else Kx += a * ey + ay * Cuv[x][y] + by * Cuu[x][y];
+                S1 += pxy * by + a * Cvv[x][y] + b * Cuv[x][y] + by * cuv;
+                S2 += pxy * ay + a * Cuv[y][x] + b * Cuu[x][y] + ay * cuv;
+                Svv += b * by + Cvv[x][y];
+                Suu += a * ay + Cuu[x][y];
+                Svu += b * ay + Cuv[y][x];
+                Suv += a * by + Cuv[x][y];
+            }
+            s1[x] = S1; s2[x] = S2; sA[x] = Svv; sB[x] = Suu; sC[x] = Svu; sD[x] = Suv;
+            gmu = Kx;
+        }
+        __syncthreads();
+        if (x < d) {
+            double L = 0.;
+            for (int k = 0; k < x; k++) L += SIDE == 0 ? s1[k] : s2[k];
+            if (SIDE == 0) gmu += L + 2. * b * cuv + a * (b * b + cvv) - b * r;
+            else gmu += L + 2. * a * cuv + b * (a * a + cuu) - a * r;
+            gm += gmu;
+        }
+        // the own diagonal block (UU for users, VV for items), accumulated over the ratings
+        for (int e = x; e < d * d; e += 64) {
+            const int p = e / d, q = e % d;
+            const double *S = SIDE == 0 ? sA : sB;
+            double v;
+            if (p < q) v = S[p];
+            else if (p > q) v = S[q];
+            else v = SIDE == 0 ? (sb[p] * sb[p] + Cvv[p][p]) / 2. : (sa[p] * sa[p] + Cuu[p][p]) / 2.;
+            OWN[p][q] += v;
+        }
+        if (SIDE == 0) {
+            // the cross blocks of this rating are touched by no other rating
+            double esum = 0.;
+            for (int y = 0; y < d; y++) esum += se[y];
+            for (int e = x; e < d * d; e += 64) {
+                const int p = e / d, q = e % d;
+                double uv, vu;
+                if (q > p) { uv = sC[p]; vu = sD[p]; }
+                else if (q < p) { uv = sD[q]; vu = sC[q]; }
+                else uv = vu = (esum - se[p]) + 2. * se[p] - r;
+                gcov[(ub + p) * K + vb + q] += inv_sig * uv;
+                gcov[(vb + p) * K + ub + q] += inv_sig * vu;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t ob = SIDE == 0 ? (size_t)row * d : (size_t)n * d + (size_t)row * d;
+    if (x < d) gmean[ob + x] += inv_sig * gm;
+    for (int e = x; e < d * d; e += 64) {
+        const int p = e / d, q = e % d;
+        gcov[(ob + p) * K + ob + q] += inv_sig * OWN[p][q];
+    }
+}
+
+// g_cov <- -(inv + inv' (1 - I)) / 2 (inv symmetric: -inv off the diagonal, -inv/2 on it), plus the
+// prior terms on the diagonal; g_mean <- mean / prior   (normal_exps_cy.pyx:286-303)
+__global__ __launch_bounds__(256) void k_full_grad_init(size_t K, size_t nd, double sig_u, double sig_v,
+                                                        const double *__restrict__ mean,
+                                                        double *__restrict__ gmean, double *__restrict__ gcov)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= K * K) return;
+    const size_t i = t / K, j = t % K;
+    const double inv = gcov[t], invt = gcov[j * K + i];
+    if (i == j) {
+        const double prior = i < nd ? sig_u : sig_v;
+        gcov[t] = -inv / 2. + 1. / (2. * prior);
+        gmean[i] = mean[i] / prior;
+    } else if (i < j) {
+        const double v = -(inv + invt) / 2.;
+        // both halves are written by the thread of the upper one: no read-after-write hazard
+        gcov[t] = v;
+        gcov[j * K + i] = -(invt + inv) / 2.;
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -590,6 +718,28 @@ int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_me
     *h_steps = steps;
     *h_converged = converged ? 1 : 0;
     return rc;
+}
+
+int apmf_full_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                          const double *d_cov, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                          double *d_g_mean, double *d_g_cov)
+{
+    APMF_REQUIRE(ctx && r && d_mean && d_cov && d_g_mean && d_g_cov, "NULL operand");
+    APMF_REQUIRE(d >= 1 && d <= FG_D, "latent_d=%d unsupported by the full-covariance gradient (1..%d)", d, FG_D);
+    APMF_REQUIRE(sigma_sq != 0. && sigma_u_sq != 0. && sigma_v_sq != 0., "zero variance");
+    const size_t K = ((size_t)r->n + r->m) * d;
+    APMF_REQUIRE(K <= 46000, "(n+m) d = %zu is too large for a dense covariance", K);
+    // entropy term: the inverse lands in g_cov and is rewritten in place
+    APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov, (int)K, d_g_cov, nullptr));
+    hipLaunchKernelGGL(k_full_grad_init, dim3((unsigned)((K * K + 255) / 256)), dim3(256), 0, ctx->stream, K,
+                       (size_t)r->n * d, sigma_u_sq, sigma_v_sq, d_mean, d_g_mean, d_g_cov);
+    const double inv_sig = 1. / sigma_sq;
+    hipLaunchKernelGGL((k_full_grad_rows<0>), dim3(r->n), dim3(64), 0, ctx->stream, r->n, r->m, d, r->ptr[0],
+                       r->idx[0], r->val[0], d_mean, d_cov, inv_sig, d_g_mean, d_g_cov);
+    hipLaunchKernelGGL((k_full_grad_rows<1>), dim3(r->m), dim3(64), 0, ctx->stream, r->n, r->m, d, r->ptr[1],
+                       r->idx[1], r->val[1], d_mean, d_cov, inv_sig, d_g_mean, d_g_cov);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
 }
 
 } // extern "C"

@@ -4,11 +4,11 @@ gradient used by ActivePMF.fit_normal.
 
 The scalar moment functions are one-candidate conveniences; pools and grids of candidates
 are scored by the HIP kernel behind ActivePMF (K2-full, csrc/k2_full.hip).
-normal_gradient is the variational-fit gradient ("next"): restated here per
-rating on the local 2d x 2d block of the covariance and batched over the ratings on the
-host.  It reproduces the reference's arithmetic, including the summed increment of
-`_cov_4exp_grad_clcl` (normal_exps_cy.pyx:188-197) that the reference's own notebook flags
-as "has to be a bug" - parity is with the code, not with the maths.
+normal_gradient is the variational-fit gradient: a HIP kernel over the
+d x d blocks of the covariance each rating touches (csrc/k5_klgrad.hip).  It reproduces the
+reference's arithmetic, including the summed increment of `_cov_4exp_grad_clcl`
+(normal_exps_cy.pyx:188-197) that the reference's own notebook flags as "has to be a bug" -
+parity is with the code, not with the maths.
 """
 import numpy as np
 
@@ -60,84 +60,31 @@ def normal_gradient(apmf):
     '''Gradient of the KL w.r.t. (mean, cov) of an ActivePMF (normal_exps_cy.pyx:140-168).'''
     if apmf is None or apmf.mean is None or apmf.cov is None:
         raise TypeError("mean, cov are None; run initialize_approx first")
+    rt = apmf._device_ratings()[1] if hasattr(apmf, '_device_ratings') else None
     return _normal_grad(apmf.mean, apmf.cov, apmf.ratings, apmf.latent_d, apmf.u, apmf.v,
-                        apmf.sigma_sq, apmf.sigma_u_sq, apmf.sigma_v_sq)
+                        apmf.sigma_sq, apmf.sigma_u_sq, apmf.sigma_v_sq, _device_ratings=rt)
 
 
-def _normal_grad(mean, cov, ratings, d, u, v, sig, sig_u, sig_v):
-    """normal_exps_cy.pyx:217-303 on the (N, 2d, 2d) stack of local covariance blocks: for the
-    rating (i, j) the only entries touched are those of [u_0..u_{d-1}, v_0..v_{d-1}]."""
-    N = ratings.shape[0]
-    grad_mean = np.zeros_like(mean)
-    grad_cov = np.zeros_like(cov)
-    ii = ratings[:, 0].astype(np.intp)
-    jj = ratings[:, 1].astype(np.intp)
-    r = ratings[:, 2]
-    idx = np.concatenate([u[:, ii].T, v[:, jj].T], axis=1)           # (N, 2d)
-    mu = mean[idx]
-    blk = cov[idx[:, :, None], idx[:, None, :]]                        # (N, 2d, 2d)
-    a, b = mu[:, :d], mu[:, d:]
-    Cuu, Cuv, Cvv = blk[:, :d, :d], blk[:, :d, d:], blk[:, d:, d:]
-    cuu = np.einsum('tkk->tk', Cuu)
-    cvv = np.einsum('tkk->tk', Cvv)
-    cuv = np.einsum('tkk->tk', Cuv)
-    p = a * b
-    e = p + cuv                                                        # E[U_k V_k]
-    Eo = e.sum(1, keepdims=True) - e                                   # sum over y != x
-    off = 1. - np.eye(d)
-    up = np.triu(np.ones((d, d)), 1)                                   # [k, l] = 1 for l > k
-
-    g_mu = np.empty_like(mu)
-    # pairs k < l (normal_exps_cy.pyx:239-249).  The k-side entries get their own sums over l;
-    # the l-side entries all receive the SAME scalar - sum_tripexpect_ccl() sums over l before
-    # `grad_mean[uli] += ...` broadcasts it - so u_x / v_x collect sum_{k < x} S(k).
-    bx, ax = b[:, :, None], a[:, :, None]
-    by, ay = b[:, None, :], a[:, None, :]
-    ey = e[:, None, :]
-    Ku = ((bx * ey + ay * Cvv + by * np.swapaxes(Cuv, 1, 2)) * up).sum(2)
-    Kv = ((ax * ey + ay * Cuv + by * Cuu) * up).sum(2)
-    S1 = ((p[:, :, None] * by + ax * Cvv + bx * Cuv + by * cuv[:, :, None]) * up).sum(2)
-    S2 = ((p[:, :, None] * ay + ax * np.swapaxes(Cuv, 1, 2) + bx * Cuu + ay * cuv[:, :, None]) * up).sum(2)
-    Lu = np.cumsum(S1, axis=1) - S1          # sum over k < x
-    Lv = np.cumsum(S2, axis=1) - S2
-    g_mu[:, :d] = Ku + Lu
-    g_mu[:, d:] = Kv + Lv
-    # squares and the linear term (:266-280)
-    g_mu[:, :d] += 2 * b * cuv + a * (b * b + cvv) - b * r[:, None]
-    g_mu[:, d:] += 2 * a * cuv + b * (a * a + cuu) - a * r[:, None]
-
-    g_blk = np.zeros_like(blk)
-    UU, UV, VU, VV = g_blk[:, :d, :d], g_blk[:, :d, d:], g_blk[:, d:, :d], g_blk[:, d:, d:]
-    # the summed increments of _cov_4exp_grad_clcl (:251-256), one scalar per k
-    S_vv = ((b[:, :, None] * b[:, None, :] + Cvv) * up).sum(2)
-    S_uu = ((a[:, :, None] * a[:, None, :] + Cuu) * up).sum(2)
-    S_vu = ((b[:, :, None] * a[:, None, :] + np.swapaxes(Cuv, 1, 2)) * up).sum(2)
-    S_uv = ((a[:, :, None] * b[:, None, :] + Cuv) * up).sum(2)
-    t_vv, t_uu = S_vv[:, :, None] * up, S_uu[:, :, None] * up
-    t_vu, t_uv = S_vu[:, :, None] * up, S_uv[:, :, None] * up
-    UU += t_vv + np.swapaxes(t_vv, 1, 2)
-    VV += t_uu + np.swapaxes(t_uu, 1, 2)
-    UV += t_vu + np.swapaxes(t_uv, 1, 2)
-    VU += np.swapaxes(t_vu, 1, 2) + t_uv
-    dk = np.arange(d)
-    UV[:, dk, dk] += Eo + 2 * e - r[:, None]
-    VU[:, dk, dk] += Eo + 2 * e - r[:, None]
-    UU[:, dk, dk] += (b * b + cvv) / 2
-    VV[:, dk, dk] += (a * a + cuu) / 2
-
-    np.add.at(grad_mean, idx, g_mu / sig)
-    np.add.at(grad_cov, (idx[:, :, None], idx[:, None, :]), g_blk / sig)
-
-    # priors (:286-291) and the entropy term (:302-303)
-    us, vs = u.reshape(-1), v.reshape(-1)
-    grad_mean[us] += mean[us] / sig_u
-    grad_mean[vs] += mean[vs] / sig_v
-    grad_cov[us, us] += 1 / (2 * sig_u)
-    grad_cov[vs, vs] += 1 / (2 * sig_v)
+def _normal_grad(mean, cov, ratings, d, u, v, sig, sig_u, sig_v, _device_ratings=None):
+    """normal_exps_cy.pyx:217-303 on the device (K5-full, csrc/k5_klgrad.hip: one wave per user /
+    item row over the d x d blocks of the covariance a rating touches; the entropy term's inverse
+    by Cholesky / LU in libapmf_dense.so).  u, v are the index maps of ActivePMF
+    (u[k, i] = i d + k, v[k, j] = n d + j d + k), which the kernel assumes."""
     try:
-        from .matrix_normal_exps_cy import inverse
+        from . import _lib
     except ImportError:
-        from matrix_normal_exps_cy import inverse
-    inv = inverse(cov)     # (n+m)d x (n+m)d, on the device
-    grad_cov -= (inv + inv.T * (1 - np.eye(cov.shape[0]))) / 2
-    return grad_mean, grad_cov
+        import _lib
+    n, m = u.shape[1], v.shape[1]
+    if not (np.array_equal(u, np.arange(n * d).reshape(n, d).T) and
+            np.array_equal(v, n * d + np.arange(m * d).reshape(m, d).T)):
+        raise ValueError("u / v are not the stacked index maps of ActivePMF")
+    ctx = _lib.default_context()
+    rt = _device_ratings or ctx.ratings(np.ascontiguousarray(ratings, np.float64), n, m)
+    K = (n + m) * d
+    g_mean, g_cov = ctx.empty(K), ctx.empty((K, K))
+    ctx.full_kl_gradient(rt, d, ctx.array(mean, np.float64), ctx.array(cov, np.float64), float(sig),
+                         float(sig_u), float(sig_v), g_mean, g_cov)
+    out = g_mean.to_host(), g_cov.to_host()
+    if _device_ratings is None:
+        rt.free()
+    return out

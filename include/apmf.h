@@ -272,6 +272,14 @@ int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_me
                        double *h_old_kl, int64_t max_steps, double *h_kl_trace, int64_t trace_cap,
                        int64_t *h_steps, int *h_converged);
 
+/* normal_gradient() / _normal_grad(), normal_exps_cy.pyx:140-303: gradient of the KL of the
+ * full-covariance approximation (ActivePMF.fit_normal) w.r.t. mean (K) and cov (K x K),
+ * K = (n+m) d, stacked as u[k,i] = i d + k, v[k,j] = n d + j d + k (active_pmf.py:141-142).
+ * The reference's arithmetic is kept, summed increments included.  latent_d <= 32. */
+int apmf_full_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                          const double *d_cov, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                          double *d_g_mean, double *d_g_cov);
+
 #ifdef __cplusplus
 }
 #endif

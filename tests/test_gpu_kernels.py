@@ -736,3 +736,26 @@ def test_config5_shard_scale(ctx):
     spec.loader.exec_module(mod)
     out, ok = mod.run(n=12500, m=20000, d=64, N=6250000, ctx=ctx)
     assert ok, out
+
+
+@pytest.mark.parametrize('shape', [(4, 3, 1, 5), (6, 5, 3, 12), (9, 14, 5, 40), (7, 6, 8, 20), (5, 4, 17, 9)])
+def test_full_kl_gradient_vs_numpy(ctx, shape):
+    """K5-full (apmf_full_kl_gradient) against the NumPy restatement of normal_exps_cy.pyx:217-303
+    (tests/full_grad_numpy.py), rows without ratings included."""
+    from full_grad_numpy import normal_grad_numpy
+    n, m, d, N = shape
+    rs = np.random.RandomState(n * 100 + m * 10 + d)
+    flat = rs.choice(n * m, N, replace=False)
+    ratings = np.c_[flat // m, flat % m, rs.randint(1, 6, N)].astype(float)
+    K = (n + m) * d
+    mean = rs.normal(size=K)
+    a = rs.normal(size=(K, K)) / np.sqrt(K)
+    cov = a @ a.T + .3 * np.eye(K)
+    u = np.arange(n * d).reshape(n, d).T
+    v = n * d + np.arange(m * d).reshape(m, d).T
+    rt = ctx.ratings(ratings, n, m)
+    gm, gc = ctx.empty(K), ctx.empty((K, K))
+    ctx.full_kl_gradient(rt, d, ctx.array(mean), ctx.array(cov), 0.7, 9., 11., gm, gc)
+    rm, rc = normal_grad_numpy(mean, cov, ratings, d, u, v, 0.7, 9., 11.)
+    np.testing.assert_allclose(gm.to_host(), rm, rtol=1e-10, atol=1e-10 * np.abs(rm).max())
+    np.testing.assert_allclose(gc.to_host(), rc, rtol=1e-10, atol=1e-10 * np.abs(rc).max())
