@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# Every device block and workspace handed out during the tests is first filled with 0xFF bytes
+# (NaN as float / double, -1 as int): a kernel that reads memory it was supposed to have written
+# itself fails the parity checks instead of passing on whatever happened to be there.  The library
+# reads the switch once, at its first allocation.
+os.environ.setdefault('APMF_POISON', '1')
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
