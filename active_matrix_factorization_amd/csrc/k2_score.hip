@@ -1099,17 +1099,24 @@ __global__ __launch_bounds__(256) void k_collect_near(int n, int m, int ld, cons
                                                       int32_t *__restrict__ pj, int cap,
                                                       int *__restrict__ count)
 {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)n * ld, stride = (int64_t)gridDim.x * blockDim.x;
-    for (; t < total; t += stride) {
-        const int i = (int)(t / ld), j = (int)(t % ld);
-        if (j >= m) continue;
-        if (mask && !mask[t]) continue;
-        const float v = var[t];
-        const bool near = want > 0 ? (v >= best - tol) : (v <= best + tol);
-        if (near) {
-            int slot = atomicAdd(count, 1);
-            if (slot < cap) { pi[slot] = i; pj[slot] = j; }
+    // rows over blocks, 4 adjacent columns per thread (16-byte score load, 4-byte mask load);
+    // near-ties are rare, so the atomic append is off the common path
+    const float lo = best - tol, hi = best + tol;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const float *vrow = var + (size_t)i * ld;
+        const uint8_t *mrow = mask ? mask + (size_t)i * ld : nullptr;
+        for (int j = threadIdx.x * 4; j < ld; j += 1024) {
+            const float4 v4 = *reinterpret_cast<const float4 *>(vrow + j);
+            const unsigned mk = mrow ? *reinterpret_cast<const unsigned *>(mrow + j) : 0x01010101u;
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const bool near = want > 0 ? v[c] >= lo : v[c] <= hi;
+                if (near && j + c < m && ((mk >> (8 * c)) & 0xFFu)) {
+                    const int slot = atomicAdd(count, 1);
+                    if (slot < cap) { pi[slot] = i; pj[slot] = j + c; }
+                }
+            }
         }
     }
 }
@@ -1207,13 +1214,14 @@ int apmf_grid_collect_near_f32(apmf_ctx *ctx, int n, int m, int ld, const float 
     APMF_REQUIRE(ctx && d_var && d_pi && d_pj && h_count, "NULL operand");
     APMF_REQUIRE(want == 1 || want == -1, "want must be +1 or -1");
     APMF_REQUIRE(n >= 1 && m >= 1 && ld >= m && cap >= 1, "bad shape");
+    APMF_REQUIRE(ld % 4 == 0 && ((uintptr_t)d_var % 16) == 0 && (!d_mask || ((uintptr_t)d_mask % 4) == 0),
+                 "grid pitch must be a multiple of 4 and the grids 16-byte (mask: 4-byte) aligned");
     void *w;
     APMF_TRY(apmf_ws(ctx, 2, 64, &w));
     int *d_count = (int *)w;
     APMF_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
     const float tol = rel_tol * (best < 0 ? -best : best);
-    int64_t total = (int64_t)n * ld;
-    int blocks = (int)(cdiv64(total, 256) < 2048 ? cdiv64(total, 256) : 2048);
+    const int blocks = n < 8192 ? n : 8192;
     hipLaunchKernelGGL(k_collect_near, dim3(blocks), dim3(256), 0, ctx->stream, n, m, ld, d_var, d_mask,
                        want, best, tol, d_pi, d_pj, cap, d_count);
     APMF_CHECK_LAUNCH();
