@@ -10,9 +10,9 @@ fitted - is supplied by the subclass.
 
 GPU note ("fork + HIP"): criteria are evaluated in the calling process -
 a HIP context does not survive fork().  Pool-scoring criteria are one batched kernel launch;
-the lookahead criteria (the ones the reference hands to its process pool) are mapped
-sequentially by default, or over a pool of threads, each with its own Context, when `procs` > 1
-(or APMF_LOOKAHEAD_THREADS) asks for it; `worker_pool` is accepted and ignored.
+the lookahead criteria (the ones the reference hands to its process pool) are mapped over a
+small pool of threads, each with its own Context: `procs` is the number of threads (default
+APMF_LOOKAHEAD_THREADS or 4; 0 or 1 = sequential), `worker_pool` is accepted and ignored.
 """
 import concurrent.futures
 import itertools
@@ -59,16 +59,18 @@ def strictmap(*args, **kwargs):
     return list(map(*args, **kwargs))
 
 
-# -- concurrent lookahead (opt-in) ------------------------------------------------------------
+# -- concurrent lookahead ---------------------------------------------------------------------
 # The reference farms the lookahead criteria (spawn_processes = True) out to a forked process
 # pool.  A HIP context does not survive fork(), but every hypothesis (candidate, rating value)
-# is an independent deep copy whose re-fit is one long C-ABI call that releases the GIL, so the
-# map can run on a pool of THREADS, each with its own Context (= own stream).  Results come
-# back in input order and are bit-identical to the sequential ones (tested).  Measured on one
-# MI355X it does not pay: a re-fit is a chain of ~100 tiny launches per step and several host
-# threads mostly queue up behind the runtime, 27.5 s threaded vs 24.1 s sequential for 10
-# hypotheses at 94 x 425 - so the default is sequential; `procs` > 1 or
-# APMF_LOOKAHEAD_THREADS turns the pool on.
+# is an independent deep copy whose re-fit is one long C-ABI call that releases the GIL, and a
+# single re-fit is a latency-bound chain of small launches that keeps only a few CUs busy: the
+# map runs on a small pool of THREADS, each with its own Context (= own stream, workspaces,
+# rocBLAS handle).  Results come back in input order and are bit-identical to the sequential
+# ones (tested; it is why the Cholesky factorisation is our own).  Measured on one MI355X, 20
+# hypotheses at 94 x 425 (tools/probe_lookahead_threads.py): 83.8 s sequential, 49.9 s with 4
+# threads (separate processes would overlap better - 3.7x at 4 - but a pool of spawned
+# processes costs a HIP context each).  `procs` / APMF_LOOKAHEAD_THREADS set the width
+# (default 4; 0 or 1 = sequential).
 _workers = None
 _worker_state = threading.local()
 
@@ -76,7 +78,10 @@ _worker_state = threading.local()
 def lookahead_threads(procs=None):
     if procs is not None and procs >= 0:
         return int(procs)
-    return int(os.environ.get('APMF_LOOKAHEAD_THREADS', '1'))
+    override = getattr(_worker_state, 'width', None)      # a `procs` given further up the call chain
+    if override is not None:
+        return override
+    return int(os.environ.get('APMF_LOOKAHEAD_THREADS', '4'))
 
 
 def _parallel_map(fn, items, procs=None):
@@ -455,7 +460,15 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             # one hypothesis chain per worker; each works on its own deep copy (the shared model's
             # device context belongs to the calling thread)
             return _parallel_map(lambda ij: key(deepcopy(self), ij), pool, procs)
-        return [key(self, ij) for ij in pool]
+        # one candidate (or `procs` <= 1): the map over the rating values inside the criterion is
+        # what runs concurrently, with the same width
+        previous = getattr(_worker_state, 'width', None)
+        if procs is not None and procs >= 0:
+            _worker_state.width = int(procs)
+        try:
+            return [key(self, ij) for ij in pool]
+        finally:
+            _worker_state.width = previous
 
     def get_key_evals(self, pool=None, key=None, procs=None, worker_pool=None):
         '''(n, m) matrix holding key's value at every element of pool, NaN elsewhere.'''

@@ -90,7 +90,7 @@ def main():
     # each with a variational refit and a full-grid total-variance sweep)
     pool = sorted(apmf.unrated)[:2]
     key = mn.KEY_FUNCS['total-variance']
-    for label, procs in (('sequential', None), ('threads', 4)):
+    for label, procs in (('threads4', None), ('sequential', 1)):
         t = time.perf_counter()
         with redirect_stdout(log):
             vals = apmf._get_key_vals(pool, key, procs=procs)
