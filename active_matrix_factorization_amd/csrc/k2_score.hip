@@ -12,11 +12,15 @@
 // per-row / per-column vectors.  The sweep is HBM-bound: 4 B read + 4 B written per
 // candidate in f32 (8 + 8 in f64).
 //
-// Kernel layout (wave64): a block is 4 waves that share a chunk of 64*VEC columns; each
-// lane keeps its VEC columns' b_j (D x VEC registers), q_j, s_jj for the whole block.  A
-// wave walks its own rows: per row the wave-uniform operands (Oa_i, a_i, a'Oa, s_ii) come in
-// through scalar loads, the s_ij row segment through one coalesced 16-byte load per lane,
-// and the scores leave through one 16-byte store per lane.  No LDS is needed.
+// Two float32/float64 kernels share the packs written by k_mn_prep:
+//  * k_mn_grid (rank <= 12, and every float64 sweep): a block is 4 waves that share a chunk of
+//    64*VEC columns; each lane keeps its VEC columns' b_j (D x VEC registers), q_j, s_jj for the
+//    whole block.  A wave walks its own 16 rows: the wave-uniform row operands (Oa_i, a_i,
+//    a'Oa, s_ii) are fetched once with coalesced loads and broadcast from registers
+//    (v_readlane), the s_ij row segment comes through one 16-byte nontemporal load per lane
+//    and the scores leave through one 16-byte nontemporal store per lane.  No LDS.
+//  * k_mn_grid_mfma (float32, rank >= 13, and reduction-only sweeps at any rank): the rank-d
+//    term on the matrix cores; see the comment above that kernel.
 #include "common.h"
 
 namespace {
