@@ -67,9 +67,11 @@ def strictmap(*args, **kwargs):
 # map runs on a small pool of THREADS, each with its own Context (= own stream, workspaces,
 # rocBLAS handle).  Results come back in input order and are bit-identical to the sequential
 # ones (tested; it is why the Cholesky factorisation is our own).  Measured on one MI355X, 20
-# hypotheses at 94 x 425 (tools/probe_lookahead_threads.py): 83.8 s sequential, 49.9 s with 4
-# threads (separate processes would overlap better - 3.7x at 4 - but a pool of spawned
-# processes costs a HIP context each).  `procs` / APMF_LOOKAHEAD_THREADS set the width
+# hypotheses at 94 x 425 (tools/probe_lookahead_threads.py): 85.8 s sequential, 31.5 s with 4
+# threads - provided the runtime has a hardware queue per stream (_lib.load sets
+# GPU_MAX_HW_QUEUES=8; with the default 4 two worker streams share a queue and it is 49.9 s).
+# More than 4 threads do not help (tools/probe_scaling.py).  `procs` / APMF_LOOKAHEAD_THREADS
+# set the width
 # (default 4; 0 or 1 = sequential).
 _workers = None
 _worker_state = threading.local()

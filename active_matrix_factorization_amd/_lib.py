@@ -123,6 +123,13 @@ def load():
                 raise ApmfError(ENODEV, 'HIP extension %s is not built (run `python -c "import '
                                 '__graft_entry__ as g; g.build()"` or `make -C %s/csrc`); there '
                                 'is no CPU fallback' % (LIB_PATH, _HERE))
+            # The lookahead criteria drive one stream per worker thread (4 by default).  With the HIP
+            # runtime's default of 4 hardware queues two of those streams end up sharing a queue and
+            # 4 threads run no faster than 2 (3.6 fits/s); with 8 queues they overlap like separate
+            # processes do (6.5 fits/s, tools/probe_scaling.py).  Read by the runtime when it
+            # initialises, so it only takes effect if nothing has touched HIP yet; never overrides
+            # a value the user set.
+            os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
             lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)   # libapmf_dense.so resolves apmf_ws etc. here
             for name, (res, args) in _SIGS.items():
                 fn = getattr(lib, name)

@@ -34,7 +34,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
 
 me = os.path.abspath(__file__)
 K = 6
-for P in (1, 2, 4):
+for P in (() if os.environ.get('THREADS_ONLY') else (1, 2, 4)):
     t = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, me, 'child', str(K)], stdout=subprocess.PIPE, text=True) for _ in range(P)]
     inner = [float(p.communicate()[0].strip()) for p in procs]
@@ -42,7 +42,7 @@ for P in (1, 2, 4):
           % (P, K, max(inner), time.perf_counter() - t, P * K / max(inner)), flush=True)
 args = setup()
 fits(*args, 1)
-for P in (1, 2, 4, 8):
+for P in (1, 4, 6, 8):
     ths = [threading.Thread(target=fits, args=args + (K,)) for _ in range(P)]
     t = time.perf_counter()
     [x.start() for x in ths]; [x.join() for x in ths]
