@@ -603,9 +603,14 @@ def run_compare(cls, key_funcs, key_names, real, ratings, rating_vals, latent_d,
         '_rating_vals': rating_vals,
         '_initial_apmf': deepcopy(apmf),
     }
-    # The reference runs one thread per key over a forked process pool; with the criteria
-    # on the GPU the keys are simply run one after the other in this process.
-    for key_name in key_names:
+    # The reference runs one thread per key (sharing a forked process pool for the lookahead
+    # keys) when do_threading is set, and the keys one after the other otherwise
+    # (mn_active_pmf.py:968-1001).  Same here: with do_threading each key's query loop runs on
+    # its own thread = its own Context / stream, up to APMF_LOOKAHEAD_THREADS at a time, and the
+    # lookahead map inside a key then stays sequential (the streams are already taken).  As in
+    # the reference, keys that draw from the global RNGs ('random') are not reproducible run to
+    # run in that mode.
+    def run_key(key_name):
         key = key_funcs[key_name]
         if do_threading:
             res = query_loop(deepcopy(apmf), real, key, key.do_normal_fit, fit_sigmas,
@@ -614,5 +619,12 @@ def run_compare(cls, key_funcs, key_names, real, ratings, rating_vals, latent_d,
             res = query_loop(deepcopy(apmf), real, key, key.do_normal_fit, fit_sigmas,
                              test_on=test_on, with_pred=with_pred, initial_fit=True,
                              refit_with_lls=True)
-        results[key_name] = list(itertools.islice(res, steps))
+        return list(itertools.islice(res, steps))
+
+    if do_threading and len(key_names) > 1 and lookahead_threads() > 1:
+        for key_name, res in zip(key_names, _parallel_map(run_key, key_names)):
+            results[key_name] = res
+    else:
+        for key_name in key_names:
+            results[key_name] = run_key(key_name)
     return results

@@ -535,3 +535,19 @@ def test_lookahead_threads_equal_sequential(pkg):
     # a single candidate: the rating values are what is mapped
     one = a.exp_total_variance(pool[2])
     assert one == seq[2]
+
+
+def test_compare_threaded_keys_equal_single_key_runs(pkg):
+    """compare(..., do_threading=True) runs one query loop per key on its own thread (own Context),
+    like the reference's thread per key: for keys that draw no random numbers the result is what
+    each key gives when run alone."""
+    g = load_golden('trace_c1_mn')
+    keys = ['pred-variance', 'pred', 'prob-ge-3.5']
+    kw = dict(rating_vals=(1, 2, 3, 4, 5), latent_d=2, do_threading=True, steps=3)
+    seed(7)
+    together = pkg.mn.compare(keys, g['real'], g['ratings'], **kw)
+    for key in keys:
+        seed(7)
+        alone = pkg.mn.compare([key], g['real'], g['ratings'], **kw)
+        assert [s[2] for s in together[key]] == [s[2] for s in alone[key]]          # picks
+        assert [s[1] for s in together[key]] == [s[1] for s in alone[key]]          # RMSEs
