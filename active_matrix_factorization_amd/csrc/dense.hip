@@ -213,8 +213,8 @@ __global__ __launch_bounds__(64) void k_small_spd(const double *__restrict__ A, 
 // running): the same input gave last-place different factors, and the accept / reject
 // searches built on it amplify that into different trajectories.  This one is a plain
 // right-looking blocked factorisation with fixed summation orders and no atomics:
-//   per panel of CH_NB columns: factor the diagonal block (one wave, LDS), solve the rows
-//   below it against that block (one thread per row), update the trailing lower triangle
+//   per panel of CH_NB columns: factor the diagonal block and invert it (one wave, everything
+//   in registers), multiply the rows below it by that inverse (64 x 64 x 64 products in LDS), update the trailing lower triangle
 //   (64 x 64 tiles, the panel staged through LDS).
 // A is row-major; only its lower triangle (i >= j) is read, and L overwrites it.
 constexpr int CH_NB = 64;
@@ -229,8 +229,10 @@ __device__ __forceinline__ double lane_value(double v, int src)
 }
 
 // Diagonal block k..k+nb, one wave, everything in registers: lane t holds row t of the block
-// (64 doubles) and other lanes' entries arrive by v_readlane - the LDS version of this kernel
-// spent 113 us per block waiting on dependent LDS round trips, this one ~20.  Writes L_kk in
+// (64 doubles) and other lanes' entries arrive by v_readlane: 55 us per block.  The LDS
+// formulations were slower: one wave walking its rows serially 113 us (dependent LDS round
+// trips; rocSOLVER's potf2_kernel_small is of this kind, 135 us), four waves sharing the
+// trailing update 87 us (320 block barriers).  Writes L_kk in
 // place and L_kk^-1 (64 x 64, row-major, zero above the diagonal) to `linv` for the panel
 // solve.  A short last block is padded with the identity.  *info = k + j + 1 at the first
 // non-positive pivot.
@@ -273,31 +275,44 @@ __global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ A, int N,
     for (int i = 0; i < CH_NB; i++) linv[i * CH_NB + t] = x[i];
 }
 
-// rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T = (row) x (L_kk^-1)'  (one thread per row;
-// the 64 products per row are independent sums, unlike a forward substitution)
-__global__ __launch_bounds__(64) void k_chol_panel(double *__restrict__ A, int N, int k, const int *__restrict__ info,
+// rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T = (rows) x (L_kk^-1)': a 64 x 64 x 64 product
+// per block of 64 rows, 4 x 4 outputs per thread, both operands in LDS (rows / columns dealt to the
+// threads with stride 16 so that neither operand read conflicts)
+__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int N, int k, const int *__restrict__ info,
                                                    const double *__restrict__ linv)
 {
-    __shared__ double X[CH_NB][CH_NB + 1];
-    const int t = threadIdx.x;
+    __shared__ double P[CH_NB][CH_NB + 1], X[CH_NB][CH_NB + 1];
+    const int tid = threadIdx.x;
     const int nb = min(CH_NB, N - k);
     if (*info != 0) return;
-    for (int e = t; e < CH_NB * CH_NB; e += 64) X[e / CH_NB][e % CH_NB] = linv[e];
+    const int r0 = k + nb + blockIdx.x * 64;
+    const int rows = min(64, N - r0);
+    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+        const int i = e / CH_NB, j = e % CH_NB;
+        X[i][j] = linv[e];
+        P[i][j] = (i < rows && j < nb) ? A[(size_t)(r0 + i) * N + k + j] : 0.;
+    }
     __syncthreads();
-    const int r = k + nb + blockIdx.x * 64 + t;
-    if (r >= N) return;
-    double *row = A + (size_t)r * N + k;
-    double x[CH_NB];
+    const int ty = tid >> 4, tx = tid & 15;
+    double acc[4][4] = {};
+    for (int c = 0; c < CH_NB; c++) {
+        double pr[4], xc[4];
 #pragma unroll
-    for (int j = 0; j < CH_NB; j++) x[j] = j < nb ? row[j] : 0.;
+        for (int u = 0; u < 4; u++) { pr[u] = P[ty + 16 * u][c]; xc[u] = X[tx + 16 * u][c]; }
 #pragma unroll
-    for (int j = 0; j < CH_NB; j++) {
-        if (j < nb) {
-            double v = 0.;
+        for (int u = 0; u < 4; u++)
 #pragma unroll
-            for (int c = 0; c <= j; c++) v += x[c] * X[j][c];
-            row[j] = v;
-        }
+            for (int v = 0; v < 4; v++) acc[u][v] += pr[u] * xc[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) P[ty + 16 * u][tx + 16 * v] = acc[u][v];
+    __syncthreads();
+    for (int e = tid; e < rows * CH_NB; e += 256) {
+        const int i = e / CH_NB, j = e % CH_NB;
+        if (j < nb) A[(size_t)(r0 + i) * N + k + j] = P[i][j];
     }
 }
 
@@ -351,7 +366,7 @@ int chol_lower(apmf_ctx *ctx, double *A, int N, int *d_info, double *d_linv /* C
         hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, ctx->stream, A, N, k, d_info, d_linv);
         const int rest = N - k - nb;
         if (rest > 0) {
-            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64), dim3(64), 0, ctx->stream, A, N, k,
+            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64), dim3(256), 0, ctx->stream, A, N, k,
                                (const int *)d_info, (const double *)d_linv);
             const int tiles = (rest + 63) / 64;
             hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, ctx->stream, A, N, k,
