@@ -551,3 +551,23 @@ def test_compare_threaded_keys_equal_single_key_runs(pkg):
         alone = pkg.mn.compare([key], g['real'], g['ratings'], **kw)
         assert [s[2] for s in together[key]] == [s[2] for s in alone[key]]          # picks
         assert [s[1] for s in together[key]] == [s[1] for s in alone[key]]          # RMSEs
+
+
+@pytest.mark.parametrize('d', [13, 16, 24])
+def test_mn_selection_rank_above_12_exact(pkg, d):
+    """Rank > 12: the class's selection runs through the matrix-core float32 sweep, the near-tie
+    short list and the float64 re-score; the pick must be the oracle's float64 arg-max over the
+    pool in pool order (the reference's first-extremum rule), for max and for min criteria."""
+    from oracle import oracle as orc
+    seed(100 + d)
+    n, m = 23, 37
+    ii, jj = np.nonzero(np.random.rand(n, m) < .3)
+    ratings = np.c_[ii, jj, np.random.randint(1, 6, ii.size)].astype(float)
+    a = pkg.mn.MNActivePMF(ratings, latent_d=d, rating_values=(1, 2, 3, 4, 5))
+    a.initialize_approx(random_cov=True)
+    pool = list(a.unrated)
+    _, pv = orc.mn_pred_means_vars(n, m, a.mean, a.cov_useritems, a.cov_latents)
+    vals = np.array([pv[i, j] for i, j in pool])
+    assert a.pick_query_point(pool=pool, key=pkg.mn.KEY_FUNCS['pred-variance']) == pool[int(np.argmax(vals))]
+    got = np.array(a._get_key_vals(pool, pkg.mn.KEY_FUNCS['pred-variance']))
+    assert np.all(np.abs(got - vals) <= 1e-9 * np.abs(vals).max())
