@@ -571,3 +571,43 @@ def test_mn_selection_rank_above_12_exact(pkg, d):
     assert a.pick_query_point(pool=pool, key=pkg.mn.KEY_FUNCS['pred-variance']) == pool[int(np.argmax(vals))]
     got = np.array(a._get_key_vals(pool, pkg.mn.KEY_FUNCS['pred-variance']))
     assert np.all(np.abs(got - vals) <= 1e-9 * np.abs(vals).max())
+
+
+def test_cli_entry_points(tmp_path, pkg, monkeypatch):
+    """The command lines the reference's results/*/Makefile targets run (mn_active_pmf.py:1011-1128,
+    bayes_pmf.py:828-937): --load-data of an .npz with the choose_training.py keys, a couple of
+    steps, results pickle with the per-key (n_rated, rmse, (i, j), vals, pred) records."""
+    import os
+    import subprocess
+    import sys
+    # a script run as __main__ pickles its classes as __main__.X; the reference's consumers import
+    # them into their own __main__ "to make pickle happy" (plot_results.py:17-24) - same here
+    main_mod = sys.modules['__main__']
+    monkeypatch.setattr(main_mod, 'MNActivePMF', pkg.mn.MNActivePMF, raising=False)
+    monkeypatch.setattr(main_mod, 'BayesianPMF', pkg.bayes.BayesianPMF, raising=False)
+    g = load_golden('trace_c1_mn')
+    data = tmp_path / 'data.npz'
+    np.savez(data, _real=g['real'], _ratings=g['ratings'], _rating_vals=np.arange(1, 6))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    out = tmp_path / 'mn.pkl'
+    r = subprocess.run([sys.executable, '-m', 'active_matrix_factorization_amd.mn_active_pmf', '--load-data', str(data),
+                        '--latent-d', '2', '--discrete-integration', '--steps', '2', '--no-threading',
+                        '--save-results', str(out), 'pred-variance', 'pred'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(out, 'rb') as f:
+        res = pickle.load(f)
+    for key in ('pred-variance', 'pred'):
+        steps = res[key]
+        assert len(steps) == 2 and steps[0][0] == g['ratings'].shape[0] and steps[1][0] == steps[0][0] + 1
+        assert len(steps[1][2]) == 2 and steps[1][4].shape == g['real'].shape
+    out = tmp_path / 'bayes.pkl'
+    r = subprocess.run([sys.executable, '-m', 'active_matrix_factorization_amd.bayes_pmf', '--load-data', str(data),
+                        '--latent-d', '2', '--steps', '1', '--samps', '8', '--lookahead-samps', '4', '--unthreaded',
+                        '--save-results', str(out), 'pred-variance'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    with open(out, 'rb') as f:
+        res = pickle.load(f)
+    assert 'pred-variance' in res and len(res['pred-variance']) >= 1
