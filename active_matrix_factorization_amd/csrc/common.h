@@ -95,6 +95,10 @@ void apmf_set_error(const char *fmt, ...);
 // device scratch slot `slot` of at least `bytes` (contents undefined)
 int apmf_ws(apmf_ctx *ctx, int slot, size_t bytes, void **out);
 int apmf_pinned(apmf_ctx *ctx, size_t bytes, void **out);
+// libapmf_dense.so internals shared between dense.hip and k5_klgrad.hip (not part of include/apmf.h)
+extern "C" int apmf_dense_logdet_keep_factor(apmf_ctx *ctx, const double *d_mat, int N, double *d_L,
+                                             double *h_logdet, int *h_have_factor);
+extern "C" int apmf_dense_inverse_from_factor(apmf_ctx *ctx, const double *d_L, int N, double *d_inv);
 
 static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 static inline int64_t cdiv64(int64_t x, int64_t a) { return (x + a - 1) / a; }

@@ -515,4 +515,57 @@ int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_i
     return APMF_OK;
 }
 
+// log|det| of a (hopefully) symmetric positive definite matrix, keeping its Cholesky factor:
+// on success *h_have_factor = 1 and d_L (N x N) holds L in its row-major lower triangle, ready for
+// apmf_dense_inverse_from_factor - the variational fit evaluates the KL of a trial point and, if
+// the trial is accepted, the gradient's inverse of the SAME matrix.  Otherwise (small, not
+// symmetric, not positive definite) *h_have_factor = 0 and the general routine supplies the value.
+int apmf_dense_logdet_keep_factor(apmf_ctx *ctx, const double *d_mat, int N, double *d_L, double *h_logdet,
+                                  int *h_have_factor)
+{
+    APMF_REQUIRE(ctx && d_mat && d_L && h_logdet && h_have_factor, "NULL operand");
+    *h_have_factor = 0;
+    if (N > SMALL_N) {
+        const size_t nn = (size_t)N * N;
+        void *w;
+        APMF_TRY(apmf_ws(ctx, 3, (CH_NB * CH_NB + 16) * sizeof(double) + 64, &w));
+        double *linv = (double *)w, *scal = linv + CH_NB * CH_NB;
+        int *info = (int *)(scal + 4);
+        APMF_CHECK_HIP(hipMemsetAsync(info + 1, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_check_symmetric, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_mat, N, info + 1);
+        APMF_CHECK_LAUNCH();
+        APMF_CHECK_HIP(hipMemcpyAsync(d_L, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        APMF_TRY(chol_lower(ctx, d_L, N, info, linv));
+        hipLaunchKernelGGL(k_logdet_chol, dim3(1), dim3(256), 0, ctx->stream, d_L, N, scal);
+        APMF_CHECK_LAUNCH();
+        double back[6];      // logdet (only meaningful if the flags are clear) and the two flags
+        APMF_TRY(apmf_d2h(ctx, back, scal, sizeof(back)));
+        int hi[2];
+        memcpy(hi, &back[4], sizeof(hi));
+        if (hi[0] == 0 && hi[1] == 0) {
+            *h_logdet = back[0];
+            *h_have_factor = 1;
+            return APMF_OK;
+        }
+    }
+    return apmf_dense_inv_logdet(ctx, d_mat, N, nullptr, h_logdet);
+}
+
+// d_inv <- (L L')^-1 from the factor left by apmf_dense_logdet_keep_factor (d_L is not modified)
+int apmf_dense_inverse_from_factor(apmf_ctx *ctx, const double *d_L, int N, double *d_inv)
+{
+    APMF_REQUIRE(ctx && d_L && d_inv && d_L != d_inv, "bad operand");
+    rocblas_handle h;
+    APMF_TRY(handle_for(ctx, &h));
+    const size_t nn = (size_t)N * N;
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 3, 64, &w));
+    APMF_CHECK_HIP(hipMemcpyAsync(d_inv, d_L, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    // row-major lower L = column-major upper U with A = U'U
+    APMF_CHECK_ROC(rocsolver_dpotri(h, rocblas_fill_upper, N, d_inv, N, (int *)w));
+    hipLaunchKernelGGL(k_mirror_triangle, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_inv, N);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
 } // extern "C"

@@ -577,10 +577,11 @@ __global__ __launch_bounds__(256) void k_full_grad_init(size_t K, size_t nd, dou
 
 extern "C" {
 
-int apmf_mn_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
-                        const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
-                        double sigma_u_sq, double sigma_v_sq, double *d_g_mean,
-                        double *d_g_cov_useritems, double *d_g_cov_latents)
+// d_factor (nullable): Cholesky factor of d_cov_useritems left by the KL evaluation of the same matrix
+static int mn_kl_gradient_impl(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                               const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
+                               double sigma_u_sq, double sigma_v_sq, double *d_g_mean,
+                               double *d_g_cov_useritems, double *d_g_cov_latents, const double *d_factor)
 {
     APMF_REQUIRE(ctx && r && d_mean && d_cov_useritems && d_cov_latents && d_g_mean && d_g_cov_useritems &&
                      d_g_cov_latents, "NULL operand");
@@ -591,7 +592,8 @@ int apmf_mn_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const doubl
     APMF_TRY(carve(ctx, q.n, q.m, d, &w));
     APMF_TRY(row_constants(ctx, q, d_mean, d_cov_useritems, d_cov_latents, w));
     // entropy terms first: g_S <- inverse, then scaled; g_Omega's inverse goes to a scratch
-    APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov_useritems, q.N, d_g_cov_useritems, nullptr));
+    if (d_factor) APMF_TRY(apmf_dense_inverse_from_factor(ctx, d_factor, q.N, d_g_cov_useritems));
+    else APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov_useritems, q.N, d_g_cov_useritems, nullptr));
     APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov_latents, d, w.Oinv, nullptr));
     const size_t nn = (size_t)q.N * q.N;
     hipLaunchKernelGGL(k_entropy_term, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -618,9 +620,11 @@ int apmf_mn_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const doubl
     return APMF_OK;
 }
 
-int apmf_mn_kl_value(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
-                     const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
-                     double sigma_u_sq, double sigma_v_sq, double *h_kl)
+// d_factor_out (nullable): receives the Cholesky factor of d_cov_useritems when *h_have_factor comes back 1
+static int mn_kl_value_impl(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                            const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
+                            double sigma_u_sq, double sigma_v_sq, double *h_kl, double *d_factor_out,
+                            int *h_have_factor)
 {
     APMF_REQUIRE(ctx && r && d_mean && d_cov_useritems && d_cov_latents && h_kl, "NULL operand");
     APMF_REQUIRE(d >= 1 && d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
@@ -639,7 +643,8 @@ int apmf_mn_kl_value(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *
     APMF_TRY(apmf_d2h(ctx, h4, w.out4, sizeof(h4)));
     APMF_TRY(apmf_d2h(ctx, &hoc, w.oc, sizeof(hoc)));
     double ld_s = 0, ld_o = 0;
-    APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov_useritems, q.N, nullptr, &ld_s));
+    if (d_factor_out) APMF_TRY(apmf_dense_logdet_keep_factor(ctx, d_cov_useritems, q.N, d_factor_out, &ld_s, h_have_factor));
+    else APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov_useritems, q.N, nullptr, &ld_s));
     APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov_latents, d, nullptr, &ld_o));
     double kl = -(ld_s * d + ld_o * q.N) / 2.;
     // sic: the item trace term is dropped and the item prior uses sigma_u_sq (:176, :191-197)
@@ -649,6 +654,23 @@ int apmf_mn_kl_value(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *
     (void)sigma_v_sq;
     *h_kl = kl;
     return APMF_OK;
+}
+
+int apmf_mn_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                        const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
+                        double sigma_u_sq, double sigma_v_sq, double *d_g_mean,
+                        double *d_g_cov_useritems, double *d_g_cov_latents)
+{
+    return mn_kl_gradient_impl(ctx, r, d, d_mean, d_cov_useritems, d_cov_latents, sigma_sq, sigma_u_sq,
+                               sigma_v_sq, d_g_mean, d_g_cov_useritems, d_g_cov_latents, nullptr);
+}
+
+int apmf_mn_kl_value(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                     const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
+                     double sigma_u_sq, double sigma_v_sq, double *h_kl)
+{
+    return mn_kl_value_impl(ctx, r, d, d_mean, d_cov_useritems, d_cov_latents, sigma_sq, sigma_u_sq, sigma_v_sq,
+                            h_kl, nullptr, nullptr);
 }
 
 int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_mean,
@@ -670,15 +692,22 @@ int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_me
         rc = apmf_malloc(ctx, cnt[k] * sizeof(double), (void **)&grad[k]);
         if (rc == APMF_OK) rc = apmf_malloc(ctx, cnt[k] * sizeof(double), (void **)&cand[k]);
     }
+    // The KL of a trial point factorises its covariance; if the trial is accepted the gradient
+    // needs the inverse of that same matrix: the factor is kept (fcand) and handed over (fcur).
+    double *fcur = nullptr, *fcand = nullptr;
+    int have_cur = 0, have_cand = 0;
+    if (rc == APMF_OK) rc = apmf_malloc(ctx, cnt[1] * sizeof(double), (void **)&fcur);
+    if (rc == APMF_OK) rc = apmf_malloc(ctx, cnt[1] * sizeof(double), (void **)&fcand);
     double lr = *h_lr, old_kl = *h_old_kl;
     int64_t steps = 0;
     bool converged = false;
     if (rc == APMF_OK && old_kl != old_kl)      // NaN: not known yet
-        rc = apmf_mn_kl_value(ctx, r, d, cur[0], cur[1], cur[2], sigma_sq, sigma_u_sq, sigma_v_sq, &old_kl);
+        rc = mn_kl_value_impl(ctx, r, d, cur[0], cur[1], cur[2], sigma_sq, sigma_u_sq, sigma_v_sq, &old_kl, fcur,
+                              &have_cur);
     // mn_active_pmf.py:242-288
     while (rc == APMF_OK && !converged && (max_steps < 0 || steps < max_steps)) {
-        rc = apmf_mn_kl_gradient(ctx, r, d, cur[0], cur[1], cur[2], sigma_sq, sigma_u_sq, sigma_v_sq, grad[0],
-                                 grad[1], grad[2]);
+        rc = mn_kl_gradient_impl(ctx, r, d, cur[0], cur[1], cur[2], sigma_sq, sigma_u_sq, sigma_v_sq, grad[0],
+                                 grad[1], grad[2], have_cur ? fcur : nullptr);
         while (rc == APMF_OK) {
             for (int k = 0; k < 3; k++)
                 hipLaunchKernelGGL(k_trial_point, dim3((unsigned)((cnt[k] + 255) / 256)), dim3(256), 0,
@@ -687,10 +716,12 @@ int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_me
             if ((rc = apmf_dense_project_psd(ctx, cand[1], (int)N, min_eig, nullptr)) != APMF_OK) break;
             if ((rc = apmf_dense_project_psd(ctx, cand[2], d, min_eig, nullptr)) != APMF_OK) break;
             double new_kl = 0.;
-            if ((rc = apmf_mn_kl_value(ctx, r, d, cand[0], cand[1], cand[2], sigma_sq, sigma_u_sq, sigma_v_sq,
-                                       &new_kl)) != APMF_OK)
+            if ((rc = mn_kl_value_impl(ctx, r, d, cand[0], cand[1], cand[2], sigma_sq, sigma_u_sq, sigma_v_sq,
+                                       &new_kl, fcand, &have_cand)) != APMF_OK)
                 break;
             if (new_kl < old_kl) {
+                std::swap(fcur, fcand);
+                have_cur = have_cand;
                 for (int k = 0; k < 3; k++)
                     (void)hipMemcpyAsync(cur[k], cand[k], cnt[k] * sizeof(double), hipMemcpyDeviceToDevice,
                                          ctx->stream);
@@ -713,6 +744,8 @@ int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_me
         if (grad[k]) (void)apmf_free(ctx, grad[k]);
         if (cand[k]) (void)apmf_free(ctx, cand[k]);
     }
+    if (fcur) (void)apmf_free(ctx, fcur);
+    if (fcand) (void)apmf_free(ctx, fcand);
     *h_lr = lr;
     *h_old_kl = old_kl;
     *h_steps = steps;
