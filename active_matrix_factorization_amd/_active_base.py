@@ -446,6 +446,15 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
         elif len(pool) == 1:
             return next(iter(pool))
         pool = list(pool)
+        impl = getattr(key, 'batched', None)
+        if impl is not None and chooser in (max, min):
+            # one launch scores the pool; the first extremum in pool order (what max() / min() over
+            # zip(pool, vals) return) is np.argmax / np.argmin's first occurrence
+            pool, pi, pj = _pool_arrays(pool)
+            vals = np.asarray(getattr(self, impl)(pi, pj), dtype=np.float64)
+            if not np.isnan(vals).any():
+                return pool[int(np.argmax(vals) if chooser is max else np.argmin(vals))]
+            return chooser(zip(pool, vals.tolist()), key=operator.itemgetter(1))[0]
         vals = self._get_key_vals(pool, key, procs, worker_pool)
         return chooser(zip(pool, vals), key=operator.itemgetter(1))[0]
 

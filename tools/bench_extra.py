@@ -71,5 +71,6 @@ t0 = time.perf_counter()
 vals = a._get_key_vals(pool, mn_active_pmf.MNActivePMF.pred_variance, None, None)
 out['mn_pred_variance_full_pool_s_class'] = time.perf_counter() - t0
 out['mn_pool_size'] = len(pool)
+t0 = time.perf_counter(); pick = a.pick_query_point(pool=pool); out['mn_pick_query_point_full_pool_s_class'] = time.perf_counter() - t0
 t0 = time.perf_counter(); tv = a._total_variance(); out['mn_total_variance_s_class'] = time.perf_counter() - t0
 print(json.dumps(out, indent=1))
