@@ -99,6 +99,8 @@ int apmf_pinned(apmf_ctx *ctx, size_t bytes, void **out);
 extern "C" int apmf_dense_logdet_keep_factor(apmf_ctx *ctx, const double *d_mat, int N, double *d_L,
                                              double *h_logdet, int *h_have_factor);
 extern "C" int apmf_dense_inverse_from_factor(apmf_ctx *ctx, const double *d_L, int N, double *d_inv);
+extern "C" int apmf_dense_certify_and_factor(apmf_ctx *ctx, double *d_mat, int N, double min_eig, double *d_L,
+                                             double *h_logdet, int *h_certified, int *h_have_factor);
 
 static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 static inline int64_t cdiv64(int64_t x, int64_t a) { return (x + a - 1) / a; }

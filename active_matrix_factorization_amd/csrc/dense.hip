@@ -236,9 +236,13 @@ __device__ __forceinline__ double lane_value(double v, int src)
 // place and L_kk^-1 (64 x 64, row-major, zero above the diagonal) to `linv` for the panel
 // solve.  A short last block is padded with the identity.  *info = k + j + 1 at the first
 // non-positive pivot.
-__global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ A, int N, int k, int *__restrict__ info,
-                                                  double *__restrict__ linv)
+__global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ A0, double *__restrict__ A1, int N, int k,
+                                                  int *__restrict__ info_, double *__restrict__ linv_)
 {
+    // blockIdx.y selects one of two matrices factored side by side (same launches, twice the blocks)
+    double *__restrict__ A = blockIdx.y ? A1 : A0;
+    int *__restrict__ info = info_ + blockIdx.y;
+    double *__restrict__ linv = linv_ + (size_t)blockIdx.y * CH_NB * CH_NB;
     const int t = threadIdx.x;
     const int nb = min(CH_NB, N - k);
     if (*info != 0) return;          // an earlier panel already failed
@@ -278,9 +282,12 @@ __global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ A, int N,
 // rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T = (rows) x (L_kk^-1)': a 64 x 64 x 64 product
 // per block of 64 rows, 4 x 4 outputs per thread, both operands in LDS (rows / columns dealt to the
 // threads with stride 16 so that neither operand read conflicts)
-__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int N, int k, const int *__restrict__ info,
-                                                   const double *__restrict__ linv)
+__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A0, double *__restrict__ A1, int N, int k,
+                                                   const int *__restrict__ info_, const double *__restrict__ linv_)
 {
+    double *__restrict__ A = blockIdx.y ? A1 : A0;
+    const int *__restrict__ info = info_ + blockIdx.y;
+    const double *__restrict__ linv = linv_ + (size_t)blockIdx.y * CH_NB * CH_NB;
     __shared__ double P[CH_NB][CH_NB + 1], X[CH_NB][CH_NB + 1];
     const int tid = threadIdx.x;
     const int nb = min(CH_NB, N - k);
@@ -318,8 +325,11 @@ __global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A, int 
 
 // trailing update: for i >= j >= k + nb:  A[i][j] -= sum_t P[i][t] P[j][t],  P = A[:, k..k+nb)
 // one 64 x 64 tile per block (tiles on or below the diagonal), 4 x 4 outputs per thread
-__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int N, int k, const int *__restrict__ info)
+__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A0, double *__restrict__ A1, int N, int k,
+                                                    const int *__restrict__ info_)
 {
+    double *__restrict__ A = blockIdx.y ? A1 : A0;
+    const int *__restrict__ info = info_ + blockIdx.y;
     __shared__ double Pi[64][CH_NB + 1], Pj[64][CH_NB + 1];
     if (*info != 0) return;
     const int nb = min(CH_NB, N - k);
@@ -358,19 +368,23 @@ __global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A, int
 
 // Cholesky of the lower triangle of the row-major N x N matrix A, in place; d_info (device int,
 // zeroed here) receives 0 or the 1-based index of the first non-positive pivot
-int chol_lower(apmf_ctx *ctx, double *A, int N, int *d_info, double *d_linv /* CH_NB^2 doubles */)
+// Cholesky of the lower triangle of the row-major N x N matrix A0 (and, side by side in the same
+// launches, of A1 when it is not NULL), in place; d_info (one device int per matrix, zeroed here)
+// receives 0 or the 1-based index of the first non-positive pivot; d_linv: CH_NB^2 doubles per matrix.
+int chol_lower(apmf_ctx *ctx, double *A0, int N, int *d_info, double *d_linv, double *A1 = nullptr)
 {
-    APMF_CHECK_HIP(hipMemsetAsync(d_info, 0, sizeof(int), ctx->stream));
+    const int nmat = A1 ? 2 : 1;
+    APMF_CHECK_HIP(hipMemsetAsync(d_info, 0, nmat * sizeof(int), ctx->stream));
     for (int k = 0; k < N; k += CH_NB) {
         const int nb = std::min(CH_NB, N - k);
-        hipLaunchKernelGGL(k_chol_diag, dim3(1), dim3(64), 0, ctx->stream, A, N, k, d_info, d_linv);
+        hipLaunchKernelGGL(k_chol_diag, dim3(1, nmat), dim3(64), 0, ctx->stream, A0, A1, N, k, d_info, d_linv);
         const int rest = N - k - nb;
         if (rest > 0) {
-            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64), dim3(256), 0, ctx->stream, A, N, k,
+            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, nmat), dim3(256), 0, ctx->stream, A0, A1, N, k,
                                (const int *)d_info, (const double *)d_linv);
             const int tiles = (rest + 63) / 64;
-            hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, ctx->stream, A, N, k,
-                               (const int *)d_info);
+            hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2, nmat), dim3(256), 0, ctx->stream, A0, A1,
+                               N, k, (const int *)d_info);
         }
     }
     APMF_CHECK_LAUNCH();
@@ -566,6 +580,48 @@ int apmf_dense_inverse_from_factor(apmf_ctx *ctx, const double *d_L, int N, doub
     hipLaunchKernelGGL(k_mirror_triangle, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_inv, N);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
+}
+
+// One trial of the variational fit needs, for the candidate covariance S: (a) project_psd's
+// verdict "no eigenvalue below min_eig" and (b) log det S with the factor kept.  Both are
+// Cholesky factorisations - of S - (min_eig + delta) I and of S - and they are run side by side in the
+// same launches (the factorisation is a latency-bound chain of small kernels; two cost what one
+// does).  d_mat is symmetrised in place, like project_psd does first.  *h_certified = 1: nothing
+// to clip, and then *h_have_factor / *h_logdet / d_L are as in apmf_dense_logdet_keep_factor.
+// *h_certified = 0: nothing is concluded (the caller runs the general project_psd).
+int apmf_dense_certify_and_factor(apmf_ctx *ctx, double *d_mat, int N, double min_eig, double *d_L,
+                                  double *h_logdet, int *h_certified, int *h_have_factor)
+{
+    APMF_REQUIRE(ctx && d_mat && d_L && h_logdet && h_certified && h_have_factor, "NULL operand");
+    APMF_REQUIRE(N > SMALL_N, "small matrices take the single-kernel path");
+    *h_certified = 0;
+    *h_have_factor = 0;
+    const size_t nn = (size_t)N * N;
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 3, (nn + 2 * CH_NB * CH_NB + 16) * sizeof(double) + 64, &w));
+    double *V = (double *)w, *linv = V + nn, *scal = linv + 2 * CH_NB * CH_NB;
+    int *info = (int *)(scal + 4);
+    hipLaunchKernelGGL(k_symmetrize, dim3(grid_for(nn)), dim3(256), 0, ctx->stream, d_mat, N);
+    APMF_CHECK_LAUNCH();
+    APMF_CHECK_HIP(hipMemcpyAsync(V, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    APMF_CHECK_HIP(hipMemcpyAsync(d_L, d_mat, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_shift_diag, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, V, N, min_eig, scal);
+    APMF_CHECK_LAUNCH();
+    APMF_TRY(chol_lower(ctx, V, N, info, linv, d_L));
+    hipLaunchKernelGGL(k_logdet_chol, dim3(1), dim3(256), 0, ctx->stream, d_L, N, scal);
+    APMF_CHECK_LAUNCH();
+    double back[6];
+    APMF_TRY(apmf_d2h(ctx, back, scal, sizeof(back)));
+    int hi[2];
+    memcpy(hi, &back[4], sizeof(hi));
+    if (hi[0] != 0) return APMF_OK;          // not certified
+    *h_certified = 1;
+    if (hi[1] == 0) {
+        *h_logdet = back[0];
+        *h_have_factor = 1;
+        return APMF_OK;
+    }
+    return apmf_dense_inv_logdet(ctx, d_mat, N, nullptr, h_logdet);
 }
 
 } // extern "C"

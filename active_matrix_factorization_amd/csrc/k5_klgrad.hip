@@ -624,7 +624,7 @@ static int mn_kl_gradient_impl(apmf_ctx *ctx, const apmf_ratings *r, int d, cons
 static int mn_kl_value_impl(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
                             const double *d_cov_useritems, const double *d_cov_latents, double sigma_sq,
                             double sigma_u_sq, double sigma_v_sq, double *h_kl, double *d_factor_out,
-                            int *h_have_factor)
+                            int *h_have_factor, const double *ld_s_known = nullptr)
 {
     APMF_REQUIRE(ctx && r && d_mean && d_cov_useritems && d_cov_latents && h_kl, "NULL operand");
     APMF_REQUIRE(d >= 1 && d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
@@ -643,7 +643,8 @@ static int mn_kl_value_impl(apmf_ctx *ctx, const apmf_ratings *r, int d, const d
     APMF_TRY(apmf_d2h(ctx, h4, w.out4, sizeof(h4)));
     APMF_TRY(apmf_d2h(ctx, &hoc, w.oc, sizeof(hoc)));
     double ld_s = 0, ld_o = 0;
-    if (d_factor_out) APMF_TRY(apmf_dense_logdet_keep_factor(ctx, d_cov_useritems, q.N, d_factor_out, &ld_s, h_have_factor));
+    if (ld_s_known) ld_s = *ld_s_known;     // the caller already factorised this matrix
+    else if (d_factor_out) APMF_TRY(apmf_dense_logdet_keep_factor(ctx, d_cov_useritems, q.N, d_factor_out, &ld_s, h_have_factor));
     else APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov_useritems, q.N, nullptr, &ld_s));
     APMF_TRY(apmf_dense_inv_logdet(ctx, d_cov_latents, d, nullptr, &ld_o));
     double kl = -(ld_s * d + ld_o * q.N) / 2.;
@@ -713,11 +714,22 @@ int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_me
                 hipLaunchKernelGGL(k_trial_point, dim3((unsigned)((cnt[k] + 255) / 256)), dim3(256), 0,
                                    ctx->stream, cnt[k], cur[k], grad[k], lr, cand[k]);
             if (hipGetLastError() != hipSuccess) { apmf_set_error("kernel launch failed"); rc = APMF_EHIP; break; }
-            if ((rc = apmf_dense_project_psd(ctx, cand[1], (int)N, min_eig, nullptr)) != APMF_OK) break;
+            // projection of the (n+m)^2 covariance: the certificate "nothing to clip" and the
+            // factorisation the KL needs anyway run side by side; only when the certificate fails
+            // does the general project_psd (eigendecomposition) run, and the KL factorises afresh
+            double ld_s = 0.;
+            int certified = 0;
+            have_cand = 0;
+            if (N > 32) {
+                if ((rc = apmf_dense_certify_and_factor(ctx, cand[1], (int)N, min_eig, fcand, &ld_s, &certified,
+                                                        &have_cand)) != APMF_OK)
+                    break;
+            }
+            if (!certified && (rc = apmf_dense_project_psd(ctx, cand[1], (int)N, min_eig, nullptr)) != APMF_OK) break;
             if ((rc = apmf_dense_project_psd(ctx, cand[2], d, min_eig, nullptr)) != APMF_OK) break;
             double new_kl = 0.;
             if ((rc = mn_kl_value_impl(ctx, r, d, cand[0], cand[1], cand[2], sigma_sq, sigma_u_sq, sigma_v_sq,
-                                       &new_kl, fcand, &have_cand)) != APMF_OK)
+                                       &new_kl, fcand, &have_cand, certified ? &ld_s : nullptr)) != APMF_OK)
                 break;
             if (new_kl < old_kl) {
                 std::swap(fcur, fcand);
