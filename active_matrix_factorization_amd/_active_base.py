@@ -67,9 +67,9 @@ def strictmap(*args, **kwargs):
 # map runs on a small pool of THREADS, each with its own Context (= own stream, workspaces,
 # rocBLAS handle).  Results come back in input order and are bit-identical to the sequential
 # ones (tested; it is why the Cholesky factorisation is our own).  Measured on one MI355X, 20
-# hypotheses at 94 x 425 (tools/probe_lookahead_threads.py): 85.8 s sequential, 31.5 s with 4
+# hypotheses at 94 x 425 (tools/probe_lookahead_threads.py): 37.5 s sequential, 14.7 s with 4
 # threads - provided the runtime has a hardware queue per stream (_lib.load sets
-# GPU_MAX_HW_QUEUES=8; with the default 4 two worker streams share a queue and it is 49.9 s).
+# GPU_MAX_HW_QUEUES=8; with the default 4 two worker streams share a queue: 1.7x instead of 2.5x).
 # More than 4 threads do not help (tools/probe_scaling.py).  `procs` / APMF_LOOKAHEAD_THREADS
 # set the width
 # (default 4; 0 or 1 = sequential).
