@@ -29,13 +29,16 @@ _lib.Context.mn_fit_normal = timed
 
 pool = sorted(a.unrated)[:4]
 key = mn.KEY_FUNCS['total-variance']
+allvals = {}
 for procs in (1, 4):
     events.clear()
     t = time.perf_counter()
     with redirect_stdout(io.StringIO()):
         vals = a._get_key_vals(pool, key, procs=procs)
     wall = time.perf_counter() - t
+    allvals[procs] = list(vals)
     infit = sum(e[2] - e[1] for e in events)
     steps = sum(e[3] for e in events)
     print('procs=%d wall %.2f s; %d fit calls, %d accepted steps, summed time inside the C call %.2f s; threads %s'
           % (procs, wall, len(events), steps, infit, sorted(set(e[0] for e in events))), flush=True)
+print('values identical across widths:', allvals[1] == allvals[4], allvals[1][:2])
