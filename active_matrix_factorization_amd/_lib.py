@@ -80,6 +80,7 @@ _SIGS = {
     'apmf_gibbs_half_sweep': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     'apmf_gibbs_half_sweep_rows': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     'apmf_sample_stats_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
+    'apmf_fill_normal_f64': (_i, [_vp, _vp, _i64, C.c_uint64, C.c_uint64]),
     'apmf_grid_gather_f64': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _vp]),
     'apmf_pool_argext_f64': (_i, [_vp, _vp, _i64, _i, C.POINTER(_i64), C.POINTER(_dbl)]),
 }
@@ -475,6 +476,11 @@ class Context(object):
         _check(self._lib.apmf_gibbs_half_sweep_rows(self._h, rt._h, side, lo, hi, _ptr(oth), d,
                                                     _ptr(alpha), _ptr(mu), beta, mean_sub, _ptr(z),
                                                     _ptr(out)))
+
+    def fill_normal(self, out, seed, offset=0):
+        """out[...] ~ N(0, 1) from the device generator (Philox4x32-10 + Box-Muller); not NumPy's stream."""
+        _check(self._lib.apmf_fill_normal_f64(self._h, _ptr(out), out.size, int(seed) & (2 ** 64 - 1),
+                                              int(offset) & (2 ** 64 - 1)))
 
     def sample_stats(self, S, n, m, d, ld, Us, Vs, add, cutoff, mean=None, var=None, prob=None):
         _check(self._lib.apmf_sample_stats_f64(self._h, S, n, m, d, ld, _ptr(Us), _ptr(Vs), add,

@@ -17,6 +17,7 @@ the reference's arithmetic, quirks included.
 from collections import namedtuple
 from copy import deepcopy
 from itertools import islice, repeat
+import os
 import random
 import warnings
 
@@ -69,6 +70,10 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
         self.discrete_expectations = discrete_expectations
         self.num_integration_pts = num_integration_pts
         self.beta = 2  # observation noise precision
+        # Opt-in: draw the per-row N(0,1)^d of the Gibbs sweeps on the device
+        # (Philox) instead of np.random.normal on the host.  Changes the random stream, so results no
+        # longer match a reference run with the same seed; the hyper-parameter draws stay on the host.
+        self.device_rng = bool(int(os.environ.get('APMF_DEVICE_RNG', '0')))
         # Gaussian-Wishart hyper-priors: (scale matrix, b0, degrees of freedom, mu0)
         self.u_hyperparams = (np.eye(latent_d), 2, latent_d, np.zeros(latent_d))
         self.v_hyperparams = (np.eye(latent_d), 2, latent_d, np.zeros(latent_d))
@@ -159,6 +164,9 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
         beta, sub = float(self.beta), self._mean_sub()
         d_users, d_items = ctx.array(user_sample), ctx.array(item_sample)
         d_z_u, d_z_v = ctx.empty((n, d)), ctx.empty((m, d))
+        device_rng = getattr(self, 'device_rng', False)
+        if device_rng:      # seeded from NumPy's generator: np.random.seed still fixes the chain
+            rng_seed, rng_ctr = int(np.random.randint(0, 2 ** 31 - 1)) * 2654435761 + 1, 0
         while True:
             mu_u, alpha_u = self.sample_hyperparam(user_sample, True)
             mu_v, alpha_v = self.sample_hyperparam(item_sample, False)
@@ -166,12 +174,20 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
             d_mu_v, d_al_v = ctx.array(mu_v, np.float64), ctx.array(alpha_v, np.float64)
             for gibbs in range(num_gibbs):
                 # one N(0,1)^d per user in user order == one (n, d) draw
-                d_z_u.upload(np.random.normal(0, 1, (n, d)))
+                if device_rng:
+                    ctx.fill_normal(d_z_u, rng_seed, rng_ctr)
+                    rng_ctr += (n * d + 1) // 2
+                else:
+                    d_z_u.upload(np.random.normal(0, 1, (n, d)))
                 new_users = ctx.empty((n, d))
                 ctx.gibbs_half_sweep(rt, 0, d_items, d, d_al_u, d_mu_u, beta, sub, d_z_u, new_users)
                 d_users = new_users
                 # items against the NEW users
-                d_z_v.upload(np.random.normal(0, 1, (m, d)))
+                if device_rng:
+                    ctx.fill_normal(d_z_v, rng_seed, rng_ctr)
+                    rng_ctr += (m * d + 1) // 2
+                else:
+                    d_z_v.upload(np.random.normal(0, 1, (m, d)))
                 new_items = ctx.empty((m, d))
                 ctx.gibbs_half_sweep(rt, 1, d_users, d, d_al_v, d_mu_v, beta, sub, d_z_v, new_items)
                 d_items = new_items

@@ -176,6 +176,38 @@ size_t gibbs_smem(int d)
     return sizeof(double) * (2 * (size_t)d * (d + 1) + 2 * d);
 }
 
+// ---- optional device-side N(0,1) draws ---------------------------
+// Philox4x32-10 counter-based generator + Box-Muller, two doubles per counter.  NOT the
+// reference's random stream (NumPy's MT19937): BayesianPMF only uses it when device_rng is
+// switched on, trading stream parity for not generating and uploading (n+m) d normals on the
+// host per half-sweep pair.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_normal(double *__restrict__ out, int64_t count, uint64_t seed,
+                                                     uint64_t offset)
+{
+    const int64_t pair = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (2 * pair >= count) return;
+    const uint64_t ctr = offset + (uint64_t)pair;
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0x243F6A88u, 0x85A308D3u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    // 53-bit uniforms in (0, 1]
+    const uint64_t a = (((uint64_t)c[0] << 32) | c[1]) >> 11, b = (((uint64_t)c[2] << 32) | c[3]) >> 11;
+    const double u1 = ((double)a + 1.) * (1. / 9007199254740992.), u2 = ((double)b + 1.) * (1. / 9007199254740992.);
+    const double rad = sqrt(-2. * log(u1)), ang = 6.283185307179586476925 * u2;
+    out[2 * pair] = rad * cos(ang);
+    if (2 * pair + 1 < count) out[2 * pair + 1] = rad * sin(ang);
+}
+
 } // namespace
 
 static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo, int row_hi,
@@ -242,5 +274,17 @@ static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo
         apmf_set_error("alpha + beta F'F (or its inverse) is not positive definite");
         return APMF_ENOTPD;
     }
+    return APMF_OK;
+}
+
+extern "C" int apmf_fill_normal_f64(apmf_ctx *ctx, double *d_out, int64_t count, uint64_t seed, uint64_t offset)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (count == 0) return APMF_OK;
+    APMF_REQUIRE(d_out && count > 0, "bad operand");
+    const int64_t pairs = (count + 1) / 2;
+    hipLaunchKernelGGL(k_fill_normal, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, d_out, count,
+                       seed, offset);
+    APMF_CHECK_LAUNCH();
     return APMF_OK;
 }

@@ -280,6 +280,12 @@ int apmf_full_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const dou
                           const double *d_cov, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
                           double *d_g_mean, double *d_g_cov);
 
+/* Optional device-side standard-normal draws for the Gibbs sweeps (Philox4x32-10 + Box-Muller,
+ * counter = offset + index / 2): d_out[0..count) ~ N(0, 1).  Not NumPy's stream - BayesianPMF
+ * uses it only with device_rng switched on (the reference draws np.random.normal per row,
+ * bayes_pmf.py:212-215). */
+int apmf_fill_normal_f64(apmf_ctx *ctx, double *d_out, int64_t count, uint64_t seed, uint64_t offset);
+
 #ifdef __cplusplus
 }
 #endif

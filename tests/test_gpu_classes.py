@@ -611,3 +611,34 @@ def test_cli_entry_points(tmp_path, pkg, monkeypatch):
     with open(out, 'rb') as f:
         res = pickle.load(f)
     assert 'pred-variance' in res and len(res['pred-variance']) >= 1
+
+
+def test_bayes_device_rng_opt_in(pkg):
+    """device_rng=True: the per-row N(0,1) draws come from the device generator.  Not the
+    reference's stream (so no golden comparison); the chain must be reproducible under
+    np.random.seed, differ from the host-RNG chain, and fit the data as well."""
+    seed(3)
+    n, m, d = 30, 25, 4
+    u, v = np.random.normal(0, 1, (n, d)), np.random.normal(0, 1, (m, d))
+    real = u @ v.T + np.random.normal(0, .1, (n, m))
+    mask = np.random.rand(n, m) < .5
+    mask[np.arange(n), np.random.randint(0, m, n)] = True
+    mask[np.random.randint(0, n, m), np.arange(m)] = True
+    ii, jj = mask.nonzero()
+    ratings = np.c_[ii, jj, real[ii, jj]]
+
+    def chain(device_rng, s):
+        seed(s)
+        b = pkg.bayes.BayesianPMF(ratings, latent_d=d)
+        b.device_rng = device_rng
+        b.do_fit()
+        samps = list(islice(b.samples(), 60))
+        pred = b.predict(samps[20:])
+        return samps, float(np.sqrt(np.mean((pred[ii, jj] - real[ii, jj]) ** 2)))
+
+    s1, rmse_dev = chain(True, 11)
+    s2, _ = chain(True, 11)
+    s3, rmse_host = chain(False, 11)
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(s1, s2))
+    assert not np.array_equal(s1[0][0], s3[0][0])
+    assert rmse_dev < 0.3 and abs(rmse_dev - rmse_host) < 0.1

@@ -759,3 +759,23 @@ def test_full_kl_gradient_vs_numpy(ctx, shape):
     rm, rc = normal_grad_numpy(mean, cov, ratings, d, u, v, 0.7, 9., 11.)
     np.testing.assert_allclose(gm.to_host(), rm, rtol=1e-10, atol=1e-10 * np.abs(rm).max())
     np.testing.assert_allclose(gc.to_host(), rc, rtol=1e-10, atol=1e-10 * np.abs(rc).max())
+
+
+def test_fill_normal_device_generator(ctx):
+    """Philox4x32-10 + Box-Muller: reproducible for (seed, offset), different across offsets, and
+    standard normal to sampling accuracy (moments, tail mass, no correlation between neighbours)."""
+    n = 1 << 20
+    a, b, c = ctx.empty(n), ctx.empty(n), ctx.empty(n + 1)
+    ctx.fill_normal(a, 12345, 0)
+    ctx.fill_normal(b, 12345, 0)
+    ctx.fill_normal(c, 12345, n // 2)
+    x, y, z = a.to_host(), b.to_host(), c.to_host()
+    assert np.array_equal(x, y) and np.all(np.isfinite(x)) and np.all(np.isfinite(z))
+    assert not np.array_equal(x[:1000], z[:1000])
+    assert abs(x.mean()) < 5 / np.sqrt(n) and abs(x.var() - 1) < 5 * np.sqrt(2. / n)
+    assert abs((x ** 4).mean() - 3) < 0.05 and abs((np.abs(x) > 3).mean() - 0.0027) < 3e-4
+    assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 5 / np.sqrt(n)
+    assert abs(np.corrcoef(x[0::2], x[1::2])[0, 1]) < 5 / np.sqrt(n / 2)     # the two outputs of a pair
+    odd = ctx.empty(7)
+    ctx.fill_normal(odd, 1, 0)
+    assert np.all(np.isfinite(odd.to_host()))
