@@ -94,6 +94,20 @@ _DENSE_SIGS = {
     'apmf_mn_fit_normal': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.POINTER(_dbl),
                                 C.POINTER(_dbl), _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
 }
+_DENSE_SIGS.update({
+    'apmf_mn_batch_create': (_i, [_vp, _vp, _i, _i, _i64, C.POINTER(_vp)]),
+    'apmf_mn_batch_destroy': (_i, [_vp, _vp]),
+    'apmf_mn_batch_size': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'apmf_mn_batch_set_state': (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    'apmf_mn_batch_set_extra': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'apmf_mn_batch_get_state': (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    'apmf_mn_batch_fit': (_i, [_vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp, _vp, _vp]),
+    'apmf_mn_batch_kl': (_i, [_vp, _vp, _dbl, _dbl, _dbl, _vp]),
+    'apmf_mn_batch_gradient': (_i, [_vp, _vp, _i, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
+    'apmf_mn_batch_total_variance': (_i, [_vp, _vp, _vp]),
+    'apmf_mn_batch_entropy': (_i, [_vp, _vp, _vp]),
+    'apmf_mn_batch_score_grid': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+})
 DENSE_LIB_PATH = os.path.join(_HERE, 'libapmf_dense.so')
 
 _lib = None
@@ -265,6 +279,95 @@ class Ratings(object):
             pass
 
 
+class MNBatch(object):
+    """H matrix-normal approximations resident on the device (apmf_mn_batch): the batched
+    one-step lookahead, and - with H = 1 - the device-resident state of one MNActivePMF."""
+
+    def __init__(self, ctx, rt, d, H, trace_cap=0):
+        self.ctx, self.rt = ctx, rt          # rt is kept alive: the batch borrows it
+        self.H, self.d, self.n, self.m = int(H), int(d), rt.n, rt.m
+        self.trace_cap = int(trace_cap)
+        self._dense = load_dense()
+        h = _vp()
+        _check(self._dense.apmf_mn_batch_create(ctx._h, rt._h, self.d, self.H, self.trace_cap, C.byref(h)))
+        self._h = h.value
+
+    def free(self):
+        if getattr(self, '_h', None):
+            if self.ctx._h:
+                self._dense.apmf_mn_batch_destroy(self.ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def set_state(self, mean=None, cov_useritems=None, cov_latents=None, per_hypothesis=0):
+        _check(self._dense.apmf_mn_batch_set_state(self.ctx._h, self._h, _ptr(mean), _ptr(cov_useritems),
+                                                   _ptr(cov_latents), int(per_hypothesis)))
+
+    def set_extra(self, hi=None, hj=None, hv=None):
+        if hi is None:
+            _check(self._dense.apmf_mn_batch_set_extra(self.ctx._h, self._h, None, None, None))
+            return
+        hi = np.ascontiguousarray(hi, np.int32)
+        hj = np.ascontiguousarray(hj, np.int32)
+        hv = np.ascontiguousarray(hv, np.float64)
+        if not (hi.size == hj.size == hv.size == self.H):
+            raise ValueError('one extra rating per hypothesis expected')
+        _check(self._dense.apmf_mn_batch_set_extra(self.ctx._h, self._h, hi.ctypes.data, hj.ctypes.data,
+                                                   hv.ctypes.data))
+
+    def get_state(self, h, mean=None, cov_useritems=None, cov_latents=None):
+        _check(self._dense.apmf_mn_batch_get_state(self.ctx._h, self._h, int(h), _ptr(mean),
+                                                   _ptr(cov_useritems), _ptr(cov_latents)))
+
+    def fit(self, sig, sig_u, sig_v, min_eig, lr, old_kl=None, max_steps=-1):
+        """-> (lr (H), old_kl (H), steps (H), converged (H), kl_trace (H, trace_cap))"""
+        lr_io = np.ascontiguousarray(np.broadcast_to(np.asarray(lr, np.float64), (self.H,))).copy()
+        kl_io = np.full(self.H, np.nan) if old_kl is None else \
+            np.ascontiguousarray(np.broadcast_to(np.asarray(old_kl, np.float64), (self.H,))).copy()
+        steps = np.zeros(self.H, np.int64)
+        conv = np.zeros(self.H, np.int32)
+        trace = np.full((self.H, max(self.trace_cap, 1)), np.nan)
+        _check(self._dense.apmf_mn_batch_fit(self.ctx._h, self._h, float(sig), float(sig_u), float(sig_v),
+                                             float(min_eig), lr_io.ctypes.data, kl_io.ctypes.data,
+                                             int(max_steps), trace.ctypes.data if self.trace_cap else None,
+                                             steps.ctypes.data, conv.ctypes.data))
+        return lr_io, kl_io, steps, conv.astype(bool), trace
+
+    def kl(self, sig, sig_u, sig_v):
+        out = np.empty(self.H)
+        _check(self._dense.apmf_mn_batch_kl(self.ctx._h, self._h, float(sig), float(sig_u), float(sig_v),
+                                            out.ctypes.data))
+        return out
+
+    def gradient(self, h, sig, sig_u, sig_v, g_mean, g_cov_useritems, g_cov_latents):
+        _check(self._dense.apmf_mn_batch_gradient(self.ctx._h, self._h, int(h), float(sig), float(sig_u),
+                                                  float(sig_v), _ptr(g_mean), _ptr(g_cov_useritems),
+                                                  _ptr(g_cov_latents)))
+
+    def total_variance(self):
+        out = np.empty(self.H)
+        _check(self._dense.apmf_mn_batch_total_variance(self.ctx._h, self._h, out.ctypes.data))
+        return out
+
+    def entropy(self):
+        out = np.empty(self.H)
+        _check(self._dense.apmf_mn_batch_entropy(self.ctx._h, self._h, out.ctypes.data))
+        return out
+
+    def score_grid(self, h0=0, B=None, f32=False, mask=None, var=None, pmean=None, dsum=None, want=0,
+                   best_val=None, best_idx=None, ld=None):
+        B = self.H - h0 if B is None else B
+        ld = grid_ld(self.m) if ld is None else ld
+        _check(self._dense.apmf_mn_batch_score_grid(self.ctx._h, self._h, int(h0), int(B), int(bool(f32)), ld,
+                                                    _ptr(mask), _ptr(var), _ptr(pmean), _ptr(dsum), int(want),
+                                                    _ptr(best_val), _ptr(best_idx)))
+
+
 class Context(object):
     """One device + one stream (apmf_ctx).  Not thread-safe; never create before fork()."""
 
@@ -349,6 +452,9 @@ class Context(object):
 
     def ratings(self, ratings, n, m):
         return Ratings(self, ratings, n, m)
+
+    def mn_batch(self, rt, d, H, trace_cap=0):
+        return MNBatch(self, rt, d, H, trace_cap)
 
     # -- K1 ---------------------------------------------------------------------------
     def pmf_gradient(self, rt, dU, dV, d, sig, sig_u, sig_v, subtract_mean, mean_rating, dgU, dgV):

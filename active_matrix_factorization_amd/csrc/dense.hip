@@ -12,6 +12,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include "common.h"
+#include "chol.h"
 
 namespace {
 
@@ -208,166 +209,7 @@ __global__ __launch_bounds__(64) void k_small_spd(const double *__restrict__ A, 
     }
 }
 
-// ---- blocked Cholesky of our own ---------------------------------------------------------
-// rocSOLVER's potrf is not bit-reproducible when the GPU is shared (another stream or process
-// running): the same input gave last-place different factors, and the accept / reject
-// searches built on it amplify that into different trajectories.  This one is a plain
-// right-looking blocked factorisation with fixed summation orders and no atomics:
-//   per panel of CH_NB columns: factor the diagonal block and invert it (one wave, everything
-//   in registers), multiply the rows below it by that inverse (64 x 64 x 64 products in LDS), update the trailing lower triangle
-//   (64 x 64 tiles, the panel staged through LDS).
-// A is row-major; only its lower triangle (i >= j) is read, and L overwrites it.
-constexpr int CH_NB = 64;
-
-// lane `src` 's value of a wave-resident double, as a wave-uniform value
-__device__ __forceinline__ double lane_value(double v, int src)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Diagonal block k..k+nb, one wave, everything in registers: lane t holds row t of the block
-// (64 doubles) and other lanes' entries arrive by v_readlane: 55 us per block.  The LDS
-// formulations were slower: one wave walking its rows serially 113 us (dependent LDS round
-// trips; rocSOLVER's potf2_kernel_small is of this kind, 135 us), four waves sharing the
-// trailing update 87 us (320 block barriers).  Writes L_kk in
-// place and L_kk^-1 (64 x 64, row-major, zero above the diagonal) to `linv` for the panel
-// solve.  A short last block is padded with the identity.  *info = k + j + 1 at the first
-// non-positive pivot.
-__global__ __launch_bounds__(64) void k_chol_diag(double *__restrict__ A0, double *__restrict__ A1, int N, int k,
-                                                  int *__restrict__ info_, double *__restrict__ linv_)
-{
-    // blockIdx.y selects one of two matrices factored side by side (same launches, twice the blocks)
-    double *__restrict__ A = blockIdx.y ? A1 : A0;
-    int *__restrict__ info = info_ + blockIdx.y;
-    double *__restrict__ linv = linv_ + (size_t)blockIdx.y * CH_NB * CH_NB;
-    const int t = threadIdx.x;
-    const int nb = min(CH_NB, N - k);
-    if (*info != 0) return;          // an earlier panel already failed
-    double r[CH_NB];
-#pragma unroll
-    for (int c = 0; c < CH_NB; c++)
-        r[c] = (t < nb && c <= t) ? A[(size_t)(k + t) * N + k + c] : (c == t ? 1. : 0.);
-    // right-looking factorisation; entries above the diagonal hold don't-care values
-#pragma unroll
-    for (int j = 0; j < CH_NB; j++) {
-        const double pj = lane_value(r[j], j);
-        if (!(pj > 0.)) {            // wave-uniform
-            if (t == 0) *info = k + j + 1;
-            return;
-        }
-        const double rj = sqrt(pj);
-        r[j] = t == j ? rj : r[j] / rj;
-#pragma unroll
-        for (int c = j + 1; c < CH_NB; c++) r[c] -= r[j] * lane_value(r[j], c);
-    }
-#pragma unroll
-    for (int c = 0; c < CH_NB; c++)
-        if (t < nb && c <= t) A[(size_t)(k + t) * N + k + c] = r[c];
-    // X = L^-1: lane c owns column c, X[i][c] = (delta_ic - sum_{m=c}^{i-1} L[i][m] X[m][c]) / L[i][i]
-    double x[CH_NB];
-#pragma unroll
-    for (int i = 0; i < CH_NB; i++) {
-        double v = i == t ? 1. : 0.;
-#pragma unroll
-        for (int m = 0; m < i; m++) v -= lane_value(r[m], i) * x[m];   // x[m] = 0 for m < c
-        x[i] = i < t ? 0. : v / lane_value(r[i], i);
-    }
-#pragma unroll
-    for (int i = 0; i < CH_NB; i++) linv[i * CH_NB + t] = x[i];
-}
-
-// rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T = (rows) x (L_kk^-1)': a 64 x 64 x 64 product
-// per block of 64 rows, 4 x 4 outputs per thread, both operands in LDS (rows / columns dealt to the
-// threads with stride 16 so that neither operand read conflicts)
-__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ A0, double *__restrict__ A1, int N, int k,
-                                                   const int *__restrict__ info_, const double *__restrict__ linv_)
-{
-    double *__restrict__ A = blockIdx.y ? A1 : A0;
-    const int *__restrict__ info = info_ + blockIdx.y;
-    const double *__restrict__ linv = linv_ + (size_t)blockIdx.y * CH_NB * CH_NB;
-    __shared__ double P[CH_NB][CH_NB + 1], X[CH_NB][CH_NB + 1];
-    const int tid = threadIdx.x;
-    const int nb = min(CH_NB, N - k);
-    if (*info != 0) return;
-    const int r0 = k + nb + blockIdx.x * 64;
-    const int rows = min(64, N - r0);
-    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-        const int i = e / CH_NB, j = e % CH_NB;
-        X[i][j] = linv[e];
-        P[i][j] = (i < rows && j < nb) ? A[(size_t)(r0 + i) * N + k + j] : 0.;
-    }
-    __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    double acc[4][4] = {};
-    for (int c = 0; c < CH_NB; c++) {
-        double pr[4], xc[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { pr[u] = P[ty + 16 * u][c]; xc[u] = X[tx + 16 * u][c]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[u][v] += pr[u] * xc[v];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) P[ty + 16 * u][tx + 16 * v] = acc[u][v];
-    __syncthreads();
-    for (int e = tid; e < rows * CH_NB; e += 256) {
-        const int i = e / CH_NB, j = e % CH_NB;
-        if (j < nb) A[(size_t)(r0 + i) * N + k + j] = P[i][j];
-    }
-}
-
-// trailing update: for i >= j >= k + nb:  A[i][j] -= sum_t P[i][t] P[j][t],  P = A[:, k..k+nb)
-// one 64 x 64 tile per block (tiles on or below the diagonal), 4 x 4 outputs per thread
-__global__ __launch_bounds__(256) void k_chol_update(double *__restrict__ A0, double *__restrict__ A1, int N, int k,
-                                                    const int *__restrict__ info_)
-{
-    double *__restrict__ A = blockIdx.y ? A1 : A0;
-    const int *__restrict__ info = info_ + blockIdx.y;
-    __shared__ double Pi[64][CH_NB + 1], Pj[64][CH_NB + 1];
-    if (*info != 0) return;
-    const int nb = min(CH_NB, N - k);
-    const int base = k + nb;
-    // triangular tile index -> (ti >= tj)
-    int ti = (int)((sqrt(8. * blockIdx.x + 1.) - 1.) / 2.);
-    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
-    while (ti * (ti + 1) / 2 > (int)blockIdx.x) ti--;
-    const int tj = blockIdx.x - ti * (ti + 1) / 2;
-    const int i0 = base + ti * 64, j0 = base + tj * 64;
-    for (int e = threadIdx.x; e < 64 * nb; e += 256) {
-        const int r = e / nb, c = e % nb;
-        Pi[r][c] = i0 + r < N ? A[(size_t)(i0 + r) * N + k + c] : 0.;
-        Pj[r][c] = j0 + r < N ? A[(size_t)(j0 + r) * N + k + c] : 0.;
-    }
-    __syncthreads();
-    const int tr = (threadIdx.x >> 4) * 4, tc = (threadIdx.x & 15) * 4;
-    double acc[4][4] = {};
-    for (int c = 0; c < nb; c++) {
-        double a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = Pi[tr + u][c]; b[u] = Pj[tc + u][c]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int i = i0 + tr + u, j = j0 + tc + v;
-            if (i < N && j <= i) A[(size_t)i * N + j] -= acc[u][v];
-        }
-}
-
-// Cholesky of the lower triangle of the row-major N x N matrix A, in place; d_info (device int,
-// zeroed here) receives 0 or the 1-based index of the first non-positive pivot
+// ---- blocked Cholesky of our own (chol.h) ----------------------------------------------------
 // Cholesky of the lower triangle of the row-major N x N matrix A0 (and, side by side in the same
 // launches, of A1 when it is not NULL), in place; d_info (one device int per matrix, zeroed here)
 // receives 0 or the 1-based index of the first non-positive pivot; d_linv: CH_NB^2 doubles per matrix.
@@ -375,20 +217,11 @@ int chol_lower(apmf_ctx *ctx, double *A0, int N, int *d_info, double *d_linv, do
 {
     const int nmat = A1 ? 2 : 1;
     APMF_CHECK_HIP(hipMemsetAsync(d_info, 0, nmat * sizeof(int), ctx->stream));
-    for (int k = 0; k < N; k += CH_NB) {
-        const int nb = std::min(CH_NB, N - k);
-        hipLaunchKernelGGL(k_chol_diag, dim3(1, nmat), dim3(64), 0, ctx->stream, A0, A1, N, k, d_info, d_linv);
-        const int rest = N - k - nb;
-        if (rest > 0) {
-            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, nmat), dim3(256), 0, ctx->stream, A0, A1, N, k,
-                               (const int *)d_info, (const double *)d_linv);
-            const int tiles = (rest + 63) / 64;
-            hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2, nmat), dim3(256), 0, ctx->stream, A0, A1,
-                               N, k, (const int *)d_info);
-        }
-    }
-    APMF_CHECK_LAUNCH();
-    return APMF_OK;
+    ChJobs J;
+    J.j[0] = ChJob{A0, d_info, d_linv, 0};
+    J.j[1] = ChJob{A1, d_info + 1, d_linv + CH_NB * CH_NB, 0};
+    J.list = nullptr;
+    return chol_lower_jobs(ctx, J, nmat, N);
 }
 
 } // namespace

@@ -674,97 +674,6 @@ int apmf_mn_kl_value(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *
                             h_kl, nullptr, nullptr);
 }
 
-int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_mean,
-                       double *d_cov_useritems, double *d_cov_latents, double sigma_sq,
-                       double sigma_u_sq, double sigma_v_sq, double min_eig, double *h_lr,
-                       double *h_old_kl, int64_t max_steps, double *h_kl_trace, int64_t trace_cap,
-                       int64_t *h_steps, int *h_converged)
-{
-    APMF_REQUIRE(ctx && r && d_mean && d_cov_useritems && d_cov_latents && h_lr && h_old_kl && h_steps &&
-                     h_converged, "NULL operand");
-    APMF_REQUIRE(d >= 1 && d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
-    APMF_REQUIRE(trace_cap == 0 || h_kl_trace, "h_kl_trace is NULL");
-    const size_t N = (size_t)r->n + r->m;
-    const size_t cnt[3] = {N * d, N * N, (size_t)d * d};
-    double *cur[3] = {d_mean, d_cov_useritems, d_cov_latents};
-    double *grad[3] = {nullptr, nullptr, nullptr}, *cand[3] = {nullptr, nullptr, nullptr};
-    int rc = APMF_OK;
-    for (int k = 0; k < 3 && rc == APMF_OK; k++) {
-        rc = apmf_malloc(ctx, cnt[k] * sizeof(double), (void **)&grad[k]);
-        if (rc == APMF_OK) rc = apmf_malloc(ctx, cnt[k] * sizeof(double), (void **)&cand[k]);
-    }
-    // The KL of a trial point factorises its covariance; if the trial is accepted the gradient
-    // needs the inverse of that same matrix: the factor is kept (fcand) and handed over (fcur).
-    double *fcur = nullptr, *fcand = nullptr;
-    int have_cur = 0, have_cand = 0;
-    if (rc == APMF_OK) rc = apmf_malloc(ctx, cnt[1] * sizeof(double), (void **)&fcur);
-    if (rc == APMF_OK) rc = apmf_malloc(ctx, cnt[1] * sizeof(double), (void **)&fcand);
-    double lr = *h_lr, old_kl = *h_old_kl;
-    int64_t steps = 0;
-    bool converged = false;
-    if (rc == APMF_OK && old_kl != old_kl)      // NaN: not known yet
-        rc = mn_kl_value_impl(ctx, r, d, cur[0], cur[1], cur[2], sigma_sq, sigma_u_sq, sigma_v_sq, &old_kl, fcur,
-                              &have_cur);
-    // mn_active_pmf.py:242-288
-    while (rc == APMF_OK && !converged && (max_steps < 0 || steps < max_steps)) {
-        rc = mn_kl_gradient_impl(ctx, r, d, cur[0], cur[1], cur[2], sigma_sq, sigma_u_sq, sigma_v_sq, grad[0],
-                                 grad[1], grad[2], have_cur ? fcur : nullptr);
-        while (rc == APMF_OK) {
-            for (int k = 0; k < 3; k++)
-                hipLaunchKernelGGL(k_trial_point, dim3((unsigned)((cnt[k] + 255) / 256)), dim3(256), 0,
-                                   ctx->stream, cnt[k], cur[k], grad[k], lr, cand[k]);
-            if (hipGetLastError() != hipSuccess) { apmf_set_error("kernel launch failed"); rc = APMF_EHIP; break; }
-            // projection of the (n+m)^2 covariance: the certificate "nothing to clip" and the
-            // factorisation the KL needs anyway run side by side; only when the certificate fails
-            // does the general project_psd (eigendecomposition) run, and the KL factorises afresh
-            double ld_s = 0.;
-            int certified = 0;
-            have_cand = 0;
-            if (N > 32) {
-                if ((rc = apmf_dense_certify_and_factor(ctx, cand[1], (int)N, min_eig, fcand, &ld_s, &certified,
-                                                        &have_cand)) != APMF_OK)
-                    break;
-            }
-            if (!certified && (rc = apmf_dense_project_psd(ctx, cand[1], (int)N, min_eig, nullptr)) != APMF_OK) break;
-            if ((rc = apmf_dense_project_psd(ctx, cand[2], d, min_eig, nullptr)) != APMF_OK) break;
-            double new_kl = 0.;
-            if ((rc = mn_kl_value_impl(ctx, r, d, cand[0], cand[1], cand[2], sigma_sq, sigma_u_sq, sigma_v_sq,
-                                       &new_kl, fcand, &have_cand, certified ? &ld_s : nullptr)) != APMF_OK)
-                break;
-            if (new_kl < old_kl) {
-                std::swap(fcur, fcand);
-                have_cur = have_cand;
-                for (int k = 0; k < 3; k++)
-                    (void)hipMemcpyAsync(cur[k], cand[k], cnt[k] * sizeof(double), hipMemcpyDeviceToDevice,
-                                         ctx->stream);
-                lr *= 1.25;
-                if (old_kl - new_kl < .005) converged = true;
-                if (steps < trace_cap) h_kl_trace[steps] = new_kl;
-                steps++;
-                old_kl = new_kl;
-                break;
-            }
-            lr *= .5;
-            if (lr < 1e-10) { converged = true; break; }
-        }
-    }
-    if (rc == APMF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        apmf_set_error("stream synchronisation failed");
-        rc = APMF_EHIP;
-    }
-    for (int k = 0; k < 3; k++) {
-        if (grad[k]) (void)apmf_free(ctx, grad[k]);
-        if (cand[k]) (void)apmf_free(ctx, cand[k]);
-    }
-    if (fcur) (void)apmf_free(ctx, fcur);
-    if (fcand) (void)apmf_free(ctx, fcand);
-    *h_lr = lr;
-    *h_old_kl = old_kl;
-    *h_steps = steps;
-    *h_converged = converged ? 1 : 0;
-    return rc;
-}
-
 int apmf_full_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
                           const double *d_cov, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
                           double *d_g_mean, double *d_g_cov)

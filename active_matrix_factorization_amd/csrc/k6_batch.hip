@@ -1,0 +1,1556 @@
+// k6_batch.hip - H matrix-normal variational fits advanced by ONE chain of launches
+// (the batched lookahead driver; part of libapmf_dense.so).
+//
+// What it replaces.  The reference evaluates a lookahead criterion by running, for every
+// hypothesis "entry (i, j) turns out to be v" (|pool| x |rating values| of them per query step,
+// mn_active_pmf.py:660-672 mapped over the pool at :749-755):
+//     deepcopy(model) -> add_rating(i, j, v) -> fit_normal() -> fn(model)
+// fit_normal (mn_active_pmf.py:236-288) is projected gradient descent on the KL with a
+// x1.25 / x0.5 learning-rate search: a latency-bound chain of small dependent kernels
+// (Cholesky panels, K5 row kernels, d x d solves) that keeps a handful of the 256 CUs busy.
+// Here the H fits are independent problems of the same shape, so every kernel of that chain
+// gets a second grid dimension - the hypothesis - and the chain is walked once for all of them:
+//   * the H states (mean, cov_useritems, cov_latents), their gradients, trial points and
+//     Cholesky factors live in HBM for the whole fit (5 N^2 + 3 N d + 5 d^2 doubles each);
+//     device-side POINTER TABLES say which buffer currently is "current" and which "trial", so
+//     accepting a trial is a pointer swap made by the kernel that takes the decision;
+//   * a hypothesis differs from the base model by ONE rating: the kernels walk the shared CSR
+//     of the base ratings and take the extra (i, j, v) of their hypothesis as the last entry of
+//     user row i / item row j - exactly where add_rating() + a rebuilt CSR would put it, so the
+//     sums are bit-identical to the one-model path;
+//   * the accept / reject decision, learning rate, KL, step counter and convergence flag of
+//     every hypothesis are device state (k_decide); the host reads one small status record per
+//     hypothesis per trial and compacts the list of still-active hypotheses (`sel`), so that
+//     converged fits cost nothing;
+//   * the rare exits of the fast path (a projection that really has to clip eigenvalues, a
+//     factorisation that fails) are handled per hypothesis by the single-matrix routines of
+//     dense.hip and re-enter the batch.
+// A hypothesis' arithmetic never depends on which other hypotheses share its launches: H = 1
+// (MNActivePMF.fit_normal itself runs through here) and H = 2048 give bit-identical fits.
+//
+// Inverse of the covariance for the entropy term of the gradient: from the Cholesky factor the
+// trial evaluation left behind, by our own kernels (rocSOLVER's potri is one more library call
+// chain per hypothesis and is not batched over pointer tables): W = L^-1 by block elimination
+// (one launch per 64-column panel, every launch a set of independent 64^3 products), then
+// S^-1 = W' W in one launch, with the -(d/2)(2 - delta) scaling of matrix_normal_exps_cy.pyx:477-480
+// applied as the tiles are written.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "chol.h"
+#include "common.h"
+
+extern "C" int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, int *h_projected);
+extern "C" int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_inv, double *h_logdet);
+extern "C" int apmf_mn_score_grid_f64(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const double *d_mean,
+                                      const double *d_cross, const double *d_diag, const double *d_omega,
+                                      const uint8_t *d_mask, double *d_var, double *d_pmean, double *d_sum,
+                                      int want, double *d_best_val, int64_t *d_best_idx);
+extern "C" int apmf_mn_score_grid_f32(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const float *d_mean,
+                                      const float *d_cross, const float *d_diag, const float *d_omega,
+                                      const uint8_t *d_mask, float *d_var, float *d_pmean, double *d_sum,
+                                      int want, float *d_best_val, int64_t *d_best_idx);
+
+namespace {
+
+// ---- pointer tables ------------------------------------------------------------------------
+enum {
+    T_M_CUR, T_M_CAND, T_M_GRAD,
+    T_S_CUR, T_S_CAND, T_S_GRAD, T_S_F, T_S_W,
+    T_O_CUR, T_O_CAND, T_O_GRAD, T_OI_CUR, T_OI_CAND,
+    T_COUNT
+};
+
+enum { ST_ACTIVE = 0, ST_CONVERGED = 1, ST_PAUSED = 2, ST_SLOW = 3 };
+enum { SLOW_CERT_S = 1, SLOW_FACT_S = 2, SLOW_CERT_O = 4, SLOW_INV_O = 8 };
+
+struct HypState {
+    double lr, old_kl, new_kl;
+    double ld_s, ld_o;            // log-determinants of the point just evaluated
+    double cur_ld_s, cur_ld_o;    // ... of the current point (entropy criterion)
+    long long steps;              // accepted steps of this call
+    long long max_steps;          // < 0: no limit
+    int status, need_grad, slow, accepted;
+};
+
+struct OmegaConsts {
+    double T, D2, off2, sdd, t2;
+    double pad[3];
+};
+
+struct Refs {
+    double **tab;         // [T_COUNT][H]
+    HypState *hs;         // [H]
+    int *info;            // [2H]: 2h certificate factorisation (W), 2h + 1 factor of S (F)
+    double *ores;         // [H][4]: cert_bad, inv_bad, logdet of cov_latents
+    double *linvF;        // [H][nbk][64 * 64] inverses of F's diagonal blocks (kept for L^-1)
+    double *linvW;        // [H][64 * 64]
+    ChJob *jobs;          // [2H]
+    // K5 per-row work arrays, [H] x ...
+    double *xoff, *crow, *qrow, *sdiag, *dgv, *racc_u, *racc_v, *part, *out4;
+    OmegaConsts *oc;
+    double *trace;        // [H][trace_cap]
+    int *ei, *ej;         // extra rating of the hypothesis (ei < 0: none)
+    double *ev;
+    int H, n, m, d, N, nbk, trace_cap;
+};
+
+__device__ __forceinline__ double *tabp(const Refs &R, int which, int h) { return R.tab[(size_t)which * R.H + h]; }
+
+// ---- small helpers shared with K5 ------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp6(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <int DP>
+__device__ __forceinline__ double gsum(double v)
+{
+    if (DP >= 2) v += dpp6<0xB1>(v);
+    if (DP >= 4) v += dpp6<0x4E>(v);
+    if (DP >= 8) v += dpp6<0x141>(v);
+    if (DP >= 16) v += dpp6<0x140>(v);
+    if (DP >= 32) v += __shfl_xor(v, 16, 64);
+    if (DP >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int DP>
+__device__ __forceinline__ double xgsum(double v)
+{
+#pragma unroll
+    for (int o = DP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- state plumbing ----------------------------------------------------------------------------
+// table[which][h] <- src (+ h * stride): broadcast (stride 0) or per-hypothesis initial states
+__global__ __launch_bounds__(256) void kb_fill(const Refs R, int which, const double *__restrict__ src,
+                                               size_t stride, size_t count)
+{
+    const int h = blockIdx.y;
+    double *__restrict__ dst = tabp(R, which, h);
+    const double *__restrict__ s = src + (size_t)h * stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = s[i];
+}
+
+// dst (+ y * stride) <- table[which][sel[y]]
+__global__ __launch_bounds__(256) void kb_gather(const Refs R, const int *__restrict__ sel, int which,
+                                                 double *__restrict__ dst, size_t stride, size_t count)
+{
+    const int h = sel ? sel[blockIdx.y] : blockIdx.y;
+    const double *__restrict__ s = tabp(R, which, h);
+    double *__restrict__ o = dst + (size_t)blockIdx.y * stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) o[i] = s[i];
+}
+
+// table[dst][h] <- table[src][h] for h in sel
+__global__ __launch_bounds__(256) void kb_copy(const Refs R, const int *__restrict__ sel, int src, int dst,
+                                               size_t count)
+{
+    const int h = sel[blockIdx.y];
+    const double *__restrict__ s = tabp(R, src, h);
+    double *__restrict__ o = tabp(R, dst, h);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) o[i] = s[i];
+}
+
+// ---- trial point ---------------------------------------------------------------------------------
+// cov_useritems: cand = sym(cur - lr * grad) with NumPy's two roundings per entry, then
+// (A + A') / 2 like project_psd's first line (mn_active_pmf.py:48).  The same pass drops the
+// two matrices the projection test and the KL need into place: W = cand - (min_eig + delta) I (its
+// Cholesky factorisation succeeding certifies "no eigenvalue below min_eig": nothing to clip)
+// and F = cand (its factor gives log det and, if the trial is accepted, the inverse).
+// 32 x 32 tiles on or above the diagonal; the mirrored tile goes through LDS so that every
+// global access is a row segment.
+__global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__restrict__ sel, double min_eig)
+{
+    __shared__ double A[32][33], B[32][33];
+    const int h = sel[blockIdx.y];
+    const int N = R.N;
+    int tj, ti;
+    tri_tile((int)blockIdx.x, tj, ti);       // ti <= tj
+    const double lr = R.hs[h].lr;
+    const double *__restrict__ cur = tabp(R, T_S_CUR, h);
+    const double *__restrict__ g = tabp(R, T_S_GRAD, h);
+    double *__restrict__ cand = tabp(R, T_S_CAND, h);
+    double *__restrict__ F = tabp(R, T_S_F, h);
+    double *__restrict__ W = tabp(R, T_S_W, h);
+    const int i0 = ti * 32, j0 = tj * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + tx;
+        A[r][tx] = (i < N && j < N) ? __dsub_rn(cur[(size_t)i * N + j], __dmul_rn(lr, g[(size_t)i * N + j])) : 0.;
+        const int i2 = j0 + r, j2 = i0 + tx;
+        B[r][tx] = (i2 < N && j2 < N) ? __dsub_rn(cur[(size_t)i2 * N + j2], __dmul_rn(lr, g[(size_t)i2 * N + j2])) : 0.;
+    }
+    __syncthreads();
+    if (ti != tj) {
+        for (int r = ty; r < 32; r += 8) {
+            // upper tile element (i, j), i < j, and the element (j0 + r, i0 + tx) of the lower tile
+            const int i = i0 + r, j = j0 + tx;
+            if (i < N && j < N) cand[(size_t)i * N + j] = (A[r][tx] + B[tx][r]) / 2;
+            const int i2 = j0 + r, j2 = i0 + tx;
+            if (i2 < N && j2 < N) {
+                const double v = (A[tx][r] + B[r][tx]) / 2;
+                cand[(size_t)i2 * N + j2] = v;
+                F[(size_t)i2 * N + j2] = v;
+                W[(size_t)i2 * N + j2] = v;
+            }
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            const int i = i0 + r, j = i0 + tx;
+            if (i >= N || j >= N) continue;
+            // (upper + lower) / 2 off the diagonal; the diagonal itself is left alone
+            const double v = r == tx ? A[r][tx] : (r < tx ? (A[r][tx] + A[tx][r]) / 2 : (A[tx][r] + A[r][tx]) / 2);
+            cand[(size_t)i * N + j] = v;
+            if (j <= i) {
+                F[(size_t)i * N + j] = v;
+                W[(size_t)i * N + j] = i == j ? v - (min_eig + 1e-10 * fmax(fabs(v), fabs(min_eig))) : v;
+            }
+        }
+    }
+}
+
+// mean and cov_latents parts of the trial point (cov_latents symmetrised like project_psd does)
+__global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *__restrict__ sel)
+{
+    const int h = sel[blockIdx.y];
+    const double lr = R.hs[h].lr;
+    const size_t nm = (size_t)R.N * R.d, dd = (size_t)R.d * R.d;
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < nm) {
+        tabp(R, T_M_CAND, h)[t] = __dsub_rn(tabp(R, T_M_CUR, h)[t], __dmul_rn(lr, tabp(R, T_M_GRAD, h)[t]));
+    } else if (t < nm + dd) {
+        const int e = (int)(t - nm), k = e / R.d, l = e % R.d;
+        const double *cur = tabp(R, T_O_CUR, h), *g = tabp(R, T_O_GRAD, h);
+        const double a = __dsub_rn(cur[k * R.d + l], __dmul_rn(lr, g[k * R.d + l]));
+        const double b = __dsub_rn(cur[l * R.d + k], __dmul_rn(lr, g[l * R.d + k]));
+        tabp(R, T_O_CAND, h)[e] = k == l ? a : (k < l ? (a + b) / 2 : (b + a) / 2);
+    }
+}
+
+// ---- factorisation jobs --------------------------------------------------------------------------
+// mode 2: certificate (W) + factor (F) per selected hypothesis; mode 1: factor only
+__global__ void kb_make_jobs(const Refs R, const int *__restrict__ sel, int nsel, int mode)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= nsel) return;
+    const int h = sel[y];
+    const size_t blk = (size_t)CH_NB * CH_NB;
+    ChJob f;
+    f.A = tabp(R, T_S_F, h);
+    f.info = R.info + 2 * h + 1;
+    f.linv = R.linvF + (size_t)h * R.nbk * blk;
+    f.linv_keep = 1;
+    R.info[2 * h + 1] = 0;
+    if (mode == 2) {
+        ChJob w;
+        w.A = tabp(R, T_S_W, h);
+        w.info = R.info + 2 * h;
+        w.linv = R.linvW + (size_t)h * blk;
+        w.linv_keep = 0;
+        R.info[2 * h] = 0;
+        R.jobs[2 * y] = w;
+        R.jobs[2 * y + 1] = f;
+    } else {
+        R.info[2 * h] = 0;
+        R.jobs[y] = f;
+    }
+}
+
+// hs[h].ld_s = 2 sum log F[i][i]
+__global__ __launch_bounds__(256) void kb_logdet(const Refs R, const int *__restrict__ sel)
+{
+    const int h = sel[blockIdx.x];
+    const double *__restrict__ L = tabp(R, T_S_F, h);
+    const int N = R.N;
+    __shared__ double sh[256];
+    double s = 0;
+    for (int i = threadIdx.x; i < N; i += 256) s += log(L[(size_t)i * N + i]);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) R.hs[h].ld_s = 2. * sh[0];
+}
+
+// d x d covariance (d <= 64), one wave per hypothesis, in LDS: optionally the projection
+// certificate (Cholesky of O - (min_eig + delta) I), then Cholesky of O itself -> log det and
+// O^-1.  ores[h] = {certificate failed, factorisation failed, log det}.
+__global__ __launch_bounds__(64) void kb_small_spd(const Refs R, const int *__restrict__ sel, int src, int dst,
+                                                   int do_cert, double min_eig)
+{
+    extern __shared__ double sm[];
+    const int h = sel[blockIdx.x];
+    const int N = R.d, P = N + 1;
+    double *L = sm, *X = sm + (size_t)N * P;
+    __shared__ int bad;
+    const double *__restrict__ A = tabp(R, src, h);
+    double *__restrict__ inv_out = tabp(R, dst, h);
+    double *__restrict__ res = R.ores + (size_t)h * 4;
+    const int t = threadIdx.x;
+    double cert_bad = 0.;
+    for (int pass = do_cert ? 0 : 1; pass < 2; pass++) {
+        const bool shift = pass == 0;
+        __syncthreads();
+        if (t == 0) bad = 0;
+        __syncthreads();
+        for (int e = t; e < N * N; e += 64) {
+            const int i = e / N, j = e % N;
+            double v = A[e];
+            if (A[(size_t)j * N + i] != v) bad = 1;
+            if (shift && i == j) v -= min_eig + 1e-10 * fmax(fabs(v), fabs(min_eig));
+            L[i * P + j] = v;
+        }
+        __syncthreads();
+        // right-looking Cholesky, lane i owns row i
+        for (int j = 0; j < N && !bad; j++) {
+            __syncthreads();
+            const double djj = L[j * P + j];
+            if (!(djj > 0.)) {
+                if (t == 0) bad = 1;
+                __syncthreads();
+                break;
+            }
+            const double rj = sqrt(djj);
+            __syncthreads();
+            if (t == j) L[j * P + j] = rj;
+            if (t > j && t < N) L[t * P + j] /= rj;
+            __syncthreads();
+            if (t > j && t < N) {
+                const double lij = L[t * P + j];
+                for (int k = j + 1; k <= t; k++) L[t * P + k] -= lij * L[k * P + j];
+            }
+        }
+        __syncthreads();
+        if (shift) cert_bad = bad ? 1. : 0.;
+    }
+    if (bad) {
+        if (t == 0) { res[0] = cert_bad; res[1] = 1.; res[2] = 0.; }
+        return;
+    }
+    if (t == 0) {
+        double s = 0;
+        for (int i = 0; i < N; i++) s += log(L[i * P + i]);
+        res[0] = cert_bad;
+        res[1] = 0.;
+        res[2] = 2. * s;
+        R.hs[h].ld_o = 2. * s;
+    }
+    // X = L^-1 (lower), column t by forward substitution
+    if (t < N) {
+        for (int i = 0; i < N; i++) {
+            double v = (i == t) ? 1. : 0.;
+            for (int k = t; k < i; k++) v -= L[i * P + k] * X[k * P + t];
+            X[i * P + t] = i < t ? 0. : v / L[i * P + i];
+        }
+    }
+    __syncthreads();
+    // O^-1 = X' X
+    for (int e = t; e < N * N; e += 64) {
+        const int i = e / N, j = e % N;
+        double v = 0;
+        for (int k = (i > j ? i : j); k < N; k++) v += X[k * P + i] * X[k * P + j];
+        inv_out[e] = v;
+    }
+}
+
+// ---- K5 kernels with a hypothesis dimension (see k5_klgrad.hip for the algebra) -------------------
+// per-row constants of the point in tables (tm, ts, to): xoff, c, q, diag(S); Omega's scalars
+__global__ __launch_bounds__(256) void kb_rowconst(const Refs R, const int *__restrict__ sel, int tm, int ts, int to)
+{
+    const int h = sel[blockIdx.y];
+    const int N = R.N, d = R.d;
+    const double *__restrict__ M = tabp(R, tm, h);
+    const double *__restrict__ S = tabp(R, ts, h);
+    const double *__restrict__ O = tabp(R, to, h);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) {
+        double T = 0, D2 = 0, off2 = 0;
+        for (int k = 0; k < d; k++) {
+            T += O[k * d + k];
+            D2 += O[k * d + k] * O[k * d + k];
+            for (int l = k + 1; l < d; l++) off2 += O[k * d + l] * O[k * d + l];
+        }
+        OmegaConsts *oc = R.oc + h;
+        oc->T = T; oc->D2 = D2; oc->off2 = off2; oc->sdd = (T * T - D2) / 2; oc->t2 = D2 + 2 * off2;
+    }
+    if (t < d) R.dgv[(size_t)h * 64 + t] = O[t * d + t];
+    if (t >= N) return;
+    const double *x = M + (size_t)t * d;
+    double xo_dot = 0, x2dg = 0;
+    for (int k = 0; k < d; k++) {
+        double w = 0;
+        for (int l = 0; l < d; l++)
+            if (l != k) w += O[l < k ? l * d + k : k * d + l] * x[l];
+        R.xoff[((size_t)h * N + t) * d + k] = w;
+        xo_dot += x[k] * w;
+        x2dg += x[k] * x[k] * O[k * d + k];
+    }
+    R.crow[(size_t)h * N + t] = (xo_dot + x2dg) / 2;
+    R.qrow[(size_t)h * N + t] = xo_dot + x2dg;
+    R.sdiag[(size_t)h * N + t] = S[(size_t)t * N + t];
+}
+
+constexpr int UN6 = 2;
+
+// One wave per row of the CURRENT point.  SIDE 0: user rows (also writes the per-rating cross
+// entries of g_S and the sums cov_latents' gradient needs); SIDE 1: item rows.  The hypothesis'
+// extra rating is entry `end` of its row.
+template <int DP, int SIDE>
+__global__ __launch_bounds__(256) void kb_kl_rows(const Refs R, const int *__restrict__ sel,
+                                                  const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                  const double *__restrict__ val, double inv_sig)
+{
+    constexpr int G = 64 / DP;
+    const int h = sel[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave_id_uniform();
+    const int rows = SIDE == 0 ? R.n : R.m;
+    if (row >= rows) return;
+    const int d = R.d, N = R.N, n = R.n;
+    const double *__restrict__ M = tabp(R, T_M_CUR, h);
+    const double *__restrict__ S = tabp(R, T_S_CUR, h);
+    double *__restrict__ gS = tabp(R, T_S_GRAD, h);
+    const double *__restrict__ xoff = R.xoff + (size_t)h * N * d;
+    const double *__restrict__ crow = R.crow + (size_t)h * N;
+    const double *__restrict__ sdiag = R.sdiag + (size_t)h * N;
+    const OmegaConsts oc = R.oc[h];
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    const int self = SIDE == 0 ? row : n + row;
+    const double xk = kok ? M[(size_t)self * d + k] : 0.;
+    const double xok = kok ? xoff[(size_t)self * d + k] : 0.;
+    const double dgk = kok ? R.dgv[(size_t)h * 64 + k] : 0.;
+    const int64_t beg = ptr[row], end0 = ptr[row + 1];
+    const int xi = R.ei[h], xj = R.ej[h];
+    const bool has_extra = xi >= 0 && (SIDE == 0 ? xi == row : xj == row);
+    const int xc = SIDE == 0 ? xj : xi;
+    const double xv = has_extra ? R.ev[h] : 0.;
+    const int64_t end = end0 + (has_extra ? 1 : 0);
+    double gm = 0., wv = 0., gs_d = 0., cv = 0., s2 = 0., rs = 0.;
+    for (int64_t t0 = beg + g; t0 < end; t0 += (int64_t)G * UN6) {
+#pragma unroll
+        for (int u = 0; u < UN6; u++) {
+            const int64_t t = t0 + (int64_t)u * G;
+            const bool ok = t < end;
+            const bool ex = ok && t == end0;     // only reachable when has_extra
+            const int c = ok ? (ex ? xc : idx[t]) : 0;
+            const double r = ok ? (ex ? xv : val[t]) : 0.;
+            const int other = SIDE == 0 ? n + c : c;
+            const double yk = (ok && kok) ? M[(size_t)other * d + k] : 0.;
+            const double yok = (ok && kok) ? xoff[(size_t)other * d + k] : 0.;
+            const double voth = ok ? sdiag[other] : 0.;
+            const double coth = ok ? crow[other] : 0.;
+            const double s = ok ? (SIDE == 0 ? S[(size_t)row * N + other] : S[(size_t)other * N + self]) : 0.;
+            const double p = xk * yk;
+            const double P = gsum<DP>(p);
+            if (ok) {
+                gm += yk * (P - p) + s * yok + voth * xok + yk * s * (oc.T - dgk) + 2. * yk * s * dgk
+                      + xk * (yk * yk + voth * dgk) - r * yk;
+                gs_d += coth + voth * (oc.off2 + oc.D2 / 2.);
+                cv += voth;
+            }
+            if (SIDE == 0) {
+                const double cross = gsum<DP>(xk * (yk * (oc.T + dgk) + yok));
+                if (ok) {
+                    wv += s * yk;
+                    s2 += s * s;
+                    rs += r * s;
+                    if (k == 0) {
+                        const double gij = inv_sig * (cross + 2. * s * (oc.sdd + oc.off2 + oc.D2) - r * oc.T);
+                        gS[(size_t)row * N + other] += gij;
+                        gS[(size_t)other * N + row] += gij;
+                    }
+                }
+            }
+        }
+    }
+    gm = xgsum<DP>(gm);
+    wv = xgsum<DP>(wv);
+    gs_d = xgsum<DP>(gs_d); cv = xgsum<DP>(cv); s2 = xgsum<DP>(s2); rs = xgsum<DP>(rs);
+    const int stride = SIDE == 0 ? 2 * d + 4 : d + 2;
+    double *out = (SIDE == 0 ? R.racc_u + (size_t)h * n * (2 * d + 4) : R.racc_v + (size_t)h * R.m * (d + 2)) +
+                  (size_t)row * stride;
+    if (g == 0 && kok) {
+        out[k] = gm;
+        if (SIDE == 0) out[d + k] = wv;
+    }
+    if (lane == 0) {
+        if (SIDE == 0) {
+            out[2 * d] = gs_d; out[2 * d + 1] = cv; out[2 * d + 2] = s2; out[2 * d + 3] = rs;
+        } else {
+            out[d] = gs_d; out[d + 1] = cv;
+        }
+    }
+}
+
+// g_mean rows and the diagonal of g_S from the per-row sums
+__global__ __launch_bounds__(256) void kb_finish_rows(const Refs R, const int *__restrict__ sel, double inv_sig,
+                                                      double sig_u, double sig_v)
+{
+    const int h = sel[blockIdx.y];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= R.N) return;
+    const int d = R.d, n = R.n;
+    const double *__restrict__ M = tabp(R, T_M_CUR, h);
+    double *__restrict__ gmean = tabp(R, T_M_GRAD, h);
+    double *__restrict__ gS = tabp(R, T_S_GRAD, h);
+    const double trO = R.oc[h].T;
+    const bool user = t < n;
+    const double *acc = user ? R.racc_u + ((size_t)h * n + t) * (2 * d + 4)
+                             : R.racc_v + ((size_t)h * R.m + (t - n)) * (d + 2);
+    const double prior = user ? sig_u : sig_v;
+    for (int k = 0; k < d; k++) gmean[(size_t)t * d + k] = inv_sig * acc[k] + M[(size_t)t * d + k] / prior;
+    const double gs = user ? acc[2 * d] : acc[d];
+    gS[(size_t)t * R.N + t] += inv_sig * gs + trO / (2. * prior);
+}
+
+// cov_latents' gradient: one block per (k, l); fixed-order sums over the rows
+__global__ __launch_bounds__(256) void kb_omega(const Refs R, const int *__restrict__ sel, double inv_sig,
+                                                double sig_u, double sig_v)
+{
+    const int h = sel[blockIdx.y];
+    const int d = R.d, n = R.n, m = R.m;
+    const int k = blockIdx.x / d, l = blockIdx.x % d;
+    const double *__restrict__ M = tabp(R, T_M_CUR, h);
+    const double *__restrict__ O = tabp(R, T_O_CUR, h);
+    const double *__restrict__ Oinv = tabp(R, T_OI_CUR, h);
+    double *__restrict__ gO = tabp(R, T_O_GRAD, h);
+    const double *__restrict__ racc_u = R.racc_u + (size_t)h * n * (2 * d + 4);
+    const double *__restrict__ racc_v = R.racc_v + (size_t)h * m * (d + 2);
+    const double *__restrict__ sdiag = R.sdiag + (size_t)h * R.N;
+    const OmegaConsts oc = R.oc[h];
+    __shared__ double sh[6][256];
+    double g = 0, svv = 0, s2 = 0, rs = 0, aw = 0, tru = 0;
+    const int su = 2 * d + 4, sv = d + 2;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double *a = M + (size_t)i * d, *acc = racc_u + (size_t)i * su;
+        const double *w = acc + d;
+        const double cvj = acc[2 * d + 1];
+        g += w[k] * a[l] + a[k] * w[l] + cvj * a[k] * a[l];
+        svv += sdiag[i] * cvj;
+        s2 += acc[2 * d + 2];
+        rs += acc[2 * d + 3];
+        double dot = 0;
+        for (int c = 0; c < d; c++) dot += a[c] * w[c];
+        aw += dot;
+        tru += sdiag[i];
+    }
+    double trv = 0;
+    for (int j = threadIdx.x; j < m; j += 256) {
+        const double *b = M + (size_t)(n + j) * d;
+        const double cvi = racc_v[(size_t)j * sv + d + 1];
+        g += cvi * b[k] * b[l];
+        trv += sdiag[n + j];
+    }
+    double vals[6] = {g, svv, s2, rs, aw, tru};
+    for (int c = 0; c < 6; c++) sh[c][threadIdx.x] = vals[c];
+    __shared__ double sh_trv[256];
+    sh_trv[threadIdx.x] = trv;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            for (int c = 0; c < 6; c++) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
+            sh_trv[threadIdx.x] += sh_trv[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double G = sh[0][0], SVV = sh[1][0], S2 = sh[2][0], RS = sh[3][0], AW = sh[4][0];
+    const double TRU = sh[5][0], TRV = sh_trv[0];
+    const double okl = O[k <= l ? k * d + l : l * d + k];
+    double out;
+    if (k != l) {
+        out = inv_sig * (G + 2. * okl * (SVV + S2));
+    } else {
+        const double dgk = O[k * d + k];
+        double X = 0;
+        for (int i = 0; i < n; i++) X += M[(size_t)i * d + k] * racc_u[(size_t)i * su + d + k];
+        const double Q = G - 2. * X;
+        const double diag_q = AW - X + S2 * (oc.T - dgk);
+        const double diag_s = .5 * (4. * X + 4. * S2 * dgk + Q + 2. * SVV * dgk);
+        out = inv_sig * (diag_q + diag_s - RS) + TRU / (2. * sig_u) + TRV / (2. * sig_v);
+    }
+    const double ik = Oinv[k * d + l], ikt = Oinv[l * d + k];
+    out -= R.N / 2. * (ik + (k == l ? 0. : ikt));
+    gO[k * d + l] = out;
+}
+
+// per-user partial of  sum_t [ E[(u.v)^2] - 2 r E[u.v] + r^2 ]  at the point in tables (tm, ts)
+template <int DP>
+__global__ __launch_bounds__(256) void kb_value_rows(const Refs R, const int *__restrict__ sel, int tm, int ts,
+                                                     const int64_t *__restrict__ ptr,
+                                                     const int32_t *__restrict__ idx,
+                                                     const double *__restrict__ val)
+{
+    constexpr int G = 64 / DP;
+    const int h = sel[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave_id_uniform();
+    if (row >= R.n) return;
+    const int d = R.d, N = R.N, n = R.n;
+    const double *__restrict__ M = tabp(R, tm, h);
+    const double *__restrict__ S = tabp(R, ts, h);
+    const double *__restrict__ xoff = R.xoff + (size_t)h * N * d;
+    const double *__restrict__ qrow = R.qrow + (size_t)h * N;
+    const double *__restrict__ sdiag = R.sdiag + (size_t)h * N;
+    const OmegaConsts oc = R.oc[h];
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    const double ak = kok ? M[(size_t)row * d + k] : 0.;
+    const double oak = kok ? xoff[(size_t)row * d + k] + R.dgv[(size_t)h * 64 + k] * ak : 0.;   // (O' a)_k
+    const double vi = sdiag[row], aOa = qrow[row];
+    double bit = 0., un = 0.;
+    if (g == 0) un = ak * ak;
+    const int64_t beg = ptr[row], end0 = ptr[row + 1];
+    const bool has_extra = R.ei[h] == row;
+    const int64_t end = end0 + (has_extra ? 1 : 0);
+    for (int64_t t = beg + g; t < end; t += G) {
+        const bool ex = t == end0;
+        const int j = n + (ex ? R.ej[h] : idx[t]);
+        const double r = ex ? R.ev[h] : val[t];
+        const double bk = kok ? M[(size_t)j * d + k] : 0.;
+        const double ab = gsum<DP>(ak * bk);
+        const double aOb = gsum<DP>(oak * bk);
+        const double s = S[(size_t)row * N + j], vj = sdiag[j];
+        const double pred = ab + s * oc.T;
+        const double var = (vi * vj + s * s) * oc.t2 + vj * aOa + vi * qrow[j] + 2. * s * aOb;
+        if (k == 0) bit += var + pred * pred - 2. * r * pred + r * r;
+    }
+    bit = wave_sum(bit);
+    un = wave_sum(un);
+    if (lane == 0) {
+        double *part = R.part + ((size_t)h * n + row) * 3;
+        part[0] = bit;
+        part[1] = un;
+        part[2] = vi;
+    }
+}
+
+// out4[h] = {sum bit, ||M_users||^2, tr(S_users), ||M_items||^2}
+__global__ __launch_bounds__(256) void kb_value_finish(const Refs R, const int *__restrict__ sel, int tm)
+{
+    const int h = sel[blockIdx.x];
+    const double *__restrict__ part = R.part + (size_t)h * R.n * 3;
+    const double *__restrict__ M = tabp(R, tm, h);
+    __shared__ double sh[4][256];
+    double a = 0, b = 0, c = 0, e = 0;
+    for (int t = threadIdx.x; t < R.n; t += 256) {
+        a += part[(size_t)t * 3]; b += part[(size_t)t * 3 + 1]; c += part[(size_t)t * 3 + 2];
+    }
+    for (size_t t = threadIdx.x; t < (size_t)R.m * R.d; t += 256) {
+        const double v = M[(size_t)R.n * R.d + t];
+        e += v * v;
+    }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c; sh[3][threadIdx.x] = e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int z = 0; z < 4; z++) sh[z][threadIdx.x] += sh[z][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int z = 0; z < 4; z++) R.out4[(size_t)h * 4 + z] = sh[z][0];
+}
+
+// ---- the decision of the learning-rate search, per hypothesis (mn_active_pmf.py:262-288) -----------
+// mode 0: a trial point was evaluated - accept (swap the pointer tables) or reject;
+// mode 1: the KL of the current point was evaluated at entry (old_kl unknown).
+// forced: the flags were dealt with by the host (slow path), ld_s / ld_o are final.
+__global__ void kb_decide(const Refs R, const int *__restrict__ sel, int nsel, int mode, int forced,
+                          double sigma_sq, double sigma_u_sq)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= nsel) return;
+    const int h = sel[y];
+    HypState &s = R.hs[h];
+    if (!forced) {
+        int slow = 0;
+        if (mode == 0 && R.info[2 * h] != 0) slow |= SLOW_CERT_S;
+        if (R.info[2 * h + 1] != 0) slow |= SLOW_FACT_S;
+        if (mode == 0 && R.ores[(size_t)h * 4] != 0.) slow |= SLOW_CERT_O;
+        if (R.ores[(size_t)h * 4 + 1] != 0.) slow |= SLOW_INV_O;
+        s.slow = slow;
+        if (slow) {
+            s.status = ST_SLOW;
+            return;
+        }
+    }
+    const double *h4 = R.out4 + (size_t)h * 4;
+    const double T = R.oc[h].T;
+    // mn_kl_divergence, matrix_normal_exps_cy.pyx:159-213 (sic: the item trace term is dropped
+    // and the item prior uses sigma_u_sq, :176, :191-197)
+    double kl = -(s.ld_s * R.d + s.ld_o * R.N) / 2.;
+    kl += (h4[1] + h4[2] * T) / (2. * sigma_u_sq);
+    kl += (h4[3] + 0. * T) / (2. * sigma_u_sq);
+    kl += h4[0] / (2. * sigma_sq);
+    s.new_kl = kl;
+    s.status = ST_ACTIVE;
+    if (mode == 1) {
+        if (s.old_kl != s.old_kl) s.old_kl = kl;
+        s.cur_ld_s = s.ld_s;
+        s.cur_ld_o = s.ld_o;
+        s.accepted = 0;
+        return;
+    }
+    if (kl < s.old_kl) {
+        // accepted: the trial becomes the current point
+        const int pairs[4][2] = {{T_M_CUR, T_M_CAND}, {T_S_CUR, T_S_CAND}, {T_O_CUR, T_O_CAND}, {T_OI_CUR, T_OI_CAND}};
+        for (int p = 0; p < 4; p++) {
+            double **a = R.tab + (size_t)pairs[p][0] * R.H + h, **b = R.tab + (size_t)pairs[p][1] * R.H + h;
+            double *t = *a; *a = *b; *b = t;
+        }
+        s.lr *= 1.25;
+        if (s.old_kl - kl < .005) s.status = ST_CONVERGED;
+        if (s.steps < R.trace_cap) R.trace[(size_t)h * R.trace_cap + s.steps] = kl;
+        s.steps++;
+        s.old_kl = kl;
+        s.cur_ld_s = s.ld_s;
+        s.cur_ld_o = s.ld_o;
+        s.need_grad = 1;
+        s.accepted = 1;
+        if (s.status == ST_ACTIVE && s.max_steps >= 0 && s.steps >= s.max_steps) s.status = ST_PAUSED;
+    } else {
+        s.lr *= .5;
+        if (s.lr < 1e-10) s.status = ST_CONVERGED;
+        s.need_grad = 0;
+        s.accepted = 0;
+    }
+}
+
+// ---- S^-1 from the factor ---------------------------------------------------------------------------
+// W = L^-1 by block elimination.  With L = L_0 L_1 ... (L_k = identity except block column k),
+// L^-1 = ... L_1^-1 L_0^-1; applying L_k^-1 multiplies block row k by Linv_kk and subtracts
+// L_ik (row k) from the rows below.  Launch k (k = 0 .. nb-2) computes, for every tile (i > k,
+// j <= k):   W_ij <- W_ij - L_ik W_kj   (W_ij = 0 when j = k, W_kk = Linv_kk),
+// and the tiles of row k + 1 are multiplied by Linv_{k+1,k+1} on the way out, so that row k + 1
+// is final when launch k + 1 reads it.  Diagonal tiles of W are never stored: they are Linv_kk.
+__device__ __forceinline__ void tile_load(double (*T)[CH_NB + 1], const double *__restrict__ A, int N, int r0, int c0)
+{
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        T[r][c] = (r0 + r < N && c0 + c < N) ? A[(size_t)(r0 + r) * N + c0 + c] : 0.;
+    }
+}
+
+__device__ __forceinline__ void tile_load_dense(double (*T)[CH_NB + 1], const double *__restrict__ B)
+{
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) T[e >> 6][e & 63] = B[e];
+}
+
+// acc[u][v] += sum_c A[ty + 16u][c] * B[c][tx + 16v]
+__device__ __forceinline__ void tile_mm(double (&acc)[4][4], const double (*A)[CH_NB + 1],
+                                        const double (*B)[CH_NB + 1], int ty, int tx)
+{
+    for (int c = 0; c < 64; c++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = A[ty + 16 * u][c]; b[u] = B[c][tx + 16 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
+    }
+}
+
+// acc[u][v] += sum_c A[c][ty + 16u] * B[c][tx + 16v]      (A' B)
+__device__ __forceinline__ void tile_mm_tn(double (&acc)[4][4], const double (*A)[CH_NB + 1],
+                                           const double (*B)[CH_NB + 1], int ty, int tx)
+{
+    for (int c = 0; c < 64; c++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = A[c][ty + 16 * u]; b[u] = B[c][tx + 16 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
+    }
+}
+
+__global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__restrict__ sel, int k)
+{
+    __shared__ double A[64][CH_NB + 1], B[64][CH_NB + 1];
+    const int h = sel[blockIdx.y];
+    const int N = R.N, nb = R.nbk;
+    const int i = k + 1 + (int)blockIdx.x / (k + 1), j = (int)blockIdx.x % (k + 1);
+    const double *__restrict__ L = tabp(R, T_S_F, h);
+    double *__restrict__ W = tabp(R, T_S_W, h);
+    const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    tile_load(A, L, N, i * 64, k * 64);                                    // L_ik
+    if (j == k) tile_load_dense(B, linv + (size_t)k * CH_NB * CH_NB);      // W_kk = Linv_kk
+    else tile_load(B, W, N, k * 64, j * 64);                               // W_kj (final)
+    __syncthreads();
+    double acc[4][4] = {};
+    tile_mm(acc, A, B, ty, tx);
+    __syncthreads();
+    // out = (j < k ? W_ij : 0) - acc
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int r = i * 64 + ty + 16 * u, c = j * 64 + tx + 16 * v;
+            const double old = (j < k && r < N && c < N) ? W[(size_t)r * N + c] : 0.;
+            acc[u][v] = old - acc[u][v];
+        }
+    if (i == k + 1) {
+        // row k + 1 becomes final: multiply by Linv_{k+1,k+1} from the left
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) B[ty + 16 * u][tx + 16 * v] = acc[u][v];
+        tile_load_dense(A, linv + (size_t)(k + 1) * CH_NB * CH_NB);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[u][v] = 0.;
+        tile_mm(acc, A, B, ty, tx);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int r = i * 64 + ty + 16 * u, c = j * 64 + tx + 16 * v;
+            if (r < N && c < N) W[(size_t)r * N + c] = acc[u][v];
+        }
+}
+
+// g_S <- -(d/2) (2 - delta) S^-1,  S^-1 = W' W: tile (i >= j) = sum_{k >= i} W_ki' W_kj, both
+// triangles written.  (The sparse rating terms are added on top by kb_kl_rows / kb_finish_rows.)
+__global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restrict__ sel, double half_mult)
+{
+    __shared__ double A[64][CH_NB + 1], B[64][CH_NB + 1];
+    const int h = sel[blockIdx.y];
+    const int N = R.N, nb = R.nbk;
+    int ti, tj;
+    tri_tile((int)blockIdx.x, ti, tj);       // ti >= tj
+    const double *__restrict__ W = tabp(R, T_S_W, h);
+    double *__restrict__ G = tabp(R, T_S_GRAD, h);
+    const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    double acc[4][4] = {};
+    for (int k = ti; k < nb; k++) {
+        __syncthreads();
+        if (k == ti) tile_load_dense(A, linv + (size_t)k * CH_NB * CH_NB);
+        else tile_load(A, W, N, k * 64, ti * 64);
+        if (k == tj) tile_load_dense(B, linv + (size_t)k * CH_NB * CH_NB);
+        else tile_load(B, W, N, k * 64, tj * 64);
+        __syncthreads();
+        tile_mm_tn(acc, A, B, ty, tx);
+    }
+    // the identity padding of a short last block must not leak into the sums: rows beyond N of a
+    // padded Linv are unit vectors whose columns are beyond N too, and those outputs are dropped
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int r = ti * 64 + ty + 16 * u, c = tj * 64 + tx + 16 * v;
+            if (r < N && c < N) {
+                const double val = -half_mult * acc[u][v] * (r == c ? 1. : 2.);
+                if (ti != tj || c <= r) {
+                    G[(size_t)r * N + c] = val;
+                    if (r != c) G[(size_t)c * N + r] = val;
+                }
+            }
+        }
+}
+
+// slow hypotheses (no factor): g_S holds S^-1 from the LU route; apply the same scaling
+__global__ __launch_bounds__(256) void kb_entropy_scale(double *__restrict__ g, int N, double half_mult)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (size_t)N * N) return;
+    const int i = (int)(t / N), j = (int)(t % N);
+    g[t] = -half_mult * g[t] * (i == j ? 1. : 2.);
+}
+
+// ---- K2 inputs from the resident states ----------------------------------------------------------------
+// contiguous (B, ...) arrays of the current points of the selected hypotheses: mean (B, N, d),
+// cross (B, n, ld) = cov_useritems[:n, n:], diag (B, N), omega (B, d, d); T = double or float
+template <typename T>
+__global__ __launch_bounds__(256) void kb_extract(const Refs R, const int *__restrict__ sel, int ld,
+                                                  T *__restrict__ mean, T *__restrict__ cross,
+                                                  T *__restrict__ diag, T *__restrict__ omega)
+{
+    const int y = blockIdx.y;
+    const int h = sel ? sel[y] : y;
+    const int N = R.N, n = R.n, m = R.m, d = R.d;
+    const double *__restrict__ M = tabp(R, T_M_CUR, h);
+    const double *__restrict__ S = tabp(R, T_S_CUR, h);
+    const double *__restrict__ O = tabp(R, T_O_CUR, h);
+    const size_t n_cross = (size_t)n * ld, n_mean = (size_t)N * d, n_o = (size_t)d * d;
+    const size_t total = n_cross + n_mean + N + n_o;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        if (t < n_cross) {
+            const int i = (int)(t / ld), j = (int)(t % ld);
+            cross[(size_t)y * n_cross + t] = j < m ? (T)S[(size_t)i * N + n + j] : (T)0;
+        } else if (t < n_cross + n_mean) {
+            const size_t e = t - n_cross;
+            mean[(size_t)y * n_mean + e] = (T)M[e];
+        } else if (t < n_cross + n_mean + N) {
+            const size_t e = t - n_cross - n_mean;
+            diag[(size_t)y * N + e] = (T)S[e * N + e];
+        } else {
+            const size_t e = t - n_cross - n_mean - N;
+            omega[(size_t)y * n_o + e] = (T)O[e];
+        }
+    }
+}
+
+int dp6_for(int d)
+{
+    int dp = 4;
+    while (dp < d) dp <<= 1;
+    return dp;
+}
+
+#define DISPATCH_DP6(dp, ...)                                                  \
+    switch (dp) {                                                              \
+    case 4: { constexpr int DP = 4; __VA_ARGS__; } break;                      \
+    case 8: { constexpr int DP = 8; __VA_ARGS__; } break;                      \
+    case 16: { constexpr int DP = 16; __VA_ARGS__; } break;                    \
+    case 32: { constexpr int DP = 32; __VA_ARGS__; } break;                    \
+    case 64: { constexpr int DP = 64; __VA_ARGS__; } break;                    \
+    default: apmf_set_error("latent_d too large"); return APMF_EINVAL;         \
+    }
+
+} // namespace
+
+// ---- the batch object -------------------------------------------------------------------------------------
+struct apmf_mn_batch {
+    apmf_ctx *ctx;
+    const apmf_ratings *r;
+    Refs R;                       // device pointers
+    void *blocks[32];             // every device allocation, for destroy
+    int nblocks;
+    HypState *hs_host;            // pinned mirror
+    int *sel_host;                // pinned, 3 * H ints
+    int *sel_dev;                 // 3 * H ints
+    std::vector<char> fvalid;     // F holds the factor of the current cov_useritems
+    std::vector<char> fvalid_cand;
+    std::vector<char> oivalid;    // OI_CUR holds the inverse of the current cov_latents
+    std::vector<double *> tab_host;
+};
+
+namespace {
+
+int balloc(apmf_mn_batch *b, size_t bytes, void **out)
+{
+    APMF_TRY(apmf_malloc(b->ctx, bytes ? bytes : 8, out));
+    b->blocks[b->nblocks++] = *out;
+    return APMF_OK;
+}
+
+int upload_sel(apmf_mn_batch *b, int slot, const std::vector<int> &v, const int **d_out)
+{
+    int *hp = b->sel_host + (size_t)slot * b->R.H, *dp = b->sel_dev + (size_t)slot * b->R.H;
+    // the pinned buffer is reused every iteration: the previous copy has completed (every
+    // iteration ends with a synchronising read of the status records)
+    memcpy(hp, v.data(), v.size() * sizeof(int));
+    APMF_CHECK_HIP(hipMemcpyAsync(dp, hp, v.size() * sizeof(int), hipMemcpyHostToDevice, b->ctx->stream));
+    *d_out = dp;
+    return APMF_OK;
+}
+
+int read_status(apmf_mn_batch *b)
+{
+    APMF_CHECK_HIP(hipMemcpyAsync(b->hs_host, b->R.hs, (size_t)b->R.H * sizeof(HypState), hipMemcpyDeviceToHost,
+                                  b->ctx->stream));
+    APMF_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    return APMF_OK;
+}
+
+int read_tables(apmf_mn_batch *b)
+{
+    b->tab_host.resize((size_t)T_COUNT * b->R.H);
+    return apmf_d2h(b->ctx, b->tab_host.data(), b->R.tab, b->tab_host.size() * sizeof(double *));
+}
+
+inline dim3 g2(size_t count, int ny, int cap = 1024)
+{
+    size_t bx = (count + 255) / 256;
+    if (bx > (size_t)cap) bx = cap;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)ny);
+}
+
+// KL pieces of the point in (tm, ts, to) for the selected hypotheses: row constants, per-user
+// sums, the four totals
+int launch_value(apmf_mn_batch *b, const int *sel, int nsel, int tm, int ts, int to)
+{
+    const Refs &R = b->R;
+    hipStream_t st = b->ctx->stream;
+    hipLaunchKernelGGL(kb_rowconst, dim3((R.N + 255) / 256, nsel), dim3(256), 0, st, R, sel, tm, ts, to);
+    DISPATCH_DP6(dp6_for(R.d), hipLaunchKernelGGL((kb_value_rows<DP>), dim3((R.n + 3) / 4, nsel), dim3(256), 0, st,
+                                                 R, sel, tm, ts, b->r->ptr[0], b->r->idx[0], b->r->val[0]));
+    hipLaunchKernelGGL(kb_value_finish, dim3(nsel), dim3(256), 0, st, R, sel, tm);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+int launch_decide(apmf_mn_batch *b, const int *sel, int nsel, int mode, int forced, double sigma_sq,
+                  double sigma_u_sq)
+{
+    hipLaunchKernelGGL(kb_decide, dim3((nsel + 63) / 64), dim3(64), 0, b->ctx->stream, b->R, sel, nsel, mode, forced,
+                       sigma_sq, sigma_u_sq);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+size_t small_smem(int d) { return 2 * (size_t)d * (d + 1) * sizeof(double); }
+
+// factor the matrices already placed in F (and W when mode == 2) of the selected hypotheses
+int launch_factor(apmf_mn_batch *b, const int *sel, int nsel, int mode)
+{
+    const Refs &R = b->R;
+    hipLaunchKernelGGL(kb_make_jobs, dim3((nsel + 63) / 64), dim3(64), 0, b->ctx->stream, R, sel, nsel, mode);
+    APMF_CHECK_LAUNCH();
+    ChJobs J;
+    memset(&J, 0, sizeof(J));
+    J.list = R.jobs;
+    APMF_TRY(chol_lower_jobs(b->ctx, J, mode == 2 ? 2 * nsel : nsel, R.N));
+    hipLaunchKernelGGL(kb_logdet, dim3(nsel), dim3(256), 0, b->ctx->stream, R, sel);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+int write_ld(apmf_mn_batch *b, int h, const double *ld_s, const double *ld_o)
+{
+    char *base = (char *)(b->R.hs + h);
+    if (ld_s) APMF_TRY(apmf_h2d(b->ctx, base + offsetof(HypState, ld_s), ld_s, sizeof(double)));
+    if (ld_o) APMF_TRY(apmf_h2d(b->ctx, base + offsetof(HypState, ld_o), ld_o, sizeof(double)));
+    return APMF_OK;
+}
+
+// One hypothesis left the fast path while its point (cand when trial, else cur) was evaluated:
+// finish the projection / factorisation with the single-matrix routines of dense.hip.
+int slow_fix(apmf_mn_batch *b, int h, int slow, bool trial, double min_eig)
+{
+    const Refs &R = b->R;
+    const int H = R.H, N = R.N, d = R.d;
+    double *S = b->tab_host[(size_t)(trial ? T_S_CAND : T_S_CUR) * H + h];
+    double *O = b->tab_host[(size_t)(trial ? T_O_CAND : T_O_CUR) * H + h];
+    double *OI = b->tab_host[(size_t)(trial ? T_OI_CAND : T_OI_CUR) * H + h];
+    double *F = b->tab_host[(size_t)T_S_F * H + h];
+    char &fv = trial ? b->fvalid_cand[h] : b->fvalid[h];
+    if (slow & (SLOW_CERT_S | SLOW_FACT_S)) {
+        if (slow & SLOW_CERT_S) APMF_TRY(apmf_dense_project_psd(b->ctx, S, N, min_eig, nullptr));
+        // factor the (projected) matrix again, alone
+        APMF_CHECK_HIP(hipMemcpyAsync(F, S, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, b->ctx->stream));
+        std::vector<int> one(1, h);
+        const int *dsel;
+        APMF_TRY(upload_sel(b, 2, one, &dsel));
+        APMF_TRY(launch_factor(b, dsel, 1, 1));
+        int info = 0;
+        APMF_TRY(apmf_d2h(b->ctx, &info, R.info + 2 * h + 1, sizeof(int)));
+        if (info != 0) {
+            double ld = 0.;
+            APMF_TRY(apmf_dense_inv_logdet(b->ctx, S, N, nullptr, &ld));   // LU, like np.linalg.slogdet
+            APMF_TRY(write_ld(b, h, &ld, nullptr));
+            fv = 0;
+        } else {
+            fv = 1;
+        }
+    }
+    if (slow & (SLOW_CERT_O | SLOW_INV_O)) {
+        if (slow & SLOW_CERT_O) APMF_TRY(apmf_dense_project_psd(b->ctx, O, d, min_eig, nullptr));
+        double ld = 0.;
+        APMF_TRY(apmf_dense_inv_logdet(b->ctx, O, d, OI, &ld));
+        APMF_TRY(write_ld(b, h, nullptr, &ld));
+    }
+    return APMF_OK;
+}
+
+// after a batch of evaluations: deal with the hypotheses that left the fast path, then decide them
+int handle_slow(apmf_mn_batch *b, const std::vector<int> &evaluated, bool trial, double min_eig, double sigma_sq,
+                double sigma_u_sq)
+{
+    std::vector<int> slow;
+    for (int h : evaluated)
+        if (b->hs_host[h].status == ST_SLOW) slow.push_back(h);
+    if (slow.empty()) return APMF_OK;
+    APMF_TRY(read_tables(b));
+    for (int h : slow) APMF_TRY(slow_fix(b, h, b->hs_host[h].slow, trial, min_eig));
+    const int *dsel;
+    APMF_TRY(upload_sel(b, 2, slow, &dsel));
+    const int tm = trial ? T_M_CAND : T_M_CUR, ts = trial ? T_S_CAND : T_S_CUR, to = trial ? T_O_CAND : T_O_CUR;
+    APMF_TRY(launch_value(b, dsel, (int)slow.size(), tm, ts, to));
+    APMF_TRY(launch_decide(b, dsel, (int)slow.size(), trial ? 0 : 1, 1, sigma_sq, sigma_u_sq));
+    return read_status(b);
+}
+
+// gradient of the KL at the current point of the selected hypotheses (matrixnormal_gradient)
+int launch_gradient(apmf_mn_batch *b, const std::vector<int> &grad, double sigma_sq, double sigma_u_sq,
+                    double sigma_v_sq)
+{
+    const Refs &R = b->R;
+    hipStream_t st = b->ctx->stream;
+    const int ng = (int)grad.size();
+    std::vector<int> fast, slow;
+    for (int h : grad) (b->fvalid[h] ? fast : slow).push_back(h);
+    const int *dgrad, *dfast = nullptr;
+    APMF_TRY(upload_sel(b, 1, grad, &dgrad));
+    const double half_mult = R.d / 2.;
+    if (!slow.empty()) {
+        APMF_TRY(read_tables(b));
+        for (int h : slow) {
+            double *S = b->tab_host[(size_t)T_S_CUR * R.H + h], *G = b->tab_host[(size_t)T_S_GRAD * R.H + h];
+            APMF_TRY(apmf_dense_inv_logdet(b->ctx, S, R.N, G, nullptr));
+            hipLaunchKernelGGL(kb_entropy_scale, dim3((unsigned)(((size_t)R.N * R.N + 255) / 256)), dim3(256), 0, st, G,
+                               R.N, half_mult);
+        }
+        APMF_CHECK_LAUNCH();
+    }
+    if (!fast.empty()) {
+        if (slow.empty()) dfast = dgrad;
+        else APMF_TRY(upload_sel(b, 2, fast, &dfast));
+        const int nf = (int)fast.size();
+        for (int k = 0; k + 1 < R.nbk; k++)
+            hipLaunchKernelGGL(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), nf), dim3(256), 0, st, R, dfast, k);
+        hipLaunchKernelGGL(kb_lauum, dim3(R.nbk * (R.nbk + 1) / 2, nf), dim3(256), 0, st, R, dfast, half_mult);
+        APMF_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(kb_rowconst, dim3((R.N + 255) / 256, ng), dim3(256), 0, st, R, dgrad, (int)T_M_CUR,
+                       (int)T_S_CUR, (int)T_O_CUR);
+    const double inv_sig = 1. / sigma_sq;
+    const int dp = dp6_for(R.d);
+    DISPATCH_DP6(dp, hipLaunchKernelGGL((kb_kl_rows<DP, 0>), dim3((R.n + 3) / 4, ng), dim3(256), 0, st, R, dgrad,
+                                        b->r->ptr[0], b->r->idx[0], b->r->val[0], inv_sig));
+    DISPATCH_DP6(dp, hipLaunchKernelGGL((kb_kl_rows<DP, 1>), dim3((R.m + 3) / 4, ng), dim3(256), 0, st, R, dgrad,
+                                        b->r->ptr[1], b->r->idx[1], b->r->val[1], inv_sig));
+    hipLaunchKernelGGL(kb_finish_rows, dim3((R.N + 255) / 256, ng), dim3(256), 0, st, R, dgrad, inv_sig, sigma_u_sq,
+                       sigma_v_sq);
+    hipLaunchKernelGGL(kb_omega, dim3(R.d * R.d, ng), dim3(256), 0, st, R, dgrad, inv_sig, sigma_u_sq, sigma_v_sq);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int apmf_mn_batch_destroy(apmf_ctx *ctx, apmf_mn_batch *b)
+{
+    if (!b) return APMF_OK;
+    (void)ctx;
+    (void)hipStreamSynchronize(b->ctx->stream);
+    for (int i = 0; i < b->nblocks; i++) (void)apmf_free(b->ctx, b->blocks[i]);
+    if (b->hs_host) (void)hipHostFree(b->hs_host);
+    if (b->sel_host) (void)hipHostFree(b->sel_host);
+    delete b;
+    return APMF_OK;
+}
+
+int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int64_t trace_cap,
+                         apmf_mn_batch **out)
+{
+    APMF_REQUIRE(ctx && r && out, "NULL operand");
+    *out = nullptr;
+    APMF_REQUIRE(d >= 1 && d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
+    APMF_REQUIRE(H >= 1 && H <= 32000, "H=%d out of range (1..32000)", H);
+    APMF_REQUIRE(trace_cap >= 0 && trace_cap <= (1 << 20), "bad trace_cap");
+    apmf_mn_batch *b = new (std::nothrow) apmf_mn_batch();
+    if (!b) { apmf_set_error("out of host memory"); return APMF_ENOMEM; }
+    b->ctx = ctx;
+    b->r = r;
+    b->nblocks = 0;
+    b->hs_host = nullptr;
+    b->sel_host = nullptr;
+    Refs &R = b->R;
+    memset(&R, 0, sizeof(R));
+    R.H = H; R.n = r->n; R.m = r->m; R.d = d; R.N = r->n + r->m;
+    R.nbk = (R.N + CH_NB - 1) / CH_NB;
+    R.trace_cap = (int)trace_cap;
+    const size_t N = R.N, nn = N * N, nd = N * d, dd = (size_t)d * d, blk = (size_t)CH_NB * CH_NB;
+    double *S_store = nullptr, *M_store = nullptr, *O_store = nullptr;
+    int rc = APMF_OK;
+#define BA(ptr, bytes)                                                      \
+    if (rc == APMF_OK) rc = balloc(b, (bytes), (void **)&(ptr));
+    BA(S_store, 5 * H * nn * sizeof(double));
+    BA(M_store, 3 * H * nd * sizeof(double));
+    BA(O_store, 5 * H * dd * sizeof(double));
+    BA(R.tab, (size_t)T_COUNT * H * sizeof(double *));
+    BA(R.hs, (size_t)H * sizeof(HypState));
+    BA(R.info, (size_t)2 * H * sizeof(int));
+    BA(R.ores, (size_t)4 * H * sizeof(double));
+    BA(R.linvF, (size_t)H * R.nbk * blk * sizeof(double));
+    BA(R.linvW, (size_t)H * blk * sizeof(double));
+    BA(R.jobs, (size_t)2 * H * sizeof(ChJob));
+    BA(R.xoff, (size_t)H * nd * sizeof(double));
+    BA(R.crow, (size_t)H * N * sizeof(double));
+    BA(R.qrow, (size_t)H * N * sizeof(double));
+    BA(R.sdiag, (size_t)H * N * sizeof(double));
+    BA(R.dgv, (size_t)H * 64 * sizeof(double));
+    BA(R.racc_u, (size_t)H * R.n * (2 * d + 4) * sizeof(double));
+    BA(R.racc_v, (size_t)H * R.m * (d + 2) * sizeof(double));
+    BA(R.part, (size_t)H * R.n * 3 * sizeof(double));
+    BA(R.out4, (size_t)H * 4 * sizeof(double));
+    BA(R.oc, (size_t)H * sizeof(OmegaConsts));
+    BA(R.trace, (size_t)H * (trace_cap ? trace_cap : 1) * sizeof(double));
+    BA(R.ei, (size_t)H * sizeof(int));
+    BA(R.ej, (size_t)H * sizeof(int));
+    BA(R.ev, (size_t)H * sizeof(double));
+    BA(b->sel_dev, (size_t)3 * H * sizeof(int));
+#undef BA
+    if (rc == APMF_OK && hipHostMalloc((void **)&b->hs_host, (size_t)H * sizeof(HypState), hipHostMallocDefault) != hipSuccess)
+        rc = APMF_ENOMEM;
+    if (rc == APMF_OK && hipHostMalloc((void **)&b->sel_host, (size_t)3 * H * sizeof(int), hipHostMallocDefault) != hipSuccess)
+        rc = APMF_ENOMEM;
+    if (rc != APMF_OK) {
+        if (rc == APMF_ENOMEM) apmf_set_error("out of memory for a batch of %d hypotheses (N=%zu)", H, N);
+        apmf_mn_batch_destroy(ctx, b);
+        return rc;
+    }
+    // canonical pointer tables
+    std::vector<double *> tab((size_t)T_COUNT * H);
+    for (int h = 0; h < H; h++) {
+        tab[(size_t)T_M_CUR * H + h] = M_store + ((size_t)0 * H + h) * nd;
+        tab[(size_t)T_M_CAND * H + h] = M_store + ((size_t)1 * H + h) * nd;
+        tab[(size_t)T_M_GRAD * H + h] = M_store + ((size_t)2 * H + h) * nd;
+        tab[(size_t)T_S_CUR * H + h] = S_store + ((size_t)0 * H + h) * nn;
+        tab[(size_t)T_S_CAND * H + h] = S_store + ((size_t)1 * H + h) * nn;
+        tab[(size_t)T_S_GRAD * H + h] = S_store + ((size_t)2 * H + h) * nn;
+        tab[(size_t)T_S_F * H + h] = S_store + ((size_t)3 * H + h) * nn;
+        tab[(size_t)T_S_W * H + h] = S_store + ((size_t)4 * H + h) * nn;
+        tab[(size_t)T_O_CUR * H + h] = O_store + ((size_t)0 * H + h) * dd;
+        tab[(size_t)T_O_CAND * H + h] = O_store + ((size_t)1 * H + h) * dd;
+        tab[(size_t)T_O_GRAD * H + h] = O_store + ((size_t)2 * H + h) * dd;
+        tab[(size_t)T_OI_CUR * H + h] = O_store + ((size_t)3 * H + h) * dd;
+        tab[(size_t)T_OI_CAND * H + h] = O_store + ((size_t)4 * H + h) * dd;
+    }
+    rc = apmf_h2d(ctx, R.tab, tab.data(), tab.size() * sizeof(double *));
+    if (rc == APMF_OK) rc = apmf_memset(ctx, R.ei, 0xFF, (size_t)H * sizeof(int));     // -1: no extra rating
+    if (rc == APMF_OK) rc = apmf_memset(ctx, R.ej, 0xFF, (size_t)H * sizeof(int));
+    if (rc == APMF_OK) rc = apmf_memset(ctx, R.ev, 0, (size_t)H * sizeof(double));
+    if (rc != APMF_OK) {
+        apmf_mn_batch_destroy(ctx, b);
+        return rc;
+    }
+    memset(b->hs_host, 0, (size_t)H * sizeof(HypState));
+    if (small_smem(d) > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)kb_small_spd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)small_smem(d));
+    b->fvalid.assign(H, 0);
+    b->fvalid_cand.assign(H, 0);
+    b->oivalid.assign(H, 0);
+    *out = b;
+    return APMF_OK;
+}
+
+int apmf_mn_batch_size(const apmf_mn_batch *b, int *H, int *n, int *m, int *d)
+{
+    APMF_REQUIRE(b, "NULL batch");
+    if (H) *H = b->R.H;
+    if (n) *n = b->R.n;
+    if (m) *m = b->R.m;
+    if (d) *d = b->R.d;
+    return APMF_OK;
+}
+
+int apmf_mn_batch_set_state(apmf_ctx *ctx, apmf_mn_batch *b, const double *d_mean, const double *d_cov_useritems,
+                            const double *d_cov_latents, int per_hypothesis)
+{
+    APMF_REQUIRE(ctx && b, "NULL operand");
+    const Refs &R = b->R;
+    const size_t nn = (size_t)R.N * R.N, nd = (size_t)R.N * R.d, dd = (size_t)R.d * R.d;
+    hipStream_t st = b->ctx->stream;
+    const int p = per_hypothesis;
+    if (d_mean)
+        hipLaunchKernelGGL(kb_fill, g2(nd, R.H, 64), dim3(256), 0, st, R, (int)T_M_CUR, d_mean, (p & 1) ? nd : 0, nd);
+    if (d_cov_useritems) {
+        hipLaunchKernelGGL(kb_fill, g2(nn, R.H, 256), dim3(256), 0, st, R, (int)T_S_CUR, d_cov_useritems,
+                           (p & 2) ? nn : 0, nn);
+        std::fill(b->fvalid.begin(), b->fvalid.end(), 0);
+    }
+    if (d_cov_latents) {
+        hipLaunchKernelGGL(kb_fill, g2(dd, R.H, 4), dim3(256), 0, st, R, (int)T_O_CUR, d_cov_latents,
+                           (p & 4) ? dd : 0, dd);
+        std::fill(b->oivalid.begin(), b->oivalid.end(), 0);
+    }
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}
+
+int apmf_mn_batch_set_extra(apmf_ctx *ctx, apmf_mn_batch *b, const int32_t *h_i, const int32_t *h_j,
+                            const double *h_v)
+{
+    APMF_REQUIRE(ctx && b, "NULL operand");
+    const Refs &R = b->R;
+    if (!h_i) {
+        APMF_TRY(apmf_memset(ctx, R.ei, 0xFF, (size_t)R.H * sizeof(int)));
+        APMF_TRY(apmf_memset(ctx, R.ej, 0xFF, (size_t)R.H * sizeof(int)));
+        return APMF_OK;
+    }
+    APMF_REQUIRE(h_j && h_v, "NULL operand");
+    for (int h = 0; h < R.H; h++)
+        APMF_REQUIRE(h_i[h] < R.n && h_j[h] < R.m && (h_i[h] >= 0) == (h_j[h] >= 0),
+                     "extra rating %d: (%d, %d) out of range", h, h_i[h], h_j[h]);
+    APMF_TRY(apmf_h2d(ctx, R.ei, h_i, (size_t)R.H * sizeof(int)));
+    APMF_TRY(apmf_h2d(ctx, R.ej, h_j, (size_t)R.H * sizeof(int)));
+    APMF_TRY(apmf_h2d(ctx, R.ev, h_v, (size_t)R.H * sizeof(double)));
+    return APMF_OK;
+}
+
+int apmf_mn_batch_get_state(apmf_ctx *ctx, apmf_mn_batch *b, int h, double *d_mean, double *d_cov_useritems,
+                            double *d_cov_latents)
+{
+    APMF_REQUIRE(ctx && b, "NULL operand");
+    const Refs &R = b->R;
+    APMF_REQUIRE(h >= 0 && h < R.H, "hypothesis %d out of range", h);
+    APMF_TRY(read_tables(b));
+    const size_t nn = (size_t)R.N * R.N, nd = (size_t)R.N * R.d, dd = (size_t)R.d * R.d;
+    if (d_mean) APMF_TRY(apmf_d2d(ctx, d_mean, b->tab_host[(size_t)T_M_CUR * R.H + h], nd * sizeof(double)));
+    if (d_cov_useritems)
+        APMF_TRY(apmf_d2d(ctx, d_cov_useritems, b->tab_host[(size_t)T_S_CUR * R.H + h], nn * sizeof(double)));
+    if (d_cov_latents) APMF_TRY(apmf_d2d(ctx, d_cov_latents, b->tab_host[(size_t)T_O_CUR * R.H + h], dd * sizeof(double)));
+    return APMF_OK;
+}
+
+// fit_normal_kls() / fit_normal() for every hypothesis of the batch (mn_active_pmf.py:236-288).
+// h_lr / h_old_kl (H each) carry the search state in and out (NaN old_kl: evaluate at entry);
+// max_steps accepted steps per hypothesis at most (< 0: until convergence).
+int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                      double min_eig, double *h_lr, double *h_old_kl, int64_t max_steps, double *h_kl_trace,
+                      int64_t *h_steps, int *h_converged)
+{
+    APMF_REQUIRE(ctx && b && h_lr && h_old_kl, "NULL operand");
+    APMF_REQUIRE(ctx == b->ctx, "batch belongs to another context");
+    APMF_REQUIRE(sigma_sq != 0. && sigma_u_sq != 0. && sigma_v_sq != 0., "zero variance");
+    const Refs &R = b->R;
+    const int H = R.H;
+    hipStream_t st = ctx->stream;
+    for (int h = 0; h < H; h++) {
+        HypState &s = b->hs_host[h];      // cur_ld_s / cur_ld_o survive from the previous call
+        s.lr = h_lr[h];
+        s.old_kl = h_old_kl[h];
+        s.new_kl = 0.;
+        s.steps = 0;
+        s.max_steps = max_steps;
+        s.status = ST_ACTIVE;
+        s.need_grad = 1;
+        s.slow = 0;
+        s.accepted = 0;
+    }
+    // a hypothesis whose KL is known AND whose factor / inverse are in place resumes directly
+    std::vector<int> init;
+    for (int h = 0; h < H; h++)
+        if (!b->fvalid[h] || !b->oivalid[h] || b->hs_host[h].old_kl != b->hs_host[h].old_kl) init.push_back(h);
+    APMF_CHECK_HIP(hipMemcpyAsync(R.hs, b->hs_host, (size_t)H * sizeof(HypState), hipMemcpyHostToDevice, st));
+    if (!init.empty()) {
+        const int *dsel;
+        const int ni = (int)init.size();
+        APMF_TRY(upload_sel(b, 0, init, &dsel));
+        hipLaunchKernelGGL(kb_copy, g2((size_t)R.N * R.N, ni, 256), dim3(256), 0, st, R, dsel, (int)T_S_CUR,
+                           (int)T_S_F, (size_t)R.N * R.N);
+        APMF_TRY(launch_factor(b, dsel, ni, 1));
+        hipLaunchKernelGGL(kb_small_spd, dim3(ni), dim3(64), small_smem(R.d), st, R, dsel, (int)T_O_CUR, (int)T_OI_CUR,
+                           0, min_eig);
+        APMF_TRY(launch_value(b, dsel, ni, T_M_CUR, T_S_CUR, T_O_CUR));
+        APMF_TRY(launch_decide(b, dsel, ni, 1, 0, sigma_sq, sigma_u_sq));
+        APMF_TRY(read_status(b));
+        for (int h : init) { b->fvalid[h] = 1; b->oivalid[h] = 1; }
+        APMF_TRY(handle_slow(b, init, false, min_eig, sigma_sq, sigma_u_sq));
+        for (int h : init) b->oivalid[h] = 1;
+    } else {
+        APMF_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    if (max_steps == 0)
+        for (int h = 0; h < H; h++) b->hs_host[h].status = ST_PAUSED;
+    std::vector<int> active, grad;
+    for (;;) {
+        active.clear();
+        grad.clear();
+        for (int h = 0; h < H; h++)
+            if (b->hs_host[h].status == ST_ACTIVE) {
+                active.push_back(h);
+                if (b->hs_host[h].need_grad) grad.push_back(h);
+            }
+        if (active.empty()) break;
+        if (!grad.empty()) APMF_TRY(launch_gradient(b, grad, sigma_sq, sigma_u_sq, sigma_v_sq));
+        const int na = (int)active.size();
+        const int *dsel;
+        APMF_TRY(upload_sel(b, 0, active, &dsel));
+        const int nt32 = (R.N + 31) / 32;
+        hipLaunchKernelGGL(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig);
+        hipLaunchKernelGGL(kb_trial_small, dim3((unsigned)(((size_t)R.N * R.d + (size_t)R.d * R.d + 255) / 256), na),
+                           dim3(256), 0, st, R, dsel);
+        APMF_CHECK_LAUNCH();
+        APMF_TRY(launch_factor(b, dsel, na, 2));
+        hipLaunchKernelGGL(kb_small_spd, dim3(na), dim3(64), small_smem(R.d), st, R, dsel, (int)T_O_CAND,
+                           (int)T_OI_CAND, 1, min_eig);
+        APMF_TRY(launch_value(b, dsel, na, T_M_CAND, T_S_CAND, T_O_CAND));
+        APMF_TRY(launch_decide(b, dsel, na, 0, 0, sigma_sq, sigma_u_sq));
+        APMF_TRY(read_status(b));
+        for (int h : active) b->fvalid_cand[h] = 1;
+        APMF_TRY(handle_slow(b, active, true, min_eig, sigma_sq, sigma_u_sq));
+        // F holds the factor of the trial point: the current one's only if the trial was accepted
+        for (int h : active) b->fvalid[h] = b->hs_host[h].accepted ? b->fvalid_cand[h] : 0;
+    }
+    for (int h = 0; h < H; h++) {
+        const HypState &s = b->hs_host[h];
+        h_lr[h] = s.lr;
+        h_old_kl[h] = s.old_kl;
+        if (h_steps) h_steps[h] = s.steps;
+        if (h_converged) h_converged[h] = s.status == ST_CONVERGED ? 1 : 0;
+    }
+    if (h_kl_trace && R.trace_cap > 0)
+        APMF_TRY(apmf_d2h(ctx, h_kl_trace, R.trace, (size_t)H * R.trace_cap * sizeof(double)));
+    return APMF_OK;
+}
+
+// KL(approximation || model) of the current point of every hypothesis (no step is taken)
+int apmf_mn_batch_kl(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                     double *h_kl)
+{
+    APMF_REQUIRE(ctx && b && h_kl, "NULL operand");
+    const int H = b->R.H;
+    std::vector<double> lr(H, 0.), kl(H, NAN);
+    APMF_TRY(apmf_mn_batch_fit(ctx, b, sigma_sq, sigma_u_sq, sigma_v_sq, 0., lr.data(), kl.data(), 0, nullptr, nullptr,
+                               nullptr));
+    memcpy(h_kl, kl.data(), (size_t)H * sizeof(double));
+    return APMF_OK;
+}
+
+// gradient of the KL at the current point of hypothesis h into caller buffers (matrixnormal_gradient)
+int apmf_mn_batch_gradient(apmf_ctx *ctx, apmf_mn_batch *b, int h, double sigma_sq, double sigma_u_sq,
+                           double sigma_v_sq, double *d_g_mean, double *d_g_cov_useritems, double *d_g_cov_latents)
+{
+    APMF_REQUIRE(ctx && b, "NULL operand");
+    const Refs &R = b->R;
+    APMF_REQUIRE(h >= 0 && h < R.H, "hypothesis %d out of range", h);
+    // make sure the factor and the d x d inverse of the current point are in place
+    std::vector<double> kl(R.H);
+    APMF_TRY(apmf_mn_batch_kl(ctx, b, sigma_sq, sigma_u_sq, sigma_v_sq, kl.data()));
+    std::vector<int> one(1, h);
+    APMF_TRY(launch_gradient(b, one, sigma_sq, sigma_u_sq, sigma_v_sq));
+    APMF_TRY(read_tables(b));
+    const size_t nn = (size_t)R.N * R.N, nd = (size_t)R.N * R.d, dd = (size_t)R.d * R.d;
+    if (d_g_mean) APMF_TRY(apmf_d2d(ctx, d_g_mean, b->tab_host[(size_t)T_M_GRAD * R.H + h], nd * sizeof(double)));
+    if (d_g_cov_useritems)
+        APMF_TRY(apmf_d2d(ctx, d_g_cov_useritems, b->tab_host[(size_t)T_S_GRAD * R.H + h], nn * sizeof(double)));
+    if (d_g_cov_latents)
+        APMF_TRY(apmf_d2d(ctx, d_g_cov_latents, b->tab_host[(size_t)T_O_GRAD * R.H + h], dd * sizeof(double)));
+    return APMF_OK;
+}
+
+// _approx_entropy() of every hypothesis (mn_active_pmf.py:513-521):
+// (d log|cov_useritems| + (n+m) log|cov_latents|) / 2, from the factorisations of the last fit
+int apmf_mn_batch_entropy(apmf_ctx *ctx, apmf_mn_batch *b, double *h_out)
+{
+    APMF_REQUIRE(ctx && b && h_out, "NULL operand");
+    const Refs &R = b->R;
+    for (int h = 0; h < R.H; h++)
+        APMF_REQUIRE(b->oivalid[h], "entropy needs a fit (or apmf_mn_batch_kl) of the current states first");
+    APMF_TRY(read_status(b));
+    for (int h = 0; h < R.H; h++)
+        h_out[h] = 0.5 * (R.d * b->hs_host[h].cur_ld_s + R.N * b->hs_host[h].cur_ld_o);
+    return APMF_OK;
+}
+
+// Candidate-grid sweep (K2) straight from the resident states: hypotheses [h0, h0 + B) are
+// packed into K2's operand layout on the device and swept in one launch.  Outputs as in
+// apmf_mn_score_grid_f64 / _f32 (use_f32: float32 sweep, d_var / d_pmean / d_best_val are float).
+int apmf_mn_batch_score_grid(apmf_ctx *ctx, apmf_mn_batch *b, int h0, int B, int use_f32, int ld,
+                             const uint8_t *d_mask, void *d_var, void *d_pmean, double *d_sum, int want,
+                             void *d_best_val, int64_t *d_best_idx)
+{
+    APMF_REQUIRE(ctx && b, "NULL operand");
+    const Refs &R = b->R;
+    APMF_REQUIRE(h0 >= 0 && B >= 1 && h0 + B <= R.H, "hypotheses [%d, %d) out of range", h0, h0 + B);
+    APMF_REQUIRE(ld >= R.m && ld % APMF_GRID_ALIGN == 0, "bad grid pitch %d", ld);
+    const size_t isz = use_f32 ? 4 : 8;
+    const size_t n_cross = (size_t)R.n * ld, n_mean = (size_t)R.N * R.d, n_o = (size_t)R.d * R.d;
+    const size_t per = n_cross + n_mean + R.N + n_o;
+    void *pack = nullptr;
+    APMF_TRY(apmf_malloc(ctx, (size_t)B * per * isz + 256, &pack));
+    std::vector<int> sel(B);
+    for (int y = 0; y < B; y++) sel[y] = h0 + y;
+    const int *dsel = nullptr;
+    int rc = APMF_OK;
+    // contiguous selection list: reuse slot 0 (no fit is in flight on this stream between calls)
+    rc = upload_sel(b, 0, sel, &dsel);
+    char *p = (char *)pack;
+    void *cross = p;                      // first: 16-byte aligned
+    void *mean = p + (size_t)B * n_cross * isz;
+    void *diag = (char *)mean + (size_t)B * n_mean * isz;
+    void *omega = (char *)diag + (size_t)B * R.N * isz;
+    if (rc == APMF_OK) {
+        if (use_f32) {
+            hipLaunchKernelGGL((kb_extract<float>), g2(per, B, 512), dim3(256), 0, ctx->stream, R, dsel, ld,
+                               (float *)mean, (float *)cross, (float *)diag, (float *)omega);
+            rc = apmf_mn_score_grid_f32(ctx, B, R.n, R.m, R.d, ld, (const float *)mean, (const float *)cross,
+                                        (const float *)diag, (const float *)omega, d_mask, (float *)d_var,
+                                        (float *)d_pmean, d_sum, want, (float *)d_best_val, d_best_idx);
+        } else {
+            hipLaunchKernelGGL((kb_extract<double>), g2(per, B, 512), dim3(256), 0, ctx->stream, R, dsel, ld,
+                               (double *)mean, (double *)cross, (double *)diag, (double *)omega);
+            rc = apmf_mn_score_grid_f64(ctx, B, R.n, R.m, R.d, ld, (const double *)mean, (const double *)cross,
+                                        (const double *)diag, (const double *)omega, d_mask, (double *)d_var,
+                                        (double *)d_pmean, d_sum, want, (double *)d_best_val, d_best_idx);
+        }
+    }
+    (void)apmf_free(ctx, pack);      // stream-ordered reuse
+    return rc;
+}
+
+// _total_variance() of every hypothesis (mn_active_pmf.py:597-598): the sum of the predictive
+// variance over the WHOLE n x m grid, one float64 sweep with B = H (chunked to bound the pack)
+int apmf_mn_batch_total_variance(apmf_ctx *ctx, apmf_mn_batch *b, double *h_out)
+{
+    APMF_REQUIRE(ctx && b && h_out, "NULL operand");
+    const Refs &R = b->R;
+    const int ld = round_up(R.m, APMF_GRID_ALIGN);
+    double *d_sum = nullptr;
+    APMF_TRY(apmf_malloc(ctx, (size_t)R.H * sizeof(double), (void **)&d_sum));
+    const size_t per = ((size_t)R.n * ld + (size_t)R.N * (R.d + 1) + (size_t)R.d * R.d) * sizeof(double);
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)R.H, ((size_t)4 << 30) / per));
+    int rc = APMF_OK;
+    for (int h0 = 0; h0 < R.H && rc == APMF_OK; h0 += chunk) {
+        const int B = std::min(chunk, R.H - h0);
+        rc = apmf_mn_batch_score_grid(ctx, b, h0, B, 0, ld, nullptr, nullptr, nullptr, d_sum + h0, 0, nullptr, nullptr);
+    }
+    if (rc == APMF_OK) rc = apmf_d2h(ctx, h_out, d_sum, (size_t)R.H * sizeof(double));
+    (void)apmf_free(ctx, d_sum);
+    return rc;
+}
+
+// fit_normal_kls() / fit_normal() of ONE model whose approximation lives in caller buffers
+// (include/apmf.h): a batch of one, so that the product's own fit and the lookahead's H fits are
+// the same code.  d_mean / d_cov_useritems / d_cov_latents are updated in place.
+int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_mean, double *d_cov_useritems,
+                       double *d_cov_latents, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                       double min_eig, double *h_lr, double *h_old_kl, int64_t max_steps, double *h_kl_trace,
+                       int64_t trace_cap, int64_t *h_steps, int *h_converged)
+{
+    APMF_REQUIRE(ctx && r && d_mean && d_cov_useritems && d_cov_latents && h_lr && h_old_kl && h_steps &&
+                     h_converged, "NULL operand");
+    APMF_REQUIRE(trace_cap == 0 || h_kl_trace, "h_kl_trace is NULL");
+    apmf_mn_batch *b = nullptr;
+    const int64_t cap = std::min<int64_t>(trace_cap, 1 << 20);
+    APMF_TRY(apmf_mn_batch_create(ctx, r, d, 1, cap, &b));
+    int rc = apmf_mn_batch_set_state(ctx, b, d_mean, d_cov_useritems, d_cov_latents, 0);
+    if (rc == APMF_OK)
+        rc = apmf_mn_batch_fit(ctx, b, sigma_sq, sigma_u_sq, sigma_v_sq, min_eig, h_lr, h_old_kl, max_steps,
+                               h_kl_trace, h_steps, h_converged);
+    if (rc == APMF_OK && *h_steps > 0) rc = apmf_mn_batch_get_state(ctx, b, 0, d_mean, d_cov_useritems, d_cov_latents);
+    if (rc == APMF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        apmf_set_error("stream synchronisation failed");
+        rc = APMF_EHIP;
+    }
+    (void)apmf_mn_batch_destroy(ctx, b);
+    return rc;
+}
+
+} // extern "C"

@@ -272,6 +272,60 @@ int apmf_mn_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_me
                        double *h_old_kl, int64_t max_steps, double *h_kl_trace, int64_t trace_cap,
                        int64_t *h_steps, int *h_converged);
 
+/* ---- batched variational fits: the one-step lookahead (libapmf_dense.so) ----------------------
+ * Replaces the body of _exp_with_rij's calculate_fn mapped over the pool (mn_active_pmf.py:660-672,
+ * 749-755): for every hypothesis "entry (i, j) turns out to be v"
+ *     deepcopy(model) -> add_rating(i, j, v) -> fit_normal() -> fn(model)
+ * A batch holds H matrix-normal approximations of the same shape resident on the device; every
+ * launch of the fit advances all of them (the hypothesis is a grid dimension), and the accept /
+ * reject search state of each is device state.  A hypothesis may carry ONE rating on top of the
+ * shared ratings container - it is treated as the last entry of its user row and item row, which
+ * is where add_rating() (pmf_cy.pyx:128-156) followed by a rebuilt container puts it, so a
+ * batched fit is bit-identical to the same fit run alone.  H = 1 without an extra rating is
+ * MNActivePMF.fit_normal itself (apmf_mn_fit_normal above is that case).
+ * `r` must outlive the batch.  trace_cap: KL values kept per hypothesis (0: none). */
+typedef struct apmf_mn_batch apmf_mn_batch;
+int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int64_t trace_cap,
+                         apmf_mn_batch **out);
+int apmf_mn_batch_destroy(apmf_ctx *ctx, apmf_mn_batch *b);
+int apmf_mn_batch_size(const apmf_mn_batch *b, int *H, int *n, int *m, int *d);
+/* Current point of every hypothesis: d_mean (n+m, d), d_cov_useritems (n+m, n+m), d_cov_latents
+ * (d, d), each nullable (= leave as is).  per_hypothesis bit 0 / 1 / 2: the mean / cov_useritems /
+ * cov_latents argument holds H consecutive arrays instead of one shared by all hypotheses. */
+int apmf_mn_batch_set_state(apmf_ctx *ctx, apmf_mn_batch *b, const double *d_mean,
+                            const double *d_cov_useritems, const double *d_cov_latents,
+                            int per_hypothesis);
+/* The extra rating (h_i[h], h_j[h], h_v[h]) of every hypothesis; h_i[h] < 0 (or h_i == NULL): none.
+ * The entry must not be rated in `r` (add_rating raises ValueError; not checked here). */
+int apmf_mn_batch_set_extra(apmf_ctx *ctx, apmf_mn_batch *b, const int32_t *h_i, const int32_t *h_j,
+                            const double *h_v);
+/* Copy the current point of hypothesis h out (device to device; each nullable). */
+int apmf_mn_batch_get_state(apmf_ctx *ctx, apmf_mn_batch *b, int h, double *d_mean,
+                            double *d_cov_useritems, double *d_cov_latents);
+/* fit_normal_kls() / fit_normal() (mn_active_pmf.py:236-288) for all H hypotheses.  h_lr, h_old_kl
+ * (H each) carry the search state in and out (NaN old_kl: evaluate the KL at entry, as the
+ * reference does before its loop); at most max_steps accepted steps per hypothesis (< 0: until
+ * convergence, 0: only evaluate).  h_kl_trace (H, trace_cap), h_steps (H), h_converged (H): nullable. */
+int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double sigma_u_sq,
+                      double sigma_v_sq, double min_eig, double *h_lr, double *h_old_kl,
+                      int64_t max_steps, double *h_kl_trace, int64_t *h_steps, int *h_converged);
+/* kl_divergence() of every current point (mn_kl_divergence, matrix_normal_exps_cy.pyx:159-213). */
+int apmf_mn_batch_kl(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double sigma_u_sq,
+                     double sigma_v_sq, double *h_kl);
+/* matrixnormal_gradient() at the current point of hypothesis h, into caller buffers. */
+int apmf_mn_batch_gradient(apmf_ctx *ctx, apmf_mn_batch *b, int h, double sigma_sq, double sigma_u_sq,
+                           double sigma_v_sq, double *d_g_mean, double *d_g_cov_useritems,
+                           double *d_g_cov_latents);
+/* _total_variance() (mn_active_pmf.py:597-598) and _approx_entropy() (:513-521) of every
+ * hypothesis: h_out (H).  The sweep is K2 with B = H, straight from the resident states. */
+int apmf_mn_batch_total_variance(apmf_ctx *ctx, apmf_mn_batch *b, double *h_out);
+int apmf_mn_batch_entropy(apmf_ctx *ctx, apmf_mn_batch *b, double *h_out);
+/* K2 over hypotheses [h0, h0 + B) from the resident states; outputs as apmf_mn_score_grid_f64
+ * (use_f32 = 0: double grids / best value) or _f32 (use_f32 = 1: float), leading dimension B. */
+int apmf_mn_batch_score_grid(apmf_ctx *ctx, apmf_mn_batch *b, int h0, int B, int use_f32, int ld,
+                             const uint8_t *d_mask, void *d_var, void *d_pmean, double *d_sum,
+                             int want, void *d_best_val, int64_t *d_best_idx);
+
 /* normal_gradient() / _normal_grad(), normal_exps_cy.pyx:140-303: gradient of the KL of the
  * full-covariance approximation (ActivePMF.fit_normal) w.r.t. mean (K) and cov (K x K),
  * K = (n+m) d, stacked as u[k,i] = i d + k, v[k,j] = n d + j d + k (active_pmf.py:141-142).

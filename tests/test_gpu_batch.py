@@ -1,0 +1,239 @@
+"""The batched variational-fit engine (csrc/k6_batch.hip, apmf_mn_batch_*) through the C-ABI:
+its KL / gradient against the reference's recorded values and an independent NumPy
+restatement, and - the property the lookahead relies on - a batch of H hypotheses giving
+bit-for-bit what each hypothesis gives when fitted alone on a ratings container that was
+rebuilt with its extra rating (deepcopy -> add_rating -> fit_normal, mn_active_pmf.py:660-668).
+Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from active_matrix_factorization_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _problem(n, m, d, seed, per_row=3):
+    rs = np.random.RandomState(seed)
+    N = n + m
+    pairs = rs.permutation(n * m)[:min(n * m // 2, per_row * N)]
+    ii = np.concatenate([np.arange(n), pairs // m])
+    jj = np.concatenate([rs.randint(0, m, n), pairs % m])
+    # every item rated at least once too
+    ii = np.concatenate([ii, rs.randint(0, n, m)])
+    jj = np.concatenate([jj, np.arange(m)])
+    keep = np.sort(np.unique(ii * m + jj, return_index=True)[1])
+    ii, jj = ii[keep], jj[keep]
+    ratings = np.column_stack([ii, jj, rs.randint(1, 6, ii.size)]).astype(float)
+    mean = rs.normal(size=(N, d))
+    A = rs.normal(size=(N, N)) / np.sqrt(N)
+    S = A @ A.T + .3 * np.eye(N)
+    B = rs.normal(size=(d, d)) / np.sqrt(d)
+    O = B @ B.T + .2 * np.eye(d)
+    return rs, ratings, mean, S, O
+
+
+def _unrated(rs, ratings, n, m, count):
+    rated = set(zip(ratings[:, 0].astype(int), ratings[:, 1].astype(int)))
+    out = []
+    while len(out) < count:
+        i, j = int(rs.randint(n)), int(rs.randint(m))
+        if (i, j) not in rated and (i, j) not in out:
+            out.append((i, j))
+    return out
+
+
+@pytest.mark.parametrize('shape', [(7, 5, 1), (13, 9, 2), (30, 41, 5), (40, 33, 16), (70, 90, 5), (100, 131, 10)])
+def test_batch_kl_and_gradient_vs_numpy(ctx, shape):
+    """KL value and gradient of the batch engine at H = 3 (same state, three different extra
+    ratings) vs tests/mn_grad_numpy.py on the ratings with the extra one appended; sizes on both
+    sides of one 64-column Cholesky panel (N = 12 ... 231: 1 to 4 panels)."""
+    import mn_grad_numpy as ref
+    n, m, d = shape
+    N = n + m
+    rs, ratings, mean, S, O = _problem(n, m, d, 1000 * n + d)
+    sig, su, sv = 0.7, 4.0, 6.0
+    extras = _unrated(rs, ratings, n, m, 2)
+    vals = [3.0, 1.0]
+    rt = ctx.ratings(ratings, n, m)
+    b = ctx.mn_batch(rt, d, 3)
+    b.set_state(ctx.array(mean), ctx.array(S), ctx.array(O))
+    b.set_extra([extras[0][0], extras[1][0], -1], [extras[0][1], extras[1][1], -1], vals + [0.])
+    kls = b.kl(sig, su, sv)
+    trO = np.trace(O)
+    for h in range(3):
+        rr = ratings if h == 2 else np.vstack([ratings, [extras[h][0], extras[h][1], vals[h]]])
+        bit = 0.
+        for i, j, r in rr:
+            i, j = int(i), int(j)
+            e2 = orc.mn_exp_dotprod_sq(n, mean, S, O, i, j)
+            bit += e2 - 2 * r * ((mean[i] * mean[n + j]).sum() + S[i, n + j] * trO) + r * r
+        ref_kl = (-(np.linalg.slogdet(S)[1] * d + np.linalg.slogdet(O)[1] * N) / 2.
+                  + ((mean[:n] ** 2).sum() + np.trace(S[:n, :n]) * trO) / (2 * su)
+                  + ((mean[n:] ** 2).sum()) / (2 * su) + bit / (2 * sig))
+        assert abs(kls[h] - ref_kl) <= 1e-10 * abs(ref_kl), (h, kls[h], ref_kl)
+        gm, gs, go = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+        b.gradient(h, sig, su, sv, gm, gs, go)
+        rm, rsg, ro = ref._mnormal_grad(mean, S, O, rr, n, d, sig, su, sv)
+        np.testing.assert_allclose(gm.to_host(), rm, rtol=1e-10, atol=1e-10 * np.abs(rm).max())
+        np.testing.assert_allclose(gs.to_host(), rsg, rtol=1e-9, atol=1e-10 * np.abs(rsg).max())
+        np.testing.assert_allclose(go.to_host(), ro, rtol=1e-9, atol=1e-10 * np.abs(ro).max())
+    # entropy = (d log|S| + N log|O|) / 2  (mn_active_pmf.py:513-521)
+    ent = b.entropy()
+    ref_ent = 0.5 * (d * np.linalg.slogdet(S)[1] + N * np.linalg.slogdet(O)[1])
+    np.testing.assert_allclose(ent, ref_ent, rtol=1e-11)
+    # total variance = sum of the oracle's variance grid
+    _, pv = orc.mn_pred_means_vars(n, m, mean, S, O)
+    np.testing.assert_allclose(b.total_variance(), pv.sum(), rtol=1e-11)
+    b.free()
+
+
+@pytest.mark.parametrize('name', ['mn_c1_10x10_d2_eye', 'mn_c1_10x10_d2_rand', 'mn_24x17_d5_rand'])
+def test_batch_fit_golden_trace(ctx, name):
+    """Three accepted fit_normal_kls steps of the reference (mn_active_pmf.py:242-288), run as
+    hypothesis 1 of a batch of 3 whose other members carry extra ratings."""
+    g = load_golden(name)
+    ratings = g['ratings']
+    n, m = g['users'].shape[0], g['items'].shape[0]
+    d = int(g['d'])
+    sig, su, sv = (float(x) for x in g['sigma'])
+    rs = np.random.RandomState(5)
+    ex = _unrated(rs, ratings, n, m, 2)
+    steps = g['kl_trace'].size
+    rt = ctx.ratings(ratings, n, m)
+    b = ctx.mn_batch(rt, d, 3, trace_cap=steps)
+    b.set_state(ctx.array(g['mean']), ctx.array(g['cov_useritems']), ctx.array(g['cov_latents']))
+    b.set_extra([ex[0][0], -1, ex[1][0]], [ex[0][1], -1, ex[1][1]], [2., 0., 4.])
+    lr, kl, nsteps, conv, trace = b.fit(sig, su, sv, 1e-5, 1e-4, max_steps=steps)
+    assert nsteps[1] == steps
+    np.testing.assert_allclose(trace[1], g['kl_trace'], rtol=1e-8)
+    N = n + m
+    dm, ds, do = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+    b.get_state(1, dm, ds, do)
+    np.testing.assert_allclose(dm.to_host(), g['mean_fit'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(ds.to_host(), g['cov_useritems_fit'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(do.to_host(), g['cov_latents_fit'], rtol=1e-6, atol=1e-8)
+    b.free()
+
+
+def _fit_alone(ctx, ratings, n, m, d, mean, S, O, sig, su, sv, max_steps, cap):
+    rt = ctx.ratings(ratings, n, m)
+    dm, ds, do = ctx.array(mean), ctx.array(S), ctx.array(O)
+    trace, steps, lr, conv, kl = ctx.mn_fit_normal(rt, d, dm, ds, do, sig, su, sv, 1e-5, 1e-4,
+                                                   max_steps=max_steps, max_trace=cap)
+    return dm.to_host(), ds.to_host(), do.to_host(), trace, steps, lr, conv, kl
+
+
+@pytest.mark.parametrize('shape,max_steps', [((24, 17, 5), 25), ((94, 425, 5), 6), ((60, 75, 3), -1)])
+def test_batched_equals_alone_bitwise(ctx, shape, max_steps):
+    """H hypotheses fitted in one batch == each fitted alone on a container rebuilt with its extra
+    rating appended (what deepcopy + add_rating + fit_normal does): states, KL traces, step counts
+    and learning rates bit-for-bit.  (94, 425, 5) is BASELINE.json configs[3]'s shape."""
+    n, m, d = shape
+    N = n + m
+    rs, ratings, mean, S, O = _problem(n, m, d, 77 + n, per_row=2)
+    # identity-like start, as initialize_approx() gives: the fit then runs many accepted steps
+    S = np.eye(N) + 0.01 * S
+    O = np.eye(d)
+    sig, su, sv = 1.0, 10.0, 10.0
+    H = 5
+    ex = _unrated(rs, ratings, n, m, H - 1)
+    vals = [1., 5., 3., 2.]
+    hi = [e[0] for e in ex] + [-1]
+    hj = [e[1] for e in ex] + [-1]
+    hv = vals + [0.]
+    cap = 64
+    rt = ctx.ratings(ratings, n, m)
+    b = ctx.mn_batch(rt, d, H, trace_cap=cap)
+    b.set_state(ctx.array(mean), ctx.array(S), ctx.array(O))
+    b.set_extra(hi, hj, hv)
+    lr, kl, nsteps, conv, trace = b.fit(sig, su, sv, 1e-5, 1e-4, max_steps=max_steps)
+    tv = b.total_variance()
+    dm, ds, do = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+    assert len(set(nsteps.tolist())) >= 1
+    for h in range(H):
+        rr = ratings if hi[h] < 0 else np.vstack([ratings, [hi[h], hj[h], hv[h]]])
+        am, as_, ao, atrace, asteps, alr, aconv, akl = _fit_alone(ctx, rr, n, m, d, mean, S, O, sig, su, sv,
+                                                                  max_steps, cap)
+        b.get_state(h, dm, ds, do)
+        assert asteps == nsteps[h] and aconv == conv[h]
+        assert alr == lr[h] and akl == kl[h]
+        k = min(cap, asteps)
+        assert np.array_equal(atrace[:k], trace[h, :k])
+        assert np.array_equal(dm.to_host(), am)
+        assert np.array_equal(ds.to_host(), as_)
+        assert np.array_equal(do.to_host(), ao)
+        # and the sweep of the batch's resident state == the f64 sweep of the stand-alone result
+        _, pv = orc.mn_pred_means_vars(n, m, am, as_, ao)
+        assert abs(tv[h] - pv.sum()) <= 1e-11 * abs(pv.sum())
+    b.free()
+
+
+def test_batch_slow_path_projection(ctx):
+    """A trial point whose covariance really needs its spectrum clipped (the certificate fails):
+    the hypothesis leaves the batch for the eigendecomposition route and comes back; the others
+    are unaffected.  Checked against a NumPy restatement of one search iteration."""
+    import mn_grad_numpy as ref
+    n, m, d = 20, 25, 3
+    N = n + m
+    rs, ratings, mean, S, O = _problem(n, m, d, 4242)
+    sig, su, sv = 1.0, 10.0, 10.0
+    # hypothesis 0: a covariance with tiny eigenvalues, so that a gradient step makes it indefinite
+    w, v = np.linalg.eigh(S)
+    S_bad = (v * np.concatenate([np.full(5, 2e-5), w[5:]])) @ v.T
+    S_bad = (S_bad + S_bad.T) / 2
+    rt = ctx.ratings(ratings, n, m)
+    b = ctx.mn_batch(rt, d, 2, trace_cap=4)
+    b.set_state(ctx.array(np.stack([mean, mean])), ctx.array(np.stack([S_bad, S])), ctx.array(np.stack([O, O])),
+                per_hypothesis=7)
+    lr0 = 1e-4
+    lr, kl, nsteps, conv, trace = b.fit(sig, su, sv, 1e-5, lr0, max_steps=1)
+
+    def project(mat, min_eig=1e-5):
+        mat = (mat + mat.T) / 2
+        vals, vecs = np.linalg.eigh(mat)
+        if vals.min() < min_eig:
+            mat = (vecs * np.maximum(vals, min_eig)) @ vecs.T
+            mat = (mat + mat.T) / 2
+        return mat
+
+    def kl_of(mean_, S_, O_):
+        trO = np.trace(O_)
+        bit = 0.
+        for i, j, r in ratings:
+            i, j = int(i), int(j)
+            e2 = orc.mn_exp_dotprod_sq(n, mean_, S_, O_, i, j)
+            bit += e2 - 2 * r * ((mean_[i] * mean_[n + j]).sum() + S_[i, n + j] * trO) + r * r
+        return (-(np.linalg.slogdet(S_)[1] * d + np.linalg.slogdet(O_)[1] * N) / 2.
+                + ((mean_[:n] ** 2).sum() + np.trace(S_[:n, :n]) * trO) / (2 * su)
+                + ((mean_[n:] ** 2).sum()) / (2 * su) + bit / (2 * sig))
+
+    clipped = False
+    for h, S0 in enumerate((S_bad, S)):
+        old = kl_of(mean, S0, O)
+        gm, gs, go = ref._mnormal_grad(mean, S0, O, ratings, n, d, sig, su, sv)
+        lr_h = lr0
+        while True:
+            raw = S0 - lr_h * gs
+            if h == 0 and np.linalg.eigvalsh((raw + raw.T) / 2).min() < 1e-5:
+                clipped = True
+            cand = (mean - lr_h * gm, project(raw), project(O - lr_h * go))
+            new = kl_of(*cand)
+            if new < old:
+                break
+            lr_h *= .5
+        assert nsteps[h] == 1
+        assert abs(trace[h, 0] - new) <= 1e-9 * abs(new)
+        dS = ctx.empty((N, N))
+        b.get_state(h, None, dS, None)
+        np.testing.assert_allclose(dS.to_host(), cand[1], rtol=1e-8, atol=1e-10)
+    assert clipped, 'the test problem no longer exercises the projection branch'
+    b.free()
