@@ -86,6 +86,13 @@ def lookahead_threads(procs=None):
     return int(os.environ.get('APMF_LOOKAHEAD_THREADS', '4'))
 
 
+def lookahead_batched():
+    """APMF_LOOKAHEAD_BATCH=0 switches the one-batch-on-the-device evaluation of the lookahead
+    hypotheses off (every hypothesis is then a deep copy re-fitted on its own; used by the tests
+    that check the two give the same values bit for bit)."""
+    return os.environ.get('APMF_LOOKAHEAD_BATCH', '1') != '0'
+
+
 def _parallel_map(fn, items, procs=None):
     """[fn(x) for x in items], concurrently when worthwhile; never nested."""
     global _workers
@@ -169,7 +176,7 @@ def batched(method_name):
     return decorator
 
 
-def _criterion(name, fit, spawn, chooser=maximize, batch=None):
+def _criterion(name, fit, spawn, chooser=maximize, batch=None, grid=None, lookahead=None):
     def wrapper(f):
         do_normal_fit(fit)(f)
         spawn_processes(spawn)(f)
@@ -177,8 +184,52 @@ def _criterion(name, fit, spawn, chooser=maximize, batch=None):
         nice_name(name)(f)
         if batch:
             batched(batch)(f)
+        if grid:
+            # `grid(self) -> (n, m) float64 array` of the criterion over the whole matrix: the
+            # full-pool selections never build the list of candidate tuples
+            f.grid = grid
+        if lookahead:
+            # (fn name, use_map): E[fn(model with R_ij known)], evaluated for a whole pool by one
+            # batched device fit when the class supports it (_lookahead_batch)
+            f.lookahead = lookahead
         return f
     return wrapper
+
+
+class _Candidates(object):
+    """The `unrated` set as a mask: host bool (n, m) and device uint8 (n, ld), 1 = candidate.
+    Kept in step with add_ratings(); rebuilt if the set was replaced or edited behind our back."""
+    __slots__ = ('host', 'dev', 'count', 'set_id', 'ld')
+
+    def __init__(self, model, ctx):
+        n, m = model.num_users, model.num_items
+        unrated, rated = model.unrated, model.rated
+        host = None
+        if len(unrated) + len(rated) == n * m:
+            # unrated = knowable - rated is disjoint from rated, so with these sizes it is the
+            # complement of rated: no need to walk the 10^6-tuple set
+            host = np.ones((n, m), bool)
+            if rated:
+                r = np.array(list(rated), dtype=np.int64).reshape(-1, 2)
+                host[r[:, 0], r[:, 1]] = False
+        if host is None:
+            host = np.zeros((n, m), bool)
+            if unrated:
+                u = np.fromiter(itertools.chain.from_iterable(unrated), dtype=np.int64,
+                                count=2 * len(unrated)).reshape(-1, 2)
+                host[u[:, 0], u[:, 1]] = True
+        self.host = host
+        self.ld = _lib.grid_ld(m)
+        self.dev = ctx.upload_grid(host.view(np.uint8), np.uint8, ld=self.ld)
+        self.count = len(unrated)
+        self.set_id = id(unrated)
+
+    def remove(self, ctx, pairs):
+        zero = np.zeros(1, np.uint8)
+        for i, j in pairs:
+            if self.host[i, j]:
+                self.host[i, j] = False
+                ctx.write_bytes(self.dev, i * self.ld + j, zero)
 
 
 def _pool_arrays(pool):
@@ -243,6 +294,44 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             self._rating_values = None
             self._rating_bounds = None
 
+    # -- candidate mask ---------------------------------------------------------------------
+    def add_ratings(self, extra):
+        super(_ActiveBase, self).add_ratings(extra)
+        dev = self.__dict__.get('_dev')
+        if dev is not None and dev.cand is not None and dev.ctx is not None:
+            extra = np.array(extra, ndmin=2)
+            dev.cand.remove(dev.ctx, [(int(i), int(j)) for i, j in extra[:, :2]])
+            dev.cand.count = len(self.unrated)
+
+    def _candidates(self):
+        dev = self._device()
+        c = dev.cand
+        if c is None or c.count != len(self.unrated) or c.set_id != id(self.unrated):
+            c = dev.cand = _Candidates(self, dev.ctx)
+        return c
+
+    def _pick_from_grid(self, vals, chooser):
+        """chooser(self.unrated, key=vals.__getitem__) without the Python loop over the set:
+        the first extremum in the set's iteration order (mn_active_pmf.py:886)."""
+        cand = self._candidates().host
+        masked = np.where(cand, vals, -np.inf if chooser is max else np.inf)
+        if np.isnan(masked).any():
+            return chooser(self.unrated, key=vals.__getitem__)
+        best = masked.max() if chooser is max else masked.min()
+        ti, tj = np.nonzero((masked == best) & cand)
+        if ti.size == 0:
+            return chooser(self.unrated, key=vals.__getitem__)
+        return self._first_in_pool_order(ti, tj)
+
+    def _first_in_pool_order(self, ti, tj):
+        if ti.size == 1:
+            return (int(ti[0]), int(tj[0]))
+        ties = set(zip(ti.tolist(), tj.tolist()))
+        for ij in self.unrated:          # the reference's tie rule: set iteration order
+            if ij in ties:
+                return ij
+        raise RuntimeError("candidate mask out of step with the unrated set")
+
     # -- supplied by the subclass ---------------------------------------------------------
     def _score_pool(self, pi, pj):
         """(mean, var) float64 arrays of E / Var[U_i.V_j] for the pool, from the GPU."""
@@ -296,7 +385,10 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
     def _pred_pool(self, pi, pj):
         return self.predicted_matrix()[pi, pj]
 
-    @_criterion("Pred Mag", False, False, batch='_pred_pool')
+    def _pred_grid(self):
+        return self.predicted_matrix()
+
+    @_criterion("Pred Mag", False, False, batch='_pred_pool', grid='_pred_grid')
     def pred(self, ij):
         '''The MAP estimate of R_ij.'''
         i, j = ij
@@ -317,18 +409,31 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
     def _prob_ge_half_pool(self, pi, pj):
         return self._prob_ge_pool(pi, pj, .5)
 
-    @_criterion("Prob >= 3.5", True, False, batch='_prob_ge_3_5_pool')
+    def _prob_ge_grid(self, cutoff):
+        mean, var = self.approx_pred_means_vars()
+        return stats.norm.sf(cutoff, loc=mean, scale=var)      # sic, as in _prob_ge_pool
+
+    def _prob_ge_3_5_grid(self):
+        return self._prob_ge_grid(3.5)
+
+    def _prob_ge_half_grid(self):
+        return self._prob_ge_grid(.5)
+
+    @_criterion("Prob >= 3.5", True, False, batch='_prob_ge_3_5_pool', grid='_prob_ge_3_5_grid')
     def prob_ge_3_5(self, ij):
         return self._prob_ge_cutoff(ij, 3.5)
 
-    @_criterion("Prob >= .5", True, False, batch='_prob_ge_half_pool')
+    @_criterion("Prob >= .5", True, False, batch='_prob_ge_half_pool', grid='_prob_ge_half_grid')
     def prob_ge_half(self, ij):
         return self._prob_ge_cutoff(ij, .5)
 
     def _pred_variance_pool(self, pi, pj):
         return self._score_pool(pi, pj)[1]
 
-    @_criterion("Pred Variance", True, False, batch='_pred_variance_pool')
+    def _pred_variance_grid(self):
+        return self.approx_pred_means_vars()[1]
+
+    @_criterion("Pred Variance", True, False, batch='_pred_variance_pool', grid='_pred_variance_grid')
     def pred_variance(self, ij):
         '''Variance of the prediction for R_ij under the current approximation.'''
         return self.approx_pred_mean_var(*ij)[1]
@@ -341,19 +446,19 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
         fn.__name__ = '_1step_{}'.format(cutoff)
         return self._exp_with_rij(ij, fn, use_map=use_map, discretize=True, pass_v=True)
 
-    @_criterion("1 step >= 3.5 (MAP)", True, True)
+    @_criterion("1 step >= 3.5 (MAP)", True, True, lookahead=(('onestep', 3.5), True))
     def onestep_ge_3_5(self, ij):
         return self._onestep_ge_cutoff(ij, 3.5, True)
 
-    @_criterion("1 step >= 3.5 (Approx)", True, True)
+    @_criterion("1 step >= 3.5 (Approx)", True, True, lookahead=(('onestep', 3.5), False))
     def onestep_ge_3_5_approx(self, ij):
         return self._onestep_ge_cutoff(ij, 3.5, False)
 
-    @_criterion("1 step >= .5 (MAP)", True, True)
+    @_criterion("1 step >= .5 (MAP)", True, True, lookahead=(('onestep', .5), True))
     def onestep_ge_half(self, ij):
         return self._onestep_ge_cutoff(ij, .5, True)
 
-    @_criterion("1 step >= .5 (Approx)", True, True)
+    @_criterion("1 step >= .5 (Approx)", True, True, lookahead=(('onestep', .5), False))
     def onestep_ge_half_approx(self, ij):
         return self._onestep_ge_cutoff(ij, .5, False)
 
@@ -365,69 +470,121 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
     def _total_variance(self):
         return self.approx_pred_means_vars()[1].sum()
 
-    @_criterion("E[U/V Entropy] (MAP)", True, True, chooser=minimize)
+    @_criterion("E[U/V Entropy] (MAP)", True, True, chooser=minimize, lookahead=('_approx_entropy', True))
     def exp_approx_entropy(self, ij):
         return self._exp_with_rij(ij, type(self)._approx_entropy, use_map=True)
 
-    @_criterion("E[U/V Entropy] (Approx)", True, True, chooser=minimize)
+    @_criterion("E[U/V Entropy] (Approx)", True, True, chooser=minimize, lookahead=('_approx_entropy', False))
     def exp_approx_entropy_byapprox(self, ij):
         return self._exp_with_rij(ij, type(self)._approx_entropy, use_map=False)
 
-    @_criterion("E[Pred Total Variance] (MAP)", True, True, chooser=minimize)
+    @_criterion("E[Pred Total Variance] (MAP)", True, True, chooser=minimize, lookahead=('_total_variance', True))
     def exp_total_variance(self, ij):
         return self._exp_with_rij(ij, type(self)._total_variance, use_map=True)
 
-    @_criterion("E[Pred Total Variance] (Approx)", True, True, chooser=minimize)
+    @_criterion("E[Pred Total Variance] (Approx)", True, True, chooser=minimize, lookahead=('_total_variance', False))
     def exp_total_variance_byapprox(self, ij):
         return self._exp_with_rij(ij, type(self)._total_variance, use_map=False)
 
-    def _exp_with_rij(self, ij, fn, use_map=True, discretize=None, pass_v=False):
-        '''E[fn(model with R_ij known)] over the predictive distribution of R_ij
-        (mn_active_pmf.py:627-696): MAP mean with variance sigma_sq if use_map, else the
-        approximation's mean/variance; summed over rating_values when discretising, else
-        integrated to +-2 sigma with scipy.'''
-        i, j = ij
-        if discretize is None:
-            discretize = self.discrete_expectations
-        if use_map:
-            mean = np.dot(self.users[i, :], self.items[j, :])
-            var = self.sigma_sq
-        else:
-            mean, var = self.approx_pred_mean_var(i, j)
-        std = math.sqrt(var)
+    # -- one-step lookahead (mn_active_pmf.py:627-696) -------------------------------------------
+    _approx_init_uses_rng = False     # initialize_approx() draws from np.random (ActivePMF)
 
-        def calculate_fn(v):
-            apmf = deepcopy(self)
-            apmf.add_rating(i, j, v)
+    def _hypothesis_model(self, i, j, v):
+        """deepcopy(self) with R_ij = v added: the model a hypothesis is evaluated on."""
+        apmf = deepcopy(self)
+        apmf.add_rating(i, j, v)
+        return apmf
+
+    def _hypothesis_values(self, hyps, fn, pass_v, procs=None):
+        """fn(model refitted with R_ij = v) for every hypothesis (i, j, v) of `hyps`, in order
+        (the reference's calculate_fn, mn_active_pmf.py:660-672).  The matrix-normal class fits
+        all of them in one batch on the device (_lookahead_batch); otherwise every hypothesis is a
+        deep copy re-fitted on its own, a few at a time on worker threads."""
+        batch = getattr(self, '_lookahead_batch', None)
+        if batch is not None and len(hyps) > 0 and lookahead_batched():
+            return batch(hyps, fn, pass_v)
+        # the copies are made here, in order: their constructors draw from the global RNG
+        models = [self._hypothesis_model(i, j, v) for i, j, v in hyps]
+
+        def evaluate(args):
+            apmf, (i, j, v) = args
             if apmf.refit_lookahead:
                 apmf.do_fit()
                 apmf.initialize_approx()
             apmf.fit_normal()
             return fn(apmf, v=v) if pass_v else fn(apmf)
+        if self.refit_lookahead and self._approx_init_uses_rng:
+            procs = 1        # initialize_approx() draws from np.random: keep the reference's order
+        return _parallel_map(evaluate, list(zip(models, hyps)), procs)
 
-        points = self.rating_values
-        if discretize and points:
-            evals = np.array(_parallel_map(calculate_fn, points))
-            if discretize == 'simps':
-                pdfs = stats.norm.pdf(points, loc=mean, scale=std)
-                import scipy.integrate
-                simpson = getattr(scipy.integrate, 'simpson', None) or scipy.integrate.simps
-                est = simpson(evals * pdfs, x=points)
-                s = "simps'ed"
-            else:
-                cdfs = stats.norm.cdf(self.rating_bounds, loc=mean, scale=std)
-                est = (evals * np.diff(cdfs)).sum()
-                s = "summed"
+    def _exp_with_rij_pool(self, pool, fn, use_map=True, discretize=None, pass_v=False, procs=None):
+        '''[E[fn(model with R_ij known)] for ij in pool] over the predictive distribution of R_ij
+        (mn_active_pmf.py:627-696): MAP mean with variance sigma_sq if use_map, else the
+        approximation's mean/variance; summed over rating_values when discretising, else
+        integrated to +-2 sigma with scipy.  All hypotheses of the pool are evaluated together.'''
+        pool = [(int(i), int(j)) for i, j in pool]
+        if discretize is None:
+            discretize = self.discrete_expectations
+        if use_map:
+            means = [float(np.dot(self.users[i, :], self.items[j, :])) for i, j in pool]
+            variances = [self.sigma_sq] * len(pool)
         else:
-            if discretize and points is None:
-                warnings.warn("{} has no rating_values; doing integral".format(type(self).__name__))
-            left, right = mean - 2 * std, mean + 2 * std
-            est = stats.norm.expect(calculate_fn, loc=mean, scale=std, lb=left, ub=right,
-                                    epsrel=.02)
-            s = "from {:5.1f} to {:5.1f}".format(left, right)
+            _, pi, pj = _pool_arrays(pool)
+            pm, pv = self._score_pool(pi, pj)
+            means, variances = [float(x) for x in pm], [float(x) for x in pv]
         name = getattr(fn, '__name__', '')
-        print("\t{:>20}({},{}) {}: {: 10.2f}".format(name, i, j, s, est))
-        return est
+        points = self.rating_values
+        out = []
+        if discretize and points:
+            hyps = [(i, j, v) for i, j in pool for v in points]
+            flat = np.asarray(self._hypothesis_values(hyps, fn, pass_v, procs), dtype=float)
+            evals_all = flat.reshape(len(pool), len(points))
+            for (i, j), mean, var, evals in zip(pool, means, variances, evals_all):
+                std = math.sqrt(var)
+                if discretize == 'simps':
+                    pdfs = stats.norm.pdf(points, loc=mean, scale=std)
+                    import scipy.integrate
+                    simpson = getattr(scipy.integrate, 'simpson', None) or scipy.integrate.simps
+                    est = simpson(evals * pdfs, x=points)
+                    s = "simps'ed"
+                else:
+                    cdfs = stats.norm.cdf(self.rating_bounds, loc=mean, scale=std)
+                    est = (evals * np.diff(cdfs)).sum()
+                    s = "summed"
+                print("\t{:>20}({},{}) {}: {: 10.2f}".format(name, i, j, s, est))
+                out.append(est)
+            return out
+        if discretize and points is None:
+            warnings.warn("{} has no rating_values; doing integral".format(type(self).__name__))
+        for (i, j), mean, var in zip(pool, means, variances):
+            std = math.sqrt(var)
+            left, right = mean - 2 * std, mean + 2 * std
+            # adaptive quadrature asks for one rating value at a time
+            est = stats.norm.expect(
+                lambda v: self._hypothesis_values([(i, j, float(v))], fn, pass_v, 1)[0],
+                loc=mean, scale=std, lb=left, ub=right, epsrel=.02)
+            s = "from {:5.1f} to {:5.1f}".format(left, right)
+            print("\t{:>20}({},{}) {}: {: 10.2f}".format(name, i, j, s, est))
+            out.append(est)
+        return out
+
+    def _exp_with_rij(self, ij, fn, use_map=True, discretize=None, pass_v=False):
+        return self._exp_with_rij_pool([ij], fn, use_map, discretize, pass_v)[0]
+
+    def _lookahead_spec(self, key):
+        """(fn, use_map, discretize, pass_v) of a lookahead criterion, or None."""
+        spec = getattr(key, 'lookahead', None)
+        if spec is None:
+            return None
+        what, use_map = spec
+        if isinstance(what, str):
+            return getattr(type(self), what), use_map, None, False
+        cutoff = what[1]
+
+        def fn(apmf, v):
+            return apmf._last_step_lookahead_helper(cutoff=cutoff, v=v)
+        fn.__name__ = '_1step_{}'.format(cutoff)
+        return fn, use_map, True, True
 
     # -- selection surface (mn_active_pmf.py:701-779) ----------------------------------------
     def _default_key(self):
@@ -436,6 +593,7 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
     def pick_query_point(self, pool=None, key=None, procs=None, worker_pool=None):
         '''Next (i, j) to query: the first extremum of `key` over `pool` (default
         self.unrated) in the pool's iteration order, max or min per key.chooser.'''
+        full = pool is None or pool is self.unrated
         if pool is None:
             pool = self.unrated
         if key is None:
@@ -445,6 +603,15 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             raise ValueError("can't pick a query point from an empty pool")
         elif len(pool) == 1:
             return next(iter(pool))
+        if full and chooser in (max, min):
+            # whole unrated set: the device holds it as a mask; no list of 10^6 tuples is built
+            fast = getattr(self, '_pick_unrated_device', None)
+            got = fast(key, chooser) if fast is not None else None
+            if got is not None:
+                return got
+            grid = getattr(key, 'grid', None)
+            if grid is not None:
+                return self._pick_from_grid(np.asarray(getattr(self, grid)(), dtype=np.float64), chooser)
         pool = list(pool)
         impl = getattr(key, 'batched', None)
         if impl is not None and chooser in (max, min):
@@ -460,33 +627,32 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
 
     def _get_key_vals(self, pool, key, procs=None, worker_pool=None):
         '''Values of `key` for every (i, j) of `pool`, in pool order.  Batched criteria are
-        one GPU launch; the others (random, lookahead) are mapped in this process.'''
+        one GPU launch; lookahead criteria evaluate all hypotheses of the pool together; the
+        rest (random) is a plain map.'''
         impl = getattr(key, 'batched', None)
         if impl is not None:
             pool, pi, pj = _pool_arrays(pool)
             if not pool:
                 return []
             return list(np.asarray(getattr(self, impl)(pi, pj), dtype=np.float64))
-        if getattr(key, 'spawn_processes', False) and len(pool) > 1 and lookahead_threads(procs) > 1:
-            # one hypothesis chain per worker; each works on its own deep copy (the shared model's
-            # device context belongs to the calling thread)
-            return _parallel_map(lambda ij: key(deepcopy(self), ij), pool, procs)
-        # one candidate (or `procs` <= 1): the map over the rating values inside the criterion is
-        # what runs concurrently, with the same width
-        previous = getattr(_worker_state, 'width', None)
-        if procs is not None and procs >= 0:
-            _worker_state.width = int(procs)
-        try:
-            return [key(self, ij) for ij in pool]
-        finally:
-            _worker_state.width = previous
+        pool = list(pool)
+        spec = self._lookahead_spec(key)
+        if spec is not None and pool:
+            fn, use_map, discretize, pass_v = spec
+            return self._exp_with_rij_pool(pool, fn, use_map, discretize, pass_v, procs)
+        return [key(self, ij) for ij in pool]
 
     def get_key_evals(self, pool=None, key=None, procs=None, worker_pool=None):
         '''(n, m) matrix holding key's value at every element of pool, NaN elsewhere.'''
+        full = pool is None or pool is self.unrated
         if pool is None:
             pool = self.unrated
         if key is None:
             key = self._default_key()
+        grid = getattr(key, 'grid', None)
+        if full and grid is not None and len(pool) > 0:
+            vals = np.asarray(getattr(self, grid)(), dtype=np.float64)
+            return np.where(self._candidates().host, vals, np.nan)
         pool = list(pool)
         evals = np.empty((self.num_users, self.num_items))
         evals.fill(np.nan)
@@ -553,7 +719,10 @@ def query_loop(apmf, real, picker_key, fit_normal, fit_sigmas, test_on=None, wit
                 vals = None
         elif matrix_vals:
             vals = apmf.get_key_evals(key=picker_key)
-            i, j = picker_key.chooser(apmf.unrated, key=vals.__getitem__)
+            if picker_key.chooser in (max, min):
+                i, j = apmf._pick_from_grid(vals, picker_key.chooser)
+            else:
+                i, j = picker_key.chooser(apmf.unrated, key=vals.__getitem__)
         else:
             pool = list(apmf.unrated)
             vals = apmf._get_key_vals(pool, picker_key, None, None)

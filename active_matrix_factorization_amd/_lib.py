@@ -76,6 +76,7 @@ _SIGS = {
     'apmf_mn_score_pool_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     'apmf_grid_collect_near_f32': (_i, [_vp, _i, _i, _i, _vp, _vp, _i, C.c_float, C.c_float, _vp, _vp,
                                         _i, C.POINTER(_i)]),
+    'apmf_grid_collect_eq_f64': (_i, [_vp, _i, _i, _i, _vp, _vp, _dbl, _vp, _vp, _i, C.POINTER(_i)]),
     'apmf_full_score_grid_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'apmf_gibbs_half_sweep': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     'apmf_gibbs_half_sweep_rows': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
@@ -106,6 +107,7 @@ _DENSE_SIGS.update({
     'apmf_mn_batch_gradient': (_i, [_vp, _vp, _i, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     'apmf_mn_batch_total_variance': (_i, [_vp, _vp, _vp]),
     'apmf_mn_batch_entropy': (_i, [_vp, _vp, _vp]),
+    'apmf_mn_batch_score_pool': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
     'apmf_mn_batch_score_grid': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
 })
 DENSE_LIB_PATH = os.path.join(_HERE, 'libapmf_dense.so')
@@ -359,6 +361,10 @@ class MNBatch(object):
         _check(self._dense.apmf_mn_batch_entropy(self.ctx._h, self._h, out.ctypes.data))
         return out
 
+    def score_pool(self, h, pi, pj, P, pmean, var):
+        _check(self._dense.apmf_mn_batch_score_pool(self.ctx._h, self._h, int(h), _ptr(pi), _ptr(pj), int(P),
+                                                    _ptr(pmean), _ptr(var)))
+
     def score_grid(self, h0=0, B=None, f32=False, mask=None, var=None, pmean=None, dsum=None, want=0,
                    best_val=None, best_idx=None, ld=None):
         B = self.H - h0 if B is None else B
@@ -429,6 +435,13 @@ class Context(object):
         _check(self._lib.apmf_h2d_2d(self._h, g.ptr, ld * isz, host_2d.ctypes.data,
                                      host_2d.strides[0], m * isz, rows))
         return g
+
+    def write_bytes(self, darr, offset, host):
+        """host bytes -> darr at byte `offset` (small patches of a resident array)"""
+        host = np.ascontiguousarray(host)
+        if offset < 0 or offset + host.nbytes > darr.nbytes:
+            raise ValueError('patch outside the device array')
+        _check(self._lib.apmf_h2d(self._h, darr.ptr + int(offset), host.ctypes.data, host.nbytes))
 
     def download_grid(self, grid, m):
         """(rows, ld) device grid -> contiguous (rows, m) host array."""
@@ -524,6 +537,12 @@ class Context(object):
         _check(self._lib.apmf_grid_collect_near_f32(self._h, n, m, ld, _ptr(var), _ptr(mask), want,
                                                     best, rel_tol, _ptr(pi), _ptr(pj), cap,
                                                     C.byref(cnt)))
+        return cnt.value
+
+    def grid_collect_eq(self, n, m, ld, var, mask, best, pi, pj, cap):
+        cnt = _i(0)
+        _check(self._lib.apmf_grid_collect_eq_f64(self._h, n, m, ld, _ptr(var), _ptr(mask), float(best),
+                                                  _ptr(pi), _ptr(pj), cap, C.byref(cnt)))
         return cnt.value
 
     def full_score_grid(self, n, m, d, ld, mean, cov, mask=None, var=None, pmean=None, dsum=None,

@@ -39,6 +39,8 @@ def project_psd(mat, min_eig=0):
 
 
 class ActivePMF(_ActiveBase):
+    _approx_init_uses_rng = True      # initialize_approx() draws its covariance from np.random
+
     def __init__(self, rating_tuples, latent_d=1, rating_values=None,
                  discrete_expectations=False, refit_lookahead=False, knowable=None,
                  fit_type=('batch',)):
@@ -160,11 +162,11 @@ class ActivePMF(_ActiveBase):
             raise ValueError("prediction cov has det with sign {}, log {}".format(s, logdet))
         return logdet
 
-    @_criterion("E[Pred Entropy Bound] (MAP)", True, True, chooser=minimize)
+    @_criterion("E[Pred Entropy Bound] (MAP)", True, True, chooser=minimize, lookahead=('_pred_entropy_bound', True))
     def exp_pred_entropy_bound(self, ij):
         return self._exp_with_rij(ij, ActivePMF._pred_entropy_bound, use_map=True)
 
-    @_criterion("E[Pred Entropy Bound] (Approx)", True, True, chooser=minimize)
+    @_criterion("E[Pred Entropy Bound] (Approx)", True, True, chooser=minimize, lookahead=('_pred_entropy_bound', False))
     def exp_pred_entropy_bound_byapprox(self, ij):
         return self._exp_with_rij(ij, ActivePMF._pred_entropy_bound, use_map=False)
 

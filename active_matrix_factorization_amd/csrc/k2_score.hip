@@ -1125,6 +1125,25 @@ __global__ __launch_bounds__(256) void k_collect_near(int n, int m, int ld, cons
     }
 }
 
+// every candidate whose float64 score EQUALS the extremum (exact ties), for the reference's
+// first-in-pool-order tie rule
+__global__ __launch_bounds__(256) void k_collect_eq(int n, int m, int ld, const double *__restrict__ var,
+                                                    const uint8_t *__restrict__ mask, double best,
+                                                    int32_t *__restrict__ pi, int32_t *__restrict__ pj, int cap,
+                                                    int *__restrict__ count)
+{
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const double *vrow = var + (size_t)i * ld;
+        const uint8_t *mrow = mask ? mask + (size_t)i * ld : nullptr;
+        for (int j = threadIdx.x; j < m; j += 256) {
+            if (vrow[j] == best && (!mrow || mrow[j])) {
+                const int slot = atomicAdd(count, 1);
+                if (slot < cap) { pi[slot] = i; pj[slot] = j; }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gather(const double *__restrict__ grid, int ld,
                                                 const int32_t *__restrict__ pi,
                                                 const int32_t *__restrict__ pj, int64_t P,
@@ -1228,6 +1247,22 @@ int apmf_grid_collect_near_f32(apmf_ctx *ctx, int n, int m, int ld, const float 
     const int blocks = n < 8192 ? n : 8192;
     hipLaunchKernelGGL(k_collect_near, dim3(blocks), dim3(256), 0, ctx->stream, n, m, ld, d_var, d_mask,
                        want, best, tol, d_pi, d_pj, cap, d_count);
+    APMF_CHECK_LAUNCH();
+    return apmf_d2h(ctx, h_count, d_count, sizeof(int));
+}
+
+int apmf_grid_collect_eq_f64(apmf_ctx *ctx, int n, int m, int ld, const double *d_var, const uint8_t *d_mask,
+                             double best, int32_t *d_pi, int32_t *d_pj, int cap, int *h_count)
+{
+    APMF_REQUIRE(ctx && d_var && d_pi && d_pj && h_count, "NULL operand");
+    APMF_REQUIRE(n >= 1 && m >= 1 && ld >= m && cap >= 1, "bad shape");
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 2, 64, &w));
+    int *d_count = (int *)w;
+    APMF_CHECK_HIP(hipMemsetAsync(d_count, 0, sizeof(int), ctx->stream));
+    const int blocks = n < 8192 ? n : 8192;
+    hipLaunchKernelGGL(k_collect_eq, dim3(blocks), dim3(256), 0, ctx->stream, n, m, ld, d_var, d_mask, best, d_pi,
+                       d_pj, cap, d_count);
     APMF_CHECK_LAUNCH();
     return apmf_d2h(ctx, h_count, d_count, sizeof(int));
 }

@@ -909,6 +909,48 @@ __global__ __launch_bounds__(256) void kb_extract(const Refs R, const int *__res
     }
 }
 
+// arbitrary pool of candidates of ONE hypothesis, straight from its resident state (float64)
+__global__ __launch_bounds__(256) void kb_pool(const Refs R, int h, const int32_t *__restrict__ pi,
+                                               const int32_t *__restrict__ pj, int64_t P,
+                                               double *__restrict__ pmean, double *__restrict__ var)
+{
+    extern __shared__ double sO[];  // d*d mirrored omega
+    const int d = R.d, n = R.n, m = R.m, N = R.N;
+    const double *__restrict__ M = tabp(R, T_M_CUR, h);
+    const double *__restrict__ S = tabp(R, T_S_CUR, h);
+    const double *__restrict__ O = tabp(R, T_O_CUR, h);
+    for (int t = threadIdx.x; t < d * d; t += blockDim.x) {
+        const int k = t / d, l = t % d;
+        sO[t] = O[k <= l ? k * d + l : l * d + k];
+    }
+    __syncthreads();
+    double t2 = 0, tr = 0;
+    for (int k = 0; k < d; k++) {
+        tr += sO[k * d + k];
+        for (int l = 0; l < d; l++) t2 += sO[k * d + l] * sO[k * d + l];
+    }
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; p < P; p += stride) {
+        const int i = pi[p], j = pj[p];
+        if (i < 0 || i >= n || j < 0 || j >= m) {
+            if (pmean) pmean[p] = __builtin_nan("");
+            if (var) var[p] = __builtin_nan("");
+            continue;
+        }
+        const double *a = M + (size_t)i * d, *b = M + (size_t)(n + j) * d;
+        const double sij = S[(size_t)i * N + n + j], sii = S[(size_t)i * N + i], sjj = S[(size_t)(n + j) * N + n + j];
+        double aOa = 0, bOb = 0, aOb = 0, ab = 0;
+        for (int k = 0; k < d; k++) {
+            double oa = 0, ob = 0;
+            for (int l = 0; l < d; l++) { oa += sO[k * d + l] * a[l]; ob += sO[k * d + l] * b[l]; }
+            aOa += a[k] * oa; bOb += b[k] * ob; aOb += b[k] * oa; ab += a[k] * b[k];
+        }
+        if (var) var[p] = (sii * sjj + sij * sij) * t2 + sjj * aOa + sii * bOb + 2 * sij * aOb;
+        if (pmean) pmean[p] = ab + sij * tr;
+    }
+}
+
 int dp6_for(int d)
 {
     int dp = 4;
@@ -1503,6 +1545,23 @@ int apmf_mn_batch_score_grid(apmf_ctx *ctx, apmf_mn_batch *b, int h0, int B, int
     }
     (void)apmf_free(ctx, pack);      // stream-ordered reuse
     return rc;
+}
+
+// approx_pred_mean_var over an arbitrary pool (mn_active_pmf.py:300-315, 731-762) for hypothesis h
+int apmf_mn_batch_score_pool(apmf_ctx *ctx, apmf_mn_batch *b, int h, const int32_t *d_pi, const int32_t *d_pj,
+                             int64_t P, double *d_pmean, double *d_var)
+{
+    APMF_REQUIRE(ctx && b, "NULL operand");
+    const Refs &R = b->R;
+    APMF_REQUIRE(h >= 0 && h < R.H, "hypothesis %d out of range", h);
+    APMF_REQUIRE(P >= 0, "negative pool size");
+    if (P == 0) return APMF_OK;
+    APMF_REQUIRE(d_pi && d_pj, "NULL operand");
+    const int blocks = (int)(cdiv64(P, 256) < 2048 ? cdiv64(P, 256) : 2048);
+    hipLaunchKernelGGL(kb_pool, dim3(blocks), dim3(256), (size_t)R.d * R.d * sizeof(double), ctx->stream, R, h, d_pi,
+                       d_pj, P, d_pmean, d_var);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
 }
 
 // _total_variance() of every hypothesis (mn_active_pmf.py:597-598): the sum of the predictive

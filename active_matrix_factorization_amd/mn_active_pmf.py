@@ -9,6 +9,8 @@ changed is where the time went: scoring every unobserved (i, j) - the per-candid
 loop through exp_dotprod_sq in the reference - is one batched HIP launch here (K2,
 csrc/k2_score.hip), in float64 so that the selected indices match the reference.
 """
+import os
+
 import numpy as np
 
 try:
@@ -31,6 +33,25 @@ except ImportError:      # top-level import (package directory on sys.path, like
 MNActivePMFEvaluator = _Evaluator
 
 
+class _Resident(object):
+    """The approximation of one model, resident on the device: an apmf_mn_batch of one
+    (csrc/k6_batch.hip).  fit_normal advances it in place and the K2 sweeps read it where it
+    lies; the host arrays behind MNActivePMF.mean / cov_useritems / cov_latents are refreshed
+    only when somebody looks at them."""
+    __slots__ = ('batch', 'rt', 'host_fresh', 'dev_fresh')
+
+    def __init__(self, batch, rt):
+        self.batch, self.rt = batch, rt
+        self.host_fresh = True      # the host arrays hold the current point
+        self.dev_fresh = False      # the device holds the current point
+
+
+def lookahead_budget_bytes():
+    """Device memory the batched lookahead may use for hypothesis states (APMF_LOOKAHEAD_GB,
+    default 96 of the 288 GB)."""
+    return int(float(os.environ.get('APMF_LOOKAHEAD_GB', '96')) * (1 << 30))
+
+
 class MNActivePMF(_ActiveBase):
     def __init__(self, rating_tuples, latent_d=1, rating_values=None,
                  discrete_expectations=False, refit_lookahead=False, knowable=None,
@@ -42,6 +63,86 @@ class MNActivePMF(_ActiveBase):
         self.mean = None
         self.cov_useritems = None
         self.cov_latents = None
+
+    # ------------------------------------------------------------------ state: host views of a device resident
+    def _part(name):
+        key = '_' + name
+
+        def get(self):
+            res = self._resident_or_none()
+            if res is not None and not res.host_fresh:
+                self._sync_host()
+            return self.__dict__.get(key)
+
+        def set_(self, value):
+            self._sync_host()                 # the other parts must not be lost
+            if value is not None:
+                # a private, read-only copy: an in-place edit would leave the device copy stale
+                # without anybody noticing (re-bind the attribute instead, like the reference does)
+                value = np.array(value, dtype=np.float64, order='C')
+                value.flags.writeable = False
+            self.__dict__[key] = value
+            res = self._resident_or_none()
+            if res is not None:
+                res.dev_fresh = False
+        return property(get, set_)
+
+    mean = _part('mean')
+    cov_useritems = _part('cov_useritems')
+    cov_latents = _part('cov_latents')
+    del _part
+
+    def _extra_dict(self):
+        # pickles keep the reference's attribute names (mn_active_pmf.py:174-178)
+        self._sync_host()
+        d = super(MNActivePMF, self)._extra_dict()
+        for name in ('mean', 'cov_useritems', 'cov_latents'):
+            d[name] = d.pop('_' + name, None)
+        return d
+
+    def _resident_or_none(self):
+        dev = self.__dict__.get('_dev')
+        return dev.resident if dev is not None else None
+
+    def _sync_host(self):
+        """Bring the host arrays up to date with the device resident (if it is ahead)."""
+        res = self._resident_or_none()
+        if res is None or res.host_fresh:
+            return
+        ctx = res.batch.ctx
+        n_all, d = self.num_users + self.num_items, self.latent_d
+        dm, ds, do = ctx.empty((n_all, d)), ctx.empty((n_all, n_all)), ctx.empty((d, d))
+        res.batch.get_state(0, dm, ds, do)
+        for name, arr in (('_mean', dm), ('_cov_useritems', ds), ('_cov_latents', do)):
+            host = arr.to_host()
+            host.flags.writeable = False
+            self.__dict__[name] = host
+        res.host_fresh = True
+
+    def _resident(self):
+        """The device resident, created / re-uploaded as needed."""
+        self._require_approx(self.__dict__.get('_mean'), self.__dict__.get('_cov_useritems'),
+                             self.__dict__.get('_cov_latents'))
+        ctx, rt = self._device_ratings()
+        dev = self._device()
+        res = dev.resident
+        if res is not None and res.rt is not rt:
+            # the ratings container was rebuilt (add_rating): the batch borrowed the old one
+            self._sync_host()
+            res.batch.free()
+            res = dev.resident = None
+        if res is None:
+            res = dev.resident = _Resident(ctx.mn_batch(rt, self.latent_d, 1, trace_cap=1), rt)
+        if not res.dev_fresh:
+            res.batch.set_state(ctx.array(self.__dict__['_mean']), ctx.array(self.__dict__['_cov_useritems']),
+                                ctx.array(self.__dict__['_cov_latents']))
+            res.dev_fresh = True
+            res.host_fresh = True
+        return res
+
+    def add_ratings(self, extra):
+        self._sync_host()
+        super(MNActivePMF, self).add_ratings(extra)
 
     # ------------------------------------------------------------------ the approximation
     def initialize_approx(self, random_cov=False):
@@ -62,8 +163,13 @@ class MNActivePMF(_ActiveBase):
         if any(p is None for p in parts):
             raise ValueError("run initialize_approx first")
 
+    def _sigmas(self):
+        return float(self.sigma_sq), float(self.sigma_u_sq), float(self.sigma_v_sq)
+
     def kl_divergence(self, mean=None, cov_useritems=None, cov_latents=None):
         '''KL(approximation || PMF model), up to an additive constant.'''
+        if mean is None and cov_useritems is None and cov_latents is None:
+            return float(self._resident().batch.kl(*self._sigmas())[0])
         mean = self.mean if mean is None else mean
         cov_useritems = self.cov_useritems if cov_useritems is None else cov_useritems
         cov_latents = self.cov_latents if cov_latents is None else cov_latents
@@ -73,31 +179,27 @@ class MNActivePMF(_ActiveBase):
                                 _device_ratings=self._device_ratings()[1])
 
     def _fit_normal_device(self, max_steps):
-        """fit_normal_kls with the approximation resident on the device (apmf_mn_fit_normal):
-        gradient, trial point, both projections, KL and the accept / reject decision of the
-        learning-rate search run without the (n+m)^2 covariance crossing PCIe; yields
-        (kl_trace, converged) per call, the host arrays re-bound after every call like the
-        reference re-binds them after every accepted step (mn_active_pmf.py:242-288)."""
-        self._require_approx(self.mean, self.cov_useritems, self.cov_latents)
-        ctx, rt = self._device_ratings()
-        dm = ctx.array(self.mean, np.float64)
-        dcu = ctx.array(self.cov_useritems, np.float64)
-        dcl = ctx.array(self.cov_latents, np.float64)
+        """fit_normal_kls on the device resident (apmf_mn_batch_fit, a batch of one): gradient,
+        trial point, both projections, KL and the accept / reject decision of the learning-rate
+        search run without the approximation ever crossing PCIe; yields (kl_trace, converged)
+        per call (mn_active_pmf.py:242-288)."""
         lr, old_kl, converged = self.normal_learning_rate, None, False
+        sig = self._sigmas()
         while not converged:
-            trace, steps, lr, converged, old_kl = ctx.mn_fit_normal(
-                rt, self.latent_d, dm, dcu, dcl, float(self.sigma_sq), float(self.sigma_u_sq),
-                float(self.sigma_v_sq), self.min_eig, lr, old_kl, max_steps=max_steps)
-            if steps:
-                self.mean, self.cov_useritems, self.cov_latents = dm.to_host(), dcu.to_host(), dcl.to_host()
-            yield trace, converged
+            res = self._resident()
+            lrs, kls, steps, conv, trace = res.batch.fit(sig[0], sig[1], sig[2], self.min_eig, lr, old_kl,
+                                                         max_steps=max_steps)
+            lr, old_kl, converged = float(lrs[0]), float(kls[0]), bool(conv[0])
+            if steps[0]:
+                res.host_fresh = False
+            yield trace[0, :min(int(steps[0]), trace.shape[1])], converged
 
     def fit_normal_kls(self):
         '''Projected gradient descent on the KL, yielding it after each accepted step
         (mn_active_pmf.py:242-288).'''
         for trace, _ in self._fit_normal_device(max_steps=1):
             for kl in trace:
-                yield kl
+                yield float(kl)
 
     def fit_normal(self):
         '''The whole fit in one device call (same steps as exhausting fit_normal_kls).'''
@@ -116,12 +218,11 @@ class MNActivePMF(_ActiveBase):
                       + (self.num_users + self.num_items) * l_logdet)
 
     # ------------------------------------------------------------------ GPU scoring (K2)
-    def _upload_state(self, state=None):
-        mean, cov_ui, cov_lat = state if state is not None else \
-            (self.mean, self.cov_useritems, self.cov_latents)
+    def _upload_state(self, state):
+        mean, cov_ui, cov_lat = state
         self._require_approx(mean, cov_ui, cov_lat)
         ctx = self._device().ctx
-        n, m = self.num_users, self.num_items
+        n = self.num_users
         cov_ui = np.asarray(cov_ui, dtype=np.float64)
         cross = ctx.upload_grid(cov_ui[:n, n:], np.float64)
         return (ctx, ctx.array(mean, np.float64), cross,
@@ -129,12 +230,20 @@ class MNActivePMF(_ActiveBase):
                 ctx.array(cov_lat, np.float64), cross.shape[1])
 
     def _score_grid(self, state=None, want_mean=True):
-        """(mean, var) of U_i.V_j over the whole n x m grid: one launch of the f64 sweep."""
-        ctx, dm, dc, dd, do, ld = self._upload_state(state)
+        """(mean, var) of U_i.V_j over the whole n x m grid: one launch of the f64 sweep,
+        from the device resident (or from an explicitly given state)."""
         n, m, d = self.num_users, self.num_items, self.latent_d
-        var = ctx.empty((n, ld))
-        pm = ctx.empty((n, ld)) if want_mean else None
-        ctx.mn_score_grid(np.float64, 1, n, m, d, ld, dm, dc, dd, do, var=var, pmean=pm)
+        if state is not None:
+            ctx, dm, dc, dd, do, ld = self._upload_state(state)
+            var = ctx.empty((n, ld))
+            pm = ctx.empty((n, ld)) if want_mean else None
+            ctx.mn_score_grid(np.float64, 1, n, m, d, ld, dm, dc, dd, do, var=var, pmean=pm)
+        else:
+            res = self._resident()
+            ctx, ld = res.batch.ctx, _lib.grid_ld(m)
+            var = ctx.empty((n, ld))
+            pm = ctx.empty((n, ld)) if want_mean else None
+            res.batch.score_grid(0, 1, var=var, pmean=pm, ld=ld)
         return (ctx.download_grid(pm, m) if want_mean else None), ctx.download_grid(var, m)
 
     def _score_pool(self, pi, pj, state=None):
@@ -148,10 +257,16 @@ class MNActivePMF(_ActiveBase):
             # most of the grid is wanted: sweep it all (coalesced) and pick
             pm, pv = self._score_grid(state)
             return pm[pi, pj], pv[pi, pj]
-        ctx, dm, dc, dd, do, ld = self._upload_state(state)
-        out_m, out_v = ctx.empty(P), ctx.empty(P)
-        ctx.mn_score_pool(n, m, d, ld, dm, dc, dd, do, ctx.array(pi, np.int32),
-                          ctx.array(pj, np.int32), P, out_m, out_v)
+        if state is not None:
+            ctx, dm, dc, dd, do, ld = self._upload_state(state)
+            out_m, out_v = ctx.empty(P), ctx.empty(P)
+            ctx.mn_score_pool(n, m, d, ld, dm, dc, dd, do, ctx.array(pi, np.int32),
+                              ctx.array(pj, np.int32), P, out_m, out_v)
+        else:
+            res = self._resident()
+            ctx = res.batch.ctx
+            out_m, out_v = ctx.empty(P), ctx.empty(P)
+            res.batch.score_pool(0, ctx.array(pi, np.int32), ctx.array(pj, np.int32), P, out_m, out_v)
         return out_m.to_host(), out_v.to_host()
 
     def approx_pred_means_vars(self):
@@ -161,11 +276,105 @@ class MNActivePMF(_ActiveBase):
 
     def _total_variance(self):
         # only the fused sum leaves the device (mn_active_pmf.py:597-598)
-        ctx, dm, dc, dd, do, ld = self._upload_state()
-        total = ctx.empty(1)
-        ctx.mn_score_grid(np.float64, 1, self.num_users, self.num_items, self.latent_d, ld, dm, dc,
-                          dd, do, dsum=total)
-        return float(total.to_host()[0])
+        return float(self._resident().batch.total_variance()[0])
+
+    def _pick_unrated_device(self, key, chooser):
+        """pick_query_point over the whole unrated set for the variance criterion
+        (mn_active_pmf.py:701-729 with the default pool): one masked float64 sweep with the
+        arg-extremum fused, straight from the device resident; exact ties (rare) are collected on
+        the device and broken by the reference's rule, first in the set's iteration order."""
+        if getattr(key, 'batched', None) != '_pred_variance_pool':
+            return None
+        res = self._resident()
+        ctx = res.batch.ctx
+        n, m = self.num_users, self.num_items
+        cand = self._candidates()
+        ld = cand.ld
+        var = ctx.empty((n, ld))
+        best_val, best_idx = ctx.empty(1), ctx.empty(1, np.int64)
+        want = 1 if chooser is max else -1
+        res.batch.score_grid(0, 1, mask=cand.dev, var=var, want=want, best_val=best_val, best_idx=best_idx,
+                             ld=ld)
+        flat = int(best_idx.to_host()[0])
+        if flat < 0:
+            return None
+        best = float(best_val.to_host()[0])
+        if best != best:
+            return None                  # NaN scores: let the host path reproduce python's max()
+        cap = 4096
+        pi, pj = ctx.empty(cap, np.int32), ctx.empty(cap, np.int32)
+        count = ctx.grid_collect_eq(n, m, ld, var, cand.dev, best, pi, pj, cap)
+        if count <= 1:
+            return (flat // m, flat % m)
+        if count > cap:
+            return None                  # a massive tie: the general path
+        return self._first_in_pool_order(pi.to_host()[:count], pj.to_host()[:count])
+
+    # ------------------------------------------------------------------ batched one-step lookahead
+    def _lookahead_batch(self, hyps, fn, pass_v):
+        """fn(model refitted with R_ij = v) for every hypothesis (i, j, v), all fitted together
+        on the device (mn_active_pmf.py:660-672 for the whole pool at once): the hypotheses are
+        H approximations starting from this model's, each with one extra rating, advanced by one
+        chain of launches (apmf_mn_batch_fit); _total_variance is then one K2 sweep with
+        B = H over the resident states and _approx_entropy comes from the factorisations the
+        fit already made.  Other `fn`s get a real model object per hypothesis, filled from the
+        batch.  With refit_lookahead every hypothesis' MAP re-fit (do_fit) runs first, on its
+        own deep copy, and the approximation restarts from it (initialize_approx)."""
+        n_all, d = self.num_users + self.num_items, self.latent_d
+        sig = self._sigmas()
+        cls = type(self)
+        special = None
+        if not pass_v and fn is getattr(cls, '_total_variance', None) and \
+                cls._total_variance is MNActivePMF._total_variance:
+            special = 'tv'
+        elif not pass_v and fn is getattr(cls, '_approx_entropy', None) and \
+                cls._approx_entropy is MNActivePMF._approx_entropy:
+            special = 'ent'
+        per_hyp = (5 * n_all * n_all + (4 + d) * n_all * d + 64 * 64 * (n_all // 64 + 3)) * 8
+        chunk = max(1, min(len(hyps), lookahead_budget_bytes() // per_hyp, 16384))
+        base = None
+        if not self.refit_lookahead:
+            res = self._resident()
+            ctx = res.batch.ctx
+            base = (ctx.empty((n_all, d)), ctx.empty((n_all, n_all)), ctx.empty((d, d)))
+            res.batch.get_state(0, *base)
+        ctx, rt = self._device_ratings()
+        out = []
+        batch = None
+        for lo in range(0, len(hyps), chunk):
+            part = hyps[lo:lo + chunk]
+            H = len(part)
+            if batch is None or batch.H != H:
+                if batch is not None:
+                    batch.free()
+                batch = ctx.mn_batch(rt, d, H)
+            models = None
+            if self.refit_lookahead:
+                # MAP re-fit per hypothesis, then initialize_approx(): mean = MAP, identity covariances
+                models = [self._hypothesis_model(i, j, v) for i, j, v in part]
+                for apmf in models:
+                    apmf.do_fit()
+                means = np.stack([np.vstack((apmf.users, apmf.items)) for apmf in models])
+                batch.set_state(ctx.array(means), ctx.array(np.eye(n_all)), ctx.array(np.eye(d)),
+                                per_hypothesis=1)
+            else:
+                batch.set_state(*base)
+            batch.set_extra([h[0] for h in part], [h[1] for h in part], [h[2] for h in part])
+            batch.fit(sig[0], sig[1], sig[2], self.min_eig, self.normal_learning_rate, None, max_steps=-1)
+            if special == 'tv':
+                out.extend(batch.total_variance().tolist())
+            elif special == 'ent':
+                out.extend(batch.entropy().tolist())
+            else:
+                dm, ds, do = ctx.empty((n_all, d)), ctx.empty((n_all, n_all)), ctx.empty((d, d))
+                for k, (i, j, v) in enumerate(part):
+                    apmf = models[k] if models is not None else self._hypothesis_model(i, j, v)
+                    batch.get_state(k, dm, ds, do)
+                    apmf.mean, apmf.cov_useritems, apmf.cov_latents = dm.to_host(), ds.to_host(), do.to_host()
+                    out.append(fn(apmf, v=v) if pass_v else fn(apmf))
+        if batch is not None:
+            batch.free()
+        return out
 
 
 ################################################################################

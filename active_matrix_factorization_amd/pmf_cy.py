@@ -35,12 +35,14 @@ def rmse_on(exp, obs, on):
 
 class _DeviceCache(object):
     """Per-object device state: never part of __getstate__, rebuilt lazily after copy/unpickle."""
-    __slots__ = ('ctx', 'ratings', 'ratings_key')
+    __slots__ = ('ctx', 'ratings', 'ratings_key', 'resident', 'cand')
 
     def __init__(self):
         self.ctx = None
         self.ratings = None
         self.ratings_key = None
+        self.resident = None     # device-resident posterior approximation (MNActivePMF)
+        self.cand = None         # candidate ("unrated") mask, host + device (_active_base._Candidates)
 
 
 _PUBLIC_STATE = (

@@ -186,6 +186,13 @@ int apmf_grid_collect_near_f32(apmf_ctx *ctx, int n, int m, int ld, const float 
                                const uint8_t *d_mask, int want, float best, float rel_tol,
                                int32_t *d_pi, int32_t *d_pj, int cap, int *h_count);
 
+/* After a float64 sweep: every candidate whose score equals `best` exactly (the ties the
+ * reference's first-in-pool-order rule has to break, mn_active_pmf.py:729), up to cap entries;
+ * *h_count receives the number found (may exceed cap). */
+int apmf_grid_collect_eq_f64(apmf_ctx *ctx, int n, int m, int ld, const double *d_var,
+                             const uint8_t *d_mask, double best, int32_t *d_pi, int32_t *d_pj, int cap,
+                             int *h_count);
+
 /* ---- K2-full: same under the full-covariance Gaussian --------------------------------
  * Replaces ActivePMF.approx_pred_mean_var / approx_pred_means_vars / pred_variance
  * (active_pmf.py:301-322, 392-400, 502-524) + normal_exps_cy.exp_dotprod_sq
@@ -325,6 +332,11 @@ int apmf_mn_batch_entropy(apmf_ctx *ctx, apmf_mn_batch *b, double *h_out);
 int apmf_mn_batch_score_grid(apmf_ctx *ctx, apmf_mn_batch *b, int h0, int B, int use_f32, int ld,
                              const uint8_t *d_mask, void *d_var, void *d_pmean, double *d_sum,
                              int want, void *d_best_val, int64_t *d_best_idx);
+
+/* approx_pred_mean_var over an arbitrary pool (mn_active_pmf.py:300-315) for hypothesis h, from
+ * its resident state: d_pi, d_pj (P) int32 -> d_pmean, d_var (P) float64 (each nullable). */
+int apmf_mn_batch_score_pool(apmf_ctx *ctx, apmf_mn_batch *b, int h, const int32_t *d_pi,
+                             const int32_t *d_pj, int64_t P, double *d_pmean, double *d_var);
 
 /* normal_gradient() / _normal_grad(), normal_exps_cy.pyx:140-303: gradient of the KL of the
  * full-covariance approximation (ActivePMF.fit_normal) w.r.t. mean (K) and cov (K x K),

@@ -555,9 +555,11 @@ def test_compare_threaded_keys_equal_single_key_runs(pkg):
 
 @pytest.mark.parametrize('d', [13, 16, 24])
 def test_mn_selection_rank_above_12_exact(pkg, d):
-    """Rank > 12: the class's selection runs through the matrix-core float32 sweep, the near-tie
-    short list and the float64 re-score; the pick must be the oracle's float64 arg-max over the
-    pool in pool order (the reference's first-extremum rule), for max and for min criteria."""
+    """Rank > 12 (the wider K2 templates): the class's selection is a float64 sweep; the pick must
+    be the oracle's float64 arg-max over the pool in pool order (the reference's first-extremum
+    rule), through the explicit-pool path and through the masked device path of the default pool.
+    (The float32 sweep -> near-tie list -> float64 re-score chain is exercised at the C-ABI level
+    in test_gpu_kernels.py::test_mn_pool_and_exact_selection.)"""
     from oracle import oracle as orc
     seed(100 + d)
     n, m = 23, 37
@@ -571,6 +573,7 @@ def test_mn_selection_rank_above_12_exact(pkg, d):
     assert a.pick_query_point(pool=pool, key=pkg.mn.KEY_FUNCS['pred-variance']) == pool[int(np.argmax(vals))]
     got = np.array(a._get_key_vals(pool, pkg.mn.KEY_FUNCS['pred-variance']))
     assert np.all(np.abs(got - vals) <= 1e-9 * np.abs(vals).max())
+    assert a.pick_query_point(key=pkg.mn.KEY_FUNCS['pred-variance']) == pool[int(np.argmax(vals))]
 
 
 def test_cli_entry_points(tmp_path, pkg, monkeypatch):
@@ -642,3 +645,156 @@ def test_bayes_device_rng_opt_in(pkg):
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(s1, s2))
     assert not np.array_equal(s1[0][0], s3[0][0])
     assert rmse_dev < 0.3 and abs(rmse_dev - rmse_host) < 0.1
+
+
+# ------------------------------------------------------------------ round 2: resident state, masks, batched lookahead
+def _lookahead_model(pkg, g, **kw):
+    a = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5),
+                           discrete_expectations=True, **kw)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+    return a
+
+
+@pytest.mark.parametrize('key', ['total-variance', 'total-variance-approx', 'uv-entropy', '1step-ge-3.5'])
+def test_lookahead_batched_equals_per_hypothesis(pkg, monkeypatch, key):
+    """The lookahead criteria evaluate all hypotheses (candidate x rating value) of a pool as ONE
+    batch on the device; with APMF_LOOKAHEAD_BATCH=0 every hypothesis is the reference's
+    deepcopy -> add_rating -> fit_normal -> fn on its own (mn_active_pmf.py:660-672).  Same
+    values bit for bit (the entropy is computed from Cholesky factors in the batch and from an LU
+    in the per-hypothesis path: 1e-12)."""
+    g = load_golden('lookahead_c1_mn')
+    a = _lookahead_model(pkg, g)
+    pool = sorted(a.unrated)[:4]
+    k = pkg.mn.KEY_FUNCS[key]
+    batched = a._get_key_vals(pool, k)
+    monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', '0')
+    alone = a._get_key_vals(pool, k, procs=1)
+    threaded = a._get_key_vals(pool, k, procs=4)
+    assert alone == threaded
+    if key == 'uv-entropy':
+        np.testing.assert_allclose(batched, alone, rtol=1e-12)
+    else:
+        assert batched == alone
+
+
+def test_lookahead_batched_refit_equals_per_hypothesis(pkg, monkeypatch):
+    """--refit-lookahead: every hypothesis re-fits the MAP estimate first and restarts the
+    approximation from it (mn_active_pmf.py:662-665)."""
+    g = load_golden('lookahead_c1_mn')
+    a = _lookahead_model(pkg, g, refit_lookahead=True)
+    pool = sorted(a.unrated)[:2]
+    k = pkg.mn.KEY_FUNCS['total-variance']
+    seed(3)
+    batched = a._get_key_vals(pool, k)
+    monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', '0')
+    seed(3)
+    alone = a._get_key_vals(pool, k, procs=1)
+    assert batched == alone
+
+
+def test_lookahead_configs3_shape(pkg, monkeypatch):
+    """BASELINE.json configs[3]'s shape (94 x 425, rank 5, 500 known): E[total variance] of two
+    candidates, batched == per-hypothesis bit for bit, from a partly fitted approximation."""
+    seed(0)
+    n, m, d, known = 94, 425, 5, 500
+    u, v = np.random.normal(0, 1, (n, d)), np.random.normal(0, 1, (m, d))
+    x = u @ v.T
+    real = np.clip(np.round(3 + x / x.std() * 1.2), 1, 5)
+    flat = np.random.choice(n * m, known, replace=False)
+    ii, jj = flat // m, flat % m
+    ratings = np.c_[ii, jj, real[ii, jj]].astype(float)
+    a = pkg.mn.MNActivePMF(ratings, latent_d=d, rating_values=(1, 2, 3, 4, 5), discrete_expectations=True)
+    a.do_fit()
+    a.initialize_approx()
+    for _ in islice(a.fit_normal_kls(), 40):
+        pass
+    # make the hypotheses' fits short: a loose convergence is not available in the reference's
+    # loop, so start them near their optimum instead - a few dozen more steps on the base model
+    pool = sorted(a.unrated)[:2]
+    k = pkg.mn.KEY_FUNCS['total-variance']
+    batched = a._get_key_vals(pool, k)
+    monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', '0')
+    alone = a._get_key_vals(pool, k, procs=4)
+    assert batched == alone
+    assert all(np.isfinite(batched))
+
+
+def test_mn_state_is_device_resident(pkg):
+    """fit_normal_kls leaves the approximation on the device; the host attributes are views
+    refreshed on access, read-only (re-bind to change them, like the reference does), and
+    pickles keep the reference's attribute names."""
+    g = load_golden('mn_24x17_d5_rand')
+    a = _make_mn(pkg, g)
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    it = a.fit_normal_kls()
+    kl0 = next(it)
+    res = a._dev.resident
+    assert res is not None and not res.host_fresh            # nothing was downloaded by the step
+    assert abs(kl0 - g['kl_trace'][0]) <= 1e-8 * abs(kl0)
+    m1 = a.mean                                              # now it is
+    assert res.host_fresh and not m1.flags.writeable
+    with pytest.raises(ValueError):
+        a.mean[0, 0] = 1.
+    kl1 = next(it)
+    assert abs(kl1 - g['kl_trace'][1]) <= 1e-8 * abs(kl1)
+    st = a.__getstate__()['__dict__']
+    assert {'mean', 'cov_useritems', 'cov_latents'} <= set(st) and not any(k.startswith('_mean') for k in st)
+    b = pickle.loads(pickle.dumps(a))
+    np.testing.assert_array_equal(b.mean, a.mean)
+    np.testing.assert_array_equal(b.cov_useritems, a.cov_useritems)
+    # re-binding a part re-uploads the state: scoring follows
+    pm0, pv0 = a.approx_pred_means_vars()
+    a.cov_latents = 2 * np.asarray(a.cov_latents)
+    pm1, pv1 = a.approx_pred_means_vars()
+    assert not np.allclose(pv0, pv1)
+    b.cov_latents = 2 * np.asarray(b.cov_latents)
+    np.testing.assert_array_equal(b.approx_pred_means_vars()[1], pv1)
+    # add_rating: the container is rebuilt, the approximation survives
+    ij = next(iter(a.unrated))
+    before = a.cov_useritems.copy()
+    a.add_rating(ij[0], ij[1], 3.)
+    np.testing.assert_array_equal(a.cov_useritems, before)
+    assert np.isfinite(a.kl_divergence())
+
+
+def test_full_pool_selection_paths(pkg):
+    """pick_query_point / get_key_evals over the default pool never build the list of candidate
+    tuples: masked sweep + fused arg-extremum for the variance criterion, masked host grids for
+    the other batched criteria; same answers as the explicit-pool path, ties broken by the
+    set's iteration order (mn_active_pmf.py:729, 886)."""
+    g = load_golden('mn_24x17_d5_rand')
+    a = _make_mn(pkg, g)
+    MN = pkg.mn.MNActivePMF
+    for key in (MN.pred_variance, MN.pred, MN.prob_ge_3_5, MN.prob_ge_half):
+        pool = list(a.unrated)
+        assert a.pick_query_point(key=key) == a.pick_query_point(pool=pool, key=key)
+        ev_full = a.get_key_evals(key=key)
+        ev_pool = a.get_key_evals(pool=pool, key=key)
+        np.testing.assert_array_equal(np.isnan(ev_full), np.isnan(ev_pool))
+        np.testing.assert_allclose(ev_full[~np.isnan(ev_full)], ev_pool[~np.isnan(ev_pool)], rtol=1e-13)
+    # exact ties: identity covariances and identical factor rows make whole rows of candidates tie
+    a.users = np.ones_like(a.users)
+    a.items = np.ones_like(a.items)
+    a.initialize_approx()
+    pool = list(a.unrated)
+    vals = a._get_key_vals(pool, MN.pred_variance)
+    assert len(set(vals)) == 1                      # everything ties
+    assert a.pick_query_point(key=MN.pred_variance) == pool[0]
+    assert a.pick_query_point(key=MN.pred) == pool[0]
+    # the mask follows add_rating and direct edits of the set
+    first = pool[0]
+    a.add_rating(first[0], first[1], 2.)
+    pool2 = list(a.unrated)
+    assert a.pick_query_point(key=MN.pred_variance) == pool2[0] and first not in pool2
+    a.unrated.discard(pool2[0])
+    assert a.pick_query_point(key=MN.pred_variance) == list(a.unrated)[0]
+    ev = a.get_key_evals(key=MN.pred_variance)
+    assert np.isnan(ev[pool2[0]]) and np.isnan(ev[first])
+    # a restricted `knowable` set
+    know = [(i, j) for i in range(0, 24, 2) for j in range(17)]
+    b = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=5, knowable=know)
+    b.users, b.items = g['users'].copy(), g['items'].copy()
+    b.mean, b.cov_useritems, b.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+    assert b.pick_query_point() == b.pick_query_point(pool=list(b.unrated))
+    assert b.pick_query_point()[0] % 2 == 0
