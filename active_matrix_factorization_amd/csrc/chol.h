@@ -51,6 +51,50 @@ __device__ __forceinline__ double lane_value(double v, int src)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+
+// ---- 64 x 64 x K tile products on the matrix cores (v_mfma_f64_16x16x4_f64) -------------------
+// A block is 4 waves; wave w owns the 32 x 32 quadrant (w >> 1, w & 1) of the 64 x 64 output as
+// 2 x 2 accumulators of 16 x 16.  Operands are LDS tiles of pitch TP (66: an [index][k] operand
+// read - lane l takes index l & 15, k = k0 + (l >> 4) - touches 32 distinct banks per half wave).
+// C/D layout of the instruction: column = lane & 15, row = (lane >> 4) + 4 * register.
+// Same peak as the f64 vector pipe (78.6 TFLOP/s) but 4 LDS reads per 4 x 2048 flops instead of 8
+// per 16 x 128: the VALU 4 x 4 micro-tile these kernels started with ran at 8 % of peak, LDS-bound.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int TP = 66;
+enum { MM_NT = 0, MM_NN = 1, MM_TN = 2 };
+
+// acc += A op B over k in [0, K) (K a multiple of 4, tiles zero-padded):
+//   MM_NT: C[i][j] += A[i][k] B[j][k]     MM_NN: C[i][j] += A[i][k] B[k][j]     MM_TN: C[i][j] += A[k][i] B[k][j]
+template <int FORM>
+__device__ __forceinline__ void tile_mfma(f64x4 (&acc)[2][2], const double (*A)[TP], const double (*B)[TP], int K)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int r0 = 32 * (w >> 1) + li, c0 = 32 * (w & 1) + li;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + g;
+        double a[2], b[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            a[u] = FORM == MM_TN ? A[k][r0 + 16 * u] : A[r0 + 16 * u][k];
+            b[u] = FORM == MM_NT ? B[c0 + 16 * u][k] : B[k][c0 + 16 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int v = 0; v < 2; v++) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+    }
+}
+
+// (row, column) within the 64 x 64 tile of accumulator element acc[u][v][r] of this lane
+__device__ __forceinline__ int tile_row(int u, int r) { return 32 * ((int)(threadIdx.x >> 6) >> 1) + 16 * u + (int)((threadIdx.x & 63) >> 4) + 4 * r; }
+__device__ __forceinline__ int tile_col(int v) { return 32 * ((int)(threadIdx.x >> 6) & 1) + 16 * v + (int)(threadIdx.x & 15); }
+
+#define TILE_FOR_EACH(u, v, r)                                   \
+    _Pragma("unroll") for (int u = 0; u < 2; u++)                \
+    _Pragma("unroll") for (int v = 0; v < 2; v++)                \
+    _Pragma("unroll") for (int r = 0; r < 4; r++)
+
 // Diagonal block k..k+nb, one wave, everything in registers: lane t holds row t of the block
 // (64 doubles) and other lanes' entries arrive by v_readlane: 55 us per block.  The LDS
 // formulations were slower: one wave walking its rows serially 113 us (dependent LDS round
@@ -101,14 +145,13 @@ __global__ __launch_bounds__(64) void k_chol_diag(const ChJobs J, int N, int k)
 }
 
 // rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T = (rows) x (L_kk^-1)': a 64 x 64 x 64 product
-// per block of 64 rows, 4 x 4 outputs per thread, both operands in LDS (rows / columns dealt to the
-// threads with stride 16 so that neither operand read conflicts)
+// per block of 64 rows on the matrix cores, both operands in LDS
 __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k)
 {
     const ChJob job = ch_job(J, blockIdx.y);
     double *__restrict__ A = job.A;
     const double *__restrict__ linv = ch_linv(job, k);
-    __shared__ double P[CH_NB][CH_NB + 1], X[CH_NB][CH_NB + 1];
+    __shared__ double P[CH_NB][TP], X[CH_NB][TP];
     const int tid = threadIdx.x;
     const int nb = min(CH_NB, N - k);
     if (*job.info != 0) return;
@@ -120,26 +163,11 @@ __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k
         P[i][j] = (i < rows && j < nb) ? A[(size_t)(r0 + i) * N + k + j] : 0.;
     }
     __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    double acc[4][4] = {};
-    for (int c = 0; c < CH_NB; c++) {
-        double pr[4], xc[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { pr[u] = P[ty + 16 * u][c]; xc[u] = X[tx + 16 * u][c]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[u][v] += pr[u] * xc[v];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) P[ty + 16 * u][tx + 16 * v] = acc[u][v];
-    __syncthreads();
-    for (int e = tid; e < rows * CH_NB; e += 256) {
-        const int i = e / CH_NB, j = e % CH_NB;
-        if (j < nb) A[(size_t)(r0 + i) * N + k + j] = P[i][j];
+    f64x4 acc[2][2] = {};
+    tile_mfma<MM_NT>(acc, P, X, CH_NB);
+    TILE_FOR_EACH(u, v, r) {
+        const int i = tile_row(u, r), j = tile_col(v);
+        if (i < rows && j < nb) A[(size_t)(r0 + i) * N + k + j] = acc[u][v][r];
     }
 }
 
@@ -153,42 +181,30 @@ __device__ __forceinline__ void tri_tile(int b, int &ti, int &tj)
 }
 
 // trailing update: for i >= j >= k + nb:  A[i][j] -= sum_t P[i][t] P[j][t],  P = A[:, k..k+nb)
-// one 64 x 64 tile per block (tiles on or below the diagonal), 4 x 4 outputs per thread
+// one 64 x 64 tile per block (tiles on or below the diagonal), on the matrix cores
 __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int k)
 {
     const ChJob job = ch_job(J, blockIdx.y);
     double *__restrict__ A = job.A;
-    __shared__ double Pi[64][CH_NB + 1], Pj[64][CH_NB + 1];
+    __shared__ double Pi[64][TP], Pj[64][TP];
     if (*job.info != 0) return;
     const int nb = min(CH_NB, N - k);
     const int base = k + nb;
     int ti, tj;
     tri_tile((int)blockIdx.x, ti, tj);
     const int i0 = base + ti * 64, j0 = base + tj * 64;
-    for (int e = threadIdx.x; e < 64 * nb; e += 256) {
-        const int r = e / nb, c = e % nb;
-        Pi[r][c] = i0 + r < N ? A[(size_t)(i0 + r) * N + k + c] : 0.;
-        Pj[r][c] = j0 + r < N ? A[(size_t)(j0 + r) * N + k + c] : 0.;
+    for (int e = threadIdx.x; e < 64 * CH_NB; e += 256) {
+        const int r = e / CH_NB, c = e % CH_NB;
+        Pi[r][c] = (i0 + r < N && c < nb) ? A[(size_t)(i0 + r) * N + k + c] : 0.;
+        Pj[r][c] = (j0 + r < N && c < nb) ? A[(size_t)(j0 + r) * N + k + c] : 0.;
     }
     __syncthreads();
-    const int tr = (threadIdx.x >> 4) * 4, tc = (threadIdx.x & 15) * 4;
-    double acc[4][4] = {};
-    for (int c = 0; c < nb; c++) {
-        double a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = Pi[tr + u][c]; b[u] = Pj[tc + u][c]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
+    f64x4 acc[2][2] = {};
+    tile_mfma<MM_NT>(acc, Pi, Pj, (nb + 3) & ~3);
+    TILE_FOR_EACH(u, v, r) {
+        const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
+        if (i < N && j <= i) A[(size_t)i * N + j] -= acc[u][v][r];
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int i = i0 + tr + u, j = j0 + tc + v;
-            if (i < N && j <= i) A[(size_t)i * N + j] -= acc[u][v];
-        }
 }
 
 } // namespace

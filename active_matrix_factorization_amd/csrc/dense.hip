@@ -228,6 +228,15 @@ int chol_lower(apmf_ctx *ctx, double *A0, int N, int *d_info, double *d_linv, do
 
 extern "C" {
 
+// the context's rocBLAS handle (bound to its stream), for k6_batch.hip's batched eigendecomposition
+int apmf_dense_handle(apmf_ctx *ctx, void **out)
+{
+    rocblas_handle h;
+    APMF_TRY(handle_for(ctx, &h));
+    *out = h;
+    return APMF_OK;
+}
+
 int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, int *h_projected)
 {
     APMF_REQUIRE(ctx && d_mat, "NULL operand");

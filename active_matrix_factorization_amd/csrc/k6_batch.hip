@@ -37,10 +37,16 @@
 #include <math.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
+
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
 
 #include "chol.h"
 #include "common.h"
+
+extern "C" int apmf_dense_handle(apmf_ctx *ctx, void **out);
 
 extern "C" int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, int *h_projected);
 extern "C" int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_inv, double *h_logdet);
@@ -91,6 +97,9 @@ struct Refs {
     // K5 per-row work arrays, [H] x ...
     double *xoff, *crow, *qrow, *sdiag, *dgv, *racc_u, *racc_v, *part, *out4;
     OmegaConsts *oc;
+    double **ptrs;        // [H] scratch pointer array (batched eigendecomposition)
+    double *evals, *evE;  // [H][N] eigenvalues / rocSOLVER's E
+    int *evinfo;          // [H]
     double *trace;        // [H][trace_cap]
     int *ei, *ej;         // extra rating of the hypothesis (ei < 0: none)
     double *ev;
@@ -735,7 +744,7 @@ __global__ void kb_decide(const Refs R, const int *__restrict__ sel, int nsel, i
 // j <= k):   W_ij <- W_ij - L_ik W_kj   (W_ij = 0 when j = k, W_kk = Linv_kk),
 // and the tiles of row k + 1 are multiplied by Linv_{k+1,k+1} on the way out, so that row k + 1
 // is final when launch k + 1 reads it.  Diagonal tiles of W are never stored: they are Linv_kk.
-__device__ __forceinline__ void tile_load(double (*T)[CH_NB + 1], const double *__restrict__ A, int N, int r0, int c0)
+__device__ __forceinline__ void tile_load(double (*T)[TP], const double *__restrict__ A, int N, int r0, int c0)
 {
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         const int r = e >> 6, c = e & 63;
@@ -743,95 +752,52 @@ __device__ __forceinline__ void tile_load(double (*T)[CH_NB + 1], const double *
     }
 }
 
-__device__ __forceinline__ void tile_load_dense(double (*T)[CH_NB + 1], const double *__restrict__ B)
+__device__ __forceinline__ void tile_load_dense(double (*T)[TP], const double *__restrict__ B)
 {
     for (int e = threadIdx.x; e < 64 * 64; e += 256) T[e >> 6][e & 63] = B[e];
 }
 
-// acc[u][v] += sum_c A[ty + 16u][c] * B[c][tx + 16v]
-__device__ __forceinline__ void tile_mm(double (&acc)[4][4], const double (*A)[CH_NB + 1],
-                                        const double (*B)[CH_NB + 1], int ty, int tx)
-{
-    for (int c = 0; c < 64; c++) {
-        double a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = A[ty + 16 * u][c]; b[u] = B[c][tx + 16 * u]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
-    }
-}
-
-// acc[u][v] += sum_c A[c][ty + 16u] * B[c][tx + 16v]      (A' B)
-__device__ __forceinline__ void tile_mm_tn(double (&acc)[4][4], const double (*A)[CH_NB + 1],
-                                           const double (*B)[CH_NB + 1], int ty, int tx)
-{
-    for (int c = 0; c < 64; c++) {
-        double a[4], b[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = A[c][ty + 16 * u]; b[u] = B[c][tx + 16 * u]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
-    }
-}
-
 __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__restrict__ sel, int k)
 {
-    __shared__ double A[64][CH_NB + 1], B[64][CH_NB + 1];
+    __shared__ double A[64][TP], B[64][TP];
     const int h = sel[blockIdx.y];
     const int N = R.N, nb = R.nbk;
     const int i = k + 1 + (int)blockIdx.x / (k + 1), j = (int)blockIdx.x % (k + 1);
     const double *__restrict__ L = tabp(R, T_S_F, h);
     double *__restrict__ W = tabp(R, T_S_W, h);
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
     tile_load(A, L, N, i * 64, k * 64);                                    // L_ik
     if (j == k) tile_load_dense(B, linv + (size_t)k * CH_NB * CH_NB);      // W_kk = Linv_kk
     else tile_load(B, W, N, k * 64, j * 64);                               // W_kj (final)
     __syncthreads();
-    double acc[4][4] = {};
-    tile_mm(acc, A, B, ty, tx);
+    f64x4 acc[2][2] = {};
+    tile_mfma<MM_NN>(acc, A, B, 64);
     __syncthreads();
     // out = (j < k ? W_ij : 0) - acc
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int r = i * 64 + ty + 16 * u, c = j * 64 + tx + 16 * v;
-            const double old = (j < k && r < N && c < N) ? W[(size_t)r * N + c] : 0.;
-            acc[u][v] = old - acc[u][v];
-        }
+    TILE_FOR_EACH(u, v, r) {
+        const int rr = i * 64 + tile_row(u, r), cc = j * 64 + tile_col(v);
+        const double old = (j < k && rr < N && cc < N) ? W[(size_t)rr * N + cc] : 0.;
+        acc[u][v][r] = old - acc[u][v][r];
+    }
     if (i == k + 1) {
         // row k + 1 becomes final: multiply by Linv_{k+1,k+1} from the left
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) B[ty + 16 * u][tx + 16 * v] = acc[u][v];
+        TILE_FOR_EACH(u, v, r) B[tile_row(u, r)][tile_col(v)] = acc[u][v][r];
         tile_load_dense(A, linv + (size_t)(k + 1) * CH_NB * CH_NB);
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) acc[u][v] = 0.;
-        tile_mm(acc, A, B, ty, tx);
+        TILE_FOR_EACH(u, v, r) acc[u][v][r] = 0.;
+        tile_mfma<MM_NN>(acc, A, B, 64);
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int r = i * 64 + ty + 16 * u, c = j * 64 + tx + 16 * v;
-            if (r < N && c < N) W[(size_t)r * N + c] = acc[u][v];
-        }
+    TILE_FOR_EACH(u, v, r) {
+        const int rr = i * 64 + tile_row(u, r), cc = j * 64 + tile_col(v);
+        if (rr < N && cc < N) W[(size_t)rr * N + cc] = acc[u][v][r];
+    }
 }
 
 // g_S <- -(d/2) (2 - delta) S^-1,  S^-1 = W' W: tile (i >= j) = sum_{k >= i} W_ki' W_kj, both
 // triangles written.  (The sparse rating terms are added on top by kb_kl_rows / kb_finish_rows.)
 __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restrict__ sel, double half_mult)
 {
-    __shared__ double A[64][CH_NB + 1], B[64][CH_NB + 1];
+    __shared__ double A[64][TP], B[64][TP];
     const int h = sel[blockIdx.y];
     const int N = R.N, nb = R.nbk;
     int ti, tj;
@@ -839,8 +805,7 @@ __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restr
     const double *__restrict__ W = tabp(R, T_S_W, h);
     double *__restrict__ G = tabp(R, T_S_GRAD, h);
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
-    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-    double acc[4][4] = {};
+    f64x4 acc[2][2] = {};
     for (int k = ti; k < nb; k++) {
         __syncthreads();
         if (k == ti) tile_load_dense(A, linv + (size_t)k * CH_NB * CH_NB);
@@ -848,23 +813,18 @@ __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restr
         if (k == tj) tile_load_dense(B, linv + (size_t)k * CH_NB * CH_NB);
         else tile_load(B, W, N, k * 64, tj * 64);
         __syncthreads();
-        tile_mm_tn(acc, A, B, ty, tx);
+        tile_mfma<MM_TN>(acc, A, B, 64);
     }
     // the identity padding of a short last block must not leak into the sums: rows beyond N of a
     // padded Linv are unit vectors whose columns are beyond N too, and those outputs are dropped
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            const int r = ti * 64 + ty + 16 * u, c = tj * 64 + tx + 16 * v;
-            if (r < N && c < N) {
-                const double val = -half_mult * acc[u][v] * (r == c ? 1. : 2.);
-                if (ti != tj || c <= r) {
-                    G[(size_t)r * N + c] = val;
-                    if (r != c) G[(size_t)c * N + r] = val;
-                }
-            }
+    TILE_FOR_EACH(u, v, r) {
+        const int rr = ti * 64 + tile_row(u, r), cc = tj * 64 + tile_col(v);
+        if (rr < N && cc < N && (ti != tj || cc <= rr)) {
+            const double val = -half_mult * acc[u][v][r] * (rr == cc ? 1. : 2.);
+            G[(size_t)rr * N + cc] = val;
+            if (rr != cc) G[(size_t)cc * N + rr] = val;
         }
+    }
 }
 
 // slow hypotheses (no factor): g_S holds S^-1 from the LU route; apply the same scaling
@@ -874,6 +834,55 @@ __global__ __launch_bounds__(256) void kb_entropy_scale(double *__restrict__ g, 
     if (t >= (size_t)N * N) return;
     const int i = (int)(t / N), j = (int)(t % N);
     g[t] = -half_mult * g[t] * (i == j ? 1. : 2.);
+}
+
+// ---- projection onto the cone {eigenvalues >= min_eig} for the hypotheses whose certificate failed ----
+// project_psd (mn_active_pmf.py:42-67): eigh, and - only if the smallest eigenvalue is below
+// min_eig - rebuild V max(L, min_eig) V'.  The eigendecompositions of all such hypotheses of a
+// search iteration are ONE rocsolver_dsyevd_batched call on copies (in W); the rebuild is ours.
+__global__ void kb_ptrs(const Refs R, const int *__restrict__ sel, int nsel, int which)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y < nsel) R.ptrs[y] = tabp(R, which, sel[y]);
+}
+
+// cand <- V max(L, min_eig) V'  where W holds the eigenvectors as rocSOLVER leaves them (column-
+// major: row c of the row-major buffer is eigenvector c) and evals (ascending) the spectrum of
+// slot y; untouched when evals[0] >= min_eig.  Lower tiles computed, both triangles written (the
+// reference symmetrises the rebuilt matrix; this one is symmetric by construction).
+__global__ __launch_bounds__(256) void kb_rebuild(const Refs R, const int *__restrict__ sel, double min_eig)
+{
+    __shared__ double A[64][TP], B[64][TP];
+    const int y = blockIdx.y, h = sel[y];
+    const int N = R.N, nb = R.nbk;
+    const double *__restrict__ w = R.evals + (size_t)y * N;
+    if (!(w[0] < min_eig)) return;
+    int ti, tj;
+    tri_tile((int)blockIdx.x, ti, tj);       // ti >= tj
+    const double *__restrict__ V = tabp(R, T_S_W, h);
+    double *__restrict__ C = tabp(R, T_S_CAND, h);
+    f64x4 acc[2][2] = {};
+    for (int k = 0; k < nb; k++) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            const int ev = k * 64 + r;
+            const double m = ev < N ? (w[ev] > min_eig ? w[ev] : min_eig) : 0.;
+            const double vi = (ev < N && ti * 64 + c < N) ? V[(size_t)ev * N + ti * 64 + c] : 0.;
+            const double vj = (ev < N && tj * 64 + c < N) ? V[(size_t)ev * N + tj * 64 + c] : 0.;
+            A[r][c] = m * vi;
+            B[r][c] = vj;
+        }
+        __syncthreads();
+        tile_mfma<MM_TN>(acc, A, B, 64);
+    }
+    TILE_FOR_EACH(u, v, r) {
+        const int rr = ti * 64 + tile_row(u, r), cc = tj * 64 + tile_col(v);
+        if (rr < N && cc < N && (ti != tj || cc <= rr)) {
+            C[(size_t)rr * N + cc] = acc[u][v][r];
+            if (rr != cc) C[(size_t)cc * N + rr] = acc[u][v][r];
+        }
+    }
 }
 
 // ---- K2 inputs from the resident states ----------------------------------------------------------------
@@ -984,6 +993,9 @@ struct apmf_mn_batch {
     std::vector<char> fvalid_cand;
     std::vector<char> oivalid;    // OI_CUR holds the inverse of the current cov_latents
     std::vector<double *> tab_host;
+    // APMF_BATCH_STATS=1: counters of the last fit, printed to stderr when it returns
+    long st_iters, st_trials, st_grads, st_slow[4], st_slow_grad;
+    double st_slow_s;
 };
 
 namespace {
@@ -1076,38 +1088,79 @@ int write_ld(apmf_mn_batch *b, int h, const double *ld_s, const double *ld_o)
     return APMF_OK;
 }
 
-// One hypothesis left the fast path while its point (cand when trial, else cur) was evaluated:
-// finish the projection / factorisation with the single-matrix routines of dense.hip.
-int slow_fix(apmf_mn_batch *b, int h, int slow, bool trial, double min_eig)
+// Hypotheses left the fast path while their point (cand when trial, else cur) was evaluated:
+// finish the projection / factorisation.  cov_useritems projections of all of them are batched;
+// what is rarer still (a d x d projection, a factorisation that fails on a projected matrix) goes
+// through the single-matrix routines of dense.hip, one hypothesis at a time.
+int slow_fix_all(apmf_mn_batch *b, const std::vector<int> &slow, bool trial, double min_eig)
 {
     const Refs &R = b->R;
     const int H = R.H, N = R.N, d = R.d;
-    double *S = b->tab_host[(size_t)(trial ? T_S_CAND : T_S_CUR) * H + h];
-    double *O = b->tab_host[(size_t)(trial ? T_O_CAND : T_O_CUR) * H + h];
-    double *OI = b->tab_host[(size_t)(trial ? T_OI_CAND : T_OI_CUR) * H + h];
-    double *F = b->tab_host[(size_t)T_S_F * H + h];
-    char &fv = trial ? b->fvalid_cand[h] : b->fvalid[h];
-    if (slow & (SLOW_CERT_S | SLOW_FACT_S)) {
-        if (slow & SLOW_CERT_S) APMF_TRY(apmf_dense_project_psd(b->ctx, S, N, min_eig, nullptr));
-        // factor the (projected) matrix again, alone
-        APMF_CHECK_HIP(hipMemcpyAsync(F, S, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, b->ctx->stream));
-        std::vector<int> one(1, h);
+    hipStream_t st = b->ctx->stream;
+    const int tS = trial ? T_S_CAND : T_S_CUR, tO = trial ? T_O_CAND : T_O_CUR, tOI = trial ? T_OI_CAND : T_OI_CUR;
+    std::vector<int> proj, refac;
+    for (int h : slow) {
+        const int f = b->hs_host[h].slow;
+        if (f & SLOW_CERT_S) proj.push_back(h);
+        if (f & (SLOW_CERT_S | SLOW_FACT_S)) refac.push_back(h);
+    }
+    const size_t nn = (size_t)N * N;
+    if (!proj.empty()) {
+        const int np = (int)proj.size();
         const int *dsel;
-        APMF_TRY(upload_sel(b, 2, one, &dsel));
-        APMF_TRY(launch_factor(b, dsel, 1, 1));
-        int info = 0;
-        APMF_TRY(apmf_d2h(b->ctx, &info, R.info + 2 * h + 1, sizeof(int)));
-        if (info != 0) {
-            double ld = 0.;
-            APMF_TRY(apmf_dense_inv_logdet(b->ctx, S, N, nullptr, &ld));   // LU, like np.linalg.slogdet
-            APMF_TRY(write_ld(b, h, &ld, nullptr));
-            fv = 0;
-        } else {
+        APMF_TRY(upload_sel(b, 2, proj, &dsel));
+        hipLaunchKernelGGL(kb_copy, g2(nn, np, 256), dim3(256), 0, st, R, dsel, (int)T_S_CAND, (int)T_S_W, nn);
+        hipLaunchKernelGGL(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
+        APMF_CHECK_LAUNCH();
+        void *hv = nullptr;
+        APMF_TRY(apmf_dense_handle(b->ctx, &hv));
+        const rocblas_status rs = rocsolver_dsyevd_batched((rocblas_handle)hv, rocblas_evect_original,
+                                                           rocblas_fill_lower, N, R.ptrs, N, R.evals, N, R.evE, N,
+                                                           R.evinfo, np);
+        if (rs != rocblas_status_success) {
+            apmf_set_error("rocsolver_dsyevd_batched failed: rocblas_status %d", (int)rs);
+            return APMF_EHIP;
+        }
+        hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, np), dim3(256), 0, st, R, dsel, min_eig);
+        APMF_CHECK_LAUNCH();
+        std::vector<int> info(np);
+        APMF_TRY(apmf_d2h(b->ctx, info.data(), R.evinfo, (size_t)np * sizeof(int)));
+        for (int y = 0; y < np; y++)
+            if (info[y] != 0) {
+                apmf_set_error("rocsolver_dsyevd_batched did not converge (hypothesis %d, info=%d)", proj[y], info[y]);
+                return APMF_EHIP;
+            }
+    }
+    if (!refac.empty()) {
+        // factor the (projected) matrices again
+        const int nr = (int)refac.size();
+        const int *dsel;
+        APMF_TRY(upload_sel(b, 2, refac, &dsel));
+        hipLaunchKernelGGL(kb_copy, g2(nn, nr, 256), dim3(256), 0, st, R, dsel, tS, (int)T_S_F, nn);
+        APMF_CHECK_LAUNCH();
+        APMF_TRY(launch_factor(b, dsel, nr, 1));
+        std::vector<int> info(2 * (size_t)H);
+        APMF_TRY(apmf_d2h(b->ctx, info.data(), R.info, info.size() * sizeof(int)));
+        bool tables = false;
+        for (int h : refac) {
+            char &fv = trial ? b->fvalid_cand[h] : b->fvalid[h];
             fv = 1;
+            if (info[2 * h + 1] != 0) {
+                if (!tables) { APMF_TRY(read_tables(b)); tables = true; }
+                double ld = 0.;
+                APMF_TRY(apmf_dense_inv_logdet(b->ctx, b->tab_host[(size_t)tS * H + h], N, nullptr, &ld));   // LU
+                APMF_TRY(write_ld(b, h, &ld, nullptr));
+                fv = 0;
+            }
         }
     }
-    if (slow & (SLOW_CERT_O | SLOW_INV_O)) {
-        if (slow & SLOW_CERT_O) APMF_TRY(apmf_dense_project_psd(b->ctx, O, d, min_eig, nullptr));
+    bool tables = false;
+    for (int h : slow) {
+        const int f = b->hs_host[h].slow;
+        if (!(f & (SLOW_CERT_O | SLOW_INV_O))) continue;
+        if (!tables) { APMF_TRY(read_tables(b)); tables = true; }
+        double *O = b->tab_host[(size_t)tO * H + h], *OI = b->tab_host[(size_t)tOI * H + h];
+        if (f & SLOW_CERT_O) APMF_TRY(apmf_dense_project_psd(b->ctx, O, d, min_eig, nullptr));
         double ld = 0.;
         APMF_TRY(apmf_dense_inv_logdet(b->ctx, O, d, OI, &ld));
         APMF_TRY(write_ld(b, h, nullptr, &ld));
@@ -1123,14 +1176,19 @@ int handle_slow(apmf_mn_batch *b, const std::vector<int> &evaluated, bool trial,
     for (int h : evaluated)
         if (b->hs_host[h].status == ST_SLOW) slow.push_back(h);
     if (slow.empty()) return APMF_OK;
-    APMF_TRY(read_tables(b));
-    for (int h : slow) APMF_TRY(slow_fix(b, h, b->hs_host[h].slow, trial, min_eig));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int h : slow)
+        for (int k = 0; k < 4; k++)
+            if (b->hs_host[h].slow & (1 << k)) b->st_slow[k]++;
+    APMF_TRY(slow_fix_all(b, slow, trial, min_eig));
     const int *dsel;
     APMF_TRY(upload_sel(b, 2, slow, &dsel));
     const int tm = trial ? T_M_CAND : T_M_CUR, ts = trial ? T_S_CAND : T_S_CUR, to = trial ? T_O_CAND : T_O_CUR;
     APMF_TRY(launch_value(b, dsel, (int)slow.size(), tm, ts, to));
     APMF_TRY(launch_decide(b, dsel, (int)slow.size(), trial ? 0 : 1, 1, sigma_sq, sigma_u_sq));
-    return read_status(b);
+    const int rc = read_status(b);
+    b->st_slow_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 // gradient of the KL at the current point of the selected hypotheses (matrixnormal_gradient)
@@ -1145,6 +1203,7 @@ int launch_gradient(apmf_mn_batch *b, const std::vector<int> &grad, double sigma
     const int *dgrad, *dfast = nullptr;
     APMF_TRY(upload_sel(b, 1, grad, &dgrad));
     const double half_mult = R.d / 2.;
+    b->st_slow_grad += (long)slow.size();
     if (!slow.empty()) {
         APMF_TRY(read_tables(b));
         for (int h : slow) {
@@ -1240,6 +1299,10 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     BA(R.part, (size_t)H * R.n * 3 * sizeof(double));
     BA(R.out4, (size_t)H * 4 * sizeof(double));
     BA(R.oc, (size_t)H * sizeof(OmegaConsts));
+    BA(R.ptrs, (size_t)H * sizeof(double *));
+    BA(R.evals, (size_t)H * N * sizeof(double));
+    BA(R.evE, (size_t)H * N * sizeof(double));
+    BA(R.evinfo, (size_t)H * sizeof(int));
     BA(R.trace, (size_t)H * (trace_cap ? trace_cap : 1) * sizeof(double));
     BA(R.ei, (size_t)H * sizeof(int));
     BA(R.ej, (size_t)H * sizeof(int));
@@ -1385,6 +1448,10 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         s.slow = 0;
         s.accepted = 0;
     }
+    b->st_iters = b->st_trials = b->st_grads = b->st_slow_grad = 0;
+    b->st_slow[0] = b->st_slow[1] = b->st_slow[2] = b->st_slow[3] = 0;
+    b->st_slow_s = 0.;
+    const auto t_fit = std::chrono::steady_clock::now();
     // a hypothesis whose KL is known AND whose factor / inverse are in place resumes directly
     std::vector<int> init;
     for (int h = 0; h < H; h++)
@@ -1410,36 +1477,73 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     }
     if (max_steps == 0)
         for (int h = 0; h < H; h++) b->hs_host[h].status = ST_PAUSED;
-    std::vector<int> active, grad;
+    // Hypotheses whose trial left the fast path (a projection that really clips eigenvalues) are
+    // PARKED: the others keep iterating, and the parked ones' eigendecompositions run as one
+    // batched call once enough of them have gathered (or nothing else is left to do).  The
+    // hypotheses are independent, so the order in which they advance changes nothing.
+    std::vector<int> active, grad, parked, decided;
+    std::vector<char> is_parked(H, 0);
     for (;;) {
         active.clear();
         grad.clear();
         for (int h = 0; h < H; h++)
-            if (b->hs_host[h].status == ST_ACTIVE) {
+            if (b->hs_host[h].status == ST_ACTIVE && !is_parked[h]) {
                 active.push_back(h);
                 if (b->hs_host[h].need_grad) grad.push_back(h);
             }
-        if (active.empty()) break;
-        if (!grad.empty()) APMF_TRY(launch_gradient(b, grad, sigma_sq, sigma_u_sq, sigma_v_sq));
-        const int na = (int)active.size();
-        const int *dsel;
-        APMF_TRY(upload_sel(b, 0, active, &dsel));
-        const int nt32 = (R.N + 31) / 32;
-        hipLaunchKernelGGL(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig);
-        hipLaunchKernelGGL(kb_trial_small, dim3((unsigned)(((size_t)R.N * R.d + (size_t)R.d * R.d + 255) / 256), na),
-                           dim3(256), 0, st, R, dsel);
-        APMF_CHECK_LAUNCH();
-        APMF_TRY(launch_factor(b, dsel, na, 2));
-        hipLaunchKernelGGL(kb_small_spd, dim3(na), dim3(64), small_smem(R.d), st, R, dsel, (int)T_O_CAND,
-                           (int)T_OI_CAND, 1, min_eig);
-        APMF_TRY(launch_value(b, dsel, na, T_M_CAND, T_S_CAND, T_O_CAND));
-        APMF_TRY(launch_decide(b, dsel, na, 0, 0, sigma_sq, sigma_u_sq));
-        APMF_TRY(read_status(b));
-        for (int h : active) b->fvalid_cand[h] = 1;
-        APMF_TRY(handle_slow(b, active, true, min_eig, sigma_sq, sigma_u_sq));
+        if (active.empty() && parked.empty()) break;
+        decided.clear();
+        if (!active.empty()) {
+            b->st_iters++;
+            b->st_trials += (long)active.size();
+            b->st_grads += (long)grad.size();
+            if (!grad.empty()) APMF_TRY(launch_gradient(b, grad, sigma_sq, sigma_u_sq, sigma_v_sq));
+            const int na = (int)active.size();
+            const int *dsel;
+            APMF_TRY(upload_sel(b, 0, active, &dsel));
+            const int nt32 = (R.N + 31) / 32;
+            hipLaunchKernelGGL(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig);
+            hipLaunchKernelGGL(kb_trial_small, dim3((unsigned)(((size_t)R.N * R.d + (size_t)R.d * R.d + 255) / 256), na),
+                               dim3(256), 0, st, R, dsel);
+            APMF_CHECK_LAUNCH();
+            APMF_TRY(launch_factor(b, dsel, na, 2));
+            hipLaunchKernelGGL(kb_small_spd, dim3(na), dim3(64), small_smem(R.d), st, R, dsel, (int)T_O_CAND,
+                               (int)T_OI_CAND, 1, min_eig);
+            APMF_TRY(launch_value(b, dsel, na, T_M_CAND, T_S_CAND, T_O_CAND));
+            APMF_TRY(launch_decide(b, dsel, na, 0, 0, sigma_sq, sigma_u_sq));
+            APMF_TRY(read_status(b));
+            for (int h : active) {
+                b->fvalid_cand[h] = 1;
+                if (b->hs_host[h].status == ST_SLOW) {
+                    parked.push_back(h);
+                    is_parked[h] = 1;
+                } else {
+                    decided.push_back(h);
+                }
+            }
+        }
+        const size_t running = decided.size();      // hypotheses that stay on the fast path
+        const size_t want = std::min<size_t>(256, std::max<size_t>(1, running / 4));
+        if (!parked.empty() && (running == 0 || parked.size() >= want)) {
+            // hs_host still holds the parked hypotheses' slow masks: nothing has touched them since
+            APMF_TRY(handle_slow(b, parked, true, min_eig, sigma_sq, sigma_u_sq));
+            for (int h : parked) {
+                decided.push_back(h);
+                is_parked[h] = 0;
+            }
+            parked.clear();
+        }
         // F holds the factor of the trial point: the current one's only if the trial was accepted
-        for (int h : active) b->fvalid[h] = b->hs_host[h].accepted ? b->fvalid_cand[h] : 0;
+        for (int h : decided) b->fvalid[h] = b->hs_host[h].accepted ? b->fvalid_cand[h] : 0;
     }
+    if (const char *e = getenv("APMF_BATCH_STATS"))
+        if (e[0] == '1')
+            fprintf(stderr,
+                    "[apmf batch] H=%d N=%d: %ld iterations, %ld trials, %ld gradients (%ld without factor); slow "
+                    "exits: projection S %ld, factor S %ld, projection O %ld, inverse O %ld, %.3f s; total %.3f s\n",
+                    H, R.N, b->st_iters, b->st_trials, b->st_grads, b->st_slow_grad, b->st_slow[0], b->st_slow[1],
+                    b->st_slow[2], b->st_slow[3], b->st_slow_s,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fit).count());
     for (int h = 0; h < H; h++) {
         const HypState &s = b->hs_host[h];
         h_lr[h] = s.lr;

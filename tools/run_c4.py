@@ -86,17 +86,34 @@ def main():
     out['picks'] = [list(map(int, s_[2])) for s_ in steps_res[1:]]
     say('query loop done')
 
-    # one lookahead criterion over a 4-candidate pool (each candidate: 5 hypothesised ratings,
-    # each with a variational refit and a full-grid total-variance sweep)
+    # one lookahead criterion over a small pool (each candidate: 5 hypothesised ratings, each with a
+    # variational refit and a full-grid total-variance sweep): all hypotheses as ONE batch on the
+    # device, against the per-hypothesis path of round 1 (deep copies on 4 worker threads)
     pool = sorted(apmf.unrated)[:2]
     key = mn.KEY_FUNCS['total-variance']
-    for label, procs in (('threads4', None), ('sequential', 1)):
+    for label, env, procs in (('batched', '1', None), ('threads4', '0', None), ('sequential', '0', 1)):
+        if label == 'sequential' and os.environ.get('APMF_C4_SKIP_SEQ'):
+            continue
+        os.environ['APMF_LOOKAHEAD_BATCH'] = env
         t = time.perf_counter()
         with redirect_stdout(log):
             vals = apmf._get_key_vals(pool, key, procs=procs)
         out['lookahead_2cand_%s_s' % label] = time.perf_counter() - t
         out['lookahead_2cand_%s_vals' % label] = [float(x) for x in vals]
         say('lookahead %s done' % label)
+    os.environ['APMF_LOOKAHEAD_BATCH'] = '1'
+    # a bigger pool through the batch: hypotheses/s is what a full-grid lookahead costs
+    big = int(os.environ.get('APMF_C4_BIG_POOL', '100'))
+    pool_big = sorted(apmf.unrated)[:big]
+    t = time.perf_counter()
+    with redirect_stdout(log):
+        vals_big = apmf._get_key_vals(pool_big, key)
+    dt = time.perf_counter() - t
+    out['lookahead_%dcand_batched_s' % big] = dt
+    out['lookahead_hypotheses_per_s'] = 5 * big / dt
+    out['lookahead_full_grid_estimate_s'] = len(apmf.unrated) * 5 / (5 * big / dt)
+    out['lookahead_%dcand_argmin' % big] = list(map(int, pool_big[int(np.argmin(vals_big))]))
+    say('lookahead big pool done')
     out['lookahead_pool'] = [list(map(int, ij)) for ij in pool]
     stop.set()
     print(json.dumps(out, indent=1))
