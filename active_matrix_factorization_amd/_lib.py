@@ -53,6 +53,7 @@ _SIGS = {
     'apmf_d2d': (_i, [_vp, _vp, _vp, _sz]),
     'apmf_h2d_2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     'apmf_d2h_2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    'apmf_axpy_f64': (_i, [_vp, _vp, _vp, _dbl, _vp, _sz]),
     'apmf_cast_f64_f32': (_i, [_vp, _vp, _vp, _sz]),
     'apmf_cast_f32_f64': (_i, [_vp, _vp, _vp, _sz]),
     'apmf_ratings_create': (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp)]),
@@ -112,14 +113,44 @@ _DENSE_SIGS.update({
 })
 DENSE_LIB_PATH = os.path.join(_HERE, 'libapmf_dense.so')
 
+_COMM_SIGS = {
+    'apmf_comm_unique_id': (_i, [_vp]),
+    'apmf_comm_create': (_i, [_vp, _i, _i, _vp, C.POINTER(_vp)]),
+    'apmf_comm_destroy': (_i, [_vp]),
+    'apmf_comm_rank': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    'apmf_comm_allgather': (_i, [_vp, _vp, _vp, _vp, _sz]),
+    'apmf_comm_allreduce_f64': (_i, [_vp, _vp, _vp, _vp, _sz]),
+    'apmf_comm_barrier': (_i, [_vp, _vp]),
+}
+COMM_LIB_PATH = os.path.join(_HERE, 'libapmf_comm.so')
+
 _lib = None
 _dense = None
+_comm = None
 _lock = threading.Lock()
 
 
 def exported_symbols():
     """Names include/apmf.h declares (used by the CPU-side ABI test)."""
-    return sorted(_SIGS) + sorted(_DENSE_SIGS)
+    return sorted(_SIGS) + sorted(_DENSE_SIGS) + sorted(_COMM_SIGS)
+
+
+def load_comm():
+    """libapmf_comm.so (RCCL underneath): opened on first use by the multi-GPU path only."""
+    global _comm
+    load()
+    with _lock:
+        if _comm is None:
+            if not os.path.exists(COMM_LIB_PATH):
+                raise ApmfError(ENODEV, 'HIP extension %s is not built; there is no CPU fallback'
+                                % COMM_LIB_PATH)
+            lib = C.CDLL(COMM_LIB_PATH, mode=C.RTLD_GLOBAL)
+            for name, (res, args) in _COMM_SIGS.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _comm = lib
+    return _comm
 
 
 def load_dense():
@@ -436,6 +467,12 @@ class Context(object):
                                      host_2d.strides[0], m * isz, rows))
         return g
 
+    def copy(self, dst, src, nbytes, dst_off=0, src_off=0):
+        """device-to-device copy of nbytes (byte offsets into the two arrays), on the stream"""
+        if dst_off < 0 or src_off < 0 or dst_off + nbytes > dst.nbytes or src_off + nbytes > src.nbytes:
+            raise ValueError('copy outside the device arrays')
+        _check(self._lib.apmf_d2d(self._h, dst.ptr + int(dst_off), src.ptr + int(src_off), int(nbytes)))
+
     def write_bytes(self, darr, offset, host):
         """host bytes -> darr at byte `offset` (small patches of a resident array)"""
         host = np.ascontiguousarray(host)
@@ -452,6 +489,11 @@ class Context(object):
         _check(self._lib.apmf_d2h_2d(self._h, out.ctypes.data, m * isz, grid.ptr, ld * isz, m * isz,
                                      rows * lead))
         return out
+
+    def axpy(self, out, x, alpha, y, count, out_off=0, x_off=0, y_off=0):
+        """out[out_off:][:count] = x[x_off:][:count] + alpha * y[y_off:][:count] (float64 elements)"""
+        _check(self._lib.apmf_axpy_f64(self._h, out.ptr + 8 * int(out_off), x.ptr + 8 * int(x_off),
+                                       float(alpha), y.ptr + 8 * int(y_off), int(count)))
 
     def cast(self, src, dtype):
         dst = DeviceArray(self, src.shape, dtype)

@@ -389,3 +389,25 @@ extern "C" int apmf_cast_f32_f64(apmf_ctx *ctx, double *d_dst, const float *d_sr
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
+
+// out = x + alpha * y with the product and the sum rounded separately, like NumPy evaluates
+// `x + alpha * y` (the trial points of the learning-rate searches, pmf_cy.pyx:271-272)
+__global__ __launch_bounds__(256) void k_axpy(double *__restrict__ out, const double *__restrict__ x, double alpha,
+                                              const double *__restrict__ y, size_t count)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += stride) out[i] = __dadd_rn(x[i], __dmul_rn(alpha, y[i]));
+}
+
+extern "C" int apmf_axpy_f64(apmf_ctx *ctx, double *d_out, const double *d_x, double alpha, const double *d_y,
+                             size_t count)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (count == 0) return APMF_OK;
+    APMF_REQUIRE(d_out && d_x && d_y, "NULL pointer");
+    int blocks = (int)(cdiv64((int64_t)count, 256) < 4096 ? cdiv64((int64_t)count, 256) : 4096);
+    hipLaunchKernelGGL(k_axpy, dim3(blocks), dim3(256), 0, ctx->stream, d_out, d_x, alpha, d_y, count);
+    APMF_CHECK_LAUNCH();
+    return APMF_OK;
+}

@@ -1,22 +1,40 @@
 """Multi-GPU sharding of the hot path: one process per GPU, row blocks of
-users / items / candidate-grid rows per rank, torch.distributed (backend "nccl" = RCCL over
-xGMI on the GPUs, "gloo" in the CPU tests) for the exchange steps.
+users / items / candidate-grid rows per rank.  No PyTorch anywhere: the exchange steps are RCCL
+collectives on device pointers behind the C-ABI (libapmf_comm.so, csrc/comm.hip), and the
+rendezvous - shipping rank 0's 128-byte ncclUniqueId to the other ranks - is a plain TCP socket,
+which also carries the host-side collectives of the CPU tests (world 2 / 3 without any GPU).
 
 What shards, and what is exchanged:
   * candidate grid (K2): rank g sweeps the user rows of its block against all items.  No
     collective during the sweep; at the end an all-gather of one (value, flat index) pair
     and one partial sum per rank, merged with the single-device tie rule (lowest flat index).
+  * lookahead hypotheses: independent; rank g takes every world-th chunk and the per-hypothesis
+    results are all-gathered (bench.py's weak-scaling step).
   * PMF fit (K1): rank g owns a block of user rows and a block of item rows.  It computes
     grad_u for its users and grad_v for its items (each from the full ratings container,
-    no reduction needed), updates its blocks of the trial point, and the trial U, V are
-    all-gathered; the three sums of the log-likelihood are all-reduced, so every rank takes
-    the same accept / reject decision of fit_lls.
+    no reduction needed), updates its blocks of the trial point ON THE DEVICE, and the trial
+    U, V are all-gathered device to device; the three sums of the log-likelihood are
+    all-reduced, so every rank takes the same accept / reject decision of fit_lls.
   * Gibbs (K3): a half-sweep is split by row block, then the freshly sampled side is
     all-gathered before the other side's half-sweep (which needs the NEW values).
-The functions here are engine-agnostic: `engine` is any object with the four row-block
-methods of HipEngine (the product, over libapmf_hip.so).  PyTorch is plumbing only.
+The functions here are engine-agnostic: `engine` is any object with the block methods of
+HipEngine (the product, over libapmf_hip.so; arrays are DeviceArrays that stay resident between
+steps) - the CPU tests plug in an engine over the oracle whose arrays are NumPy.
+
+The reference's analogue is the forked multiprocessing.Pool that pickles whole model objects to
+its workers (active_pmf.py:739-770, bayes_pmf.py:385-422).
 """
+import os
+import socket
+import struct
+import time
+
 import numpy as np
+
+try:
+    from . import _lib
+except ImportError:
+    import _lib
 
 
 def block_size(n, world):
@@ -31,65 +49,246 @@ def block_range(n, rank, world):
     return lo, min(n, lo + bs)
 
 
+# ---------------------------------------------------------------------------- host transport
+_MAGIC = b'APMFCOMM1'
+
+
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack('<Q', len(payload)) + payload)
+
+
+def _recv_exact(sock, count):
+    buf = bytearray()
+    while len(buf) < count:
+        chunk = sock.recv(count - len(buf))
+        if not chunk:
+            raise ConnectionError('peer closed the connection')
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock):
+    (count,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    return _recv_exact(sock, count)
+
+
 class Comm(object):
-    """torch.distributed wrapper for host NumPy blocks; world == 1 needs no process group."""
+    """Rank `rank` of `world` processes on one node.
 
-    def __init__(self, device=None):
-        self.dist = None
-        self.rank, self.world = 0, 1
-        self.device = device
-        # torch is only touched when the caller has already imported it (a process group can
-        # only exist then).  Import order matters on ROCm: torch bundles its own rocBLAS /
-        # rocSOLVER, so in a multi-GPU run `import torch` must come BEFORE the first Context
-        # (libapmf_dense.so then binds to the copies torch loaded).
-        import sys
-        if 'torch' in sys.modules:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized():
-                self.dist = dist
-                self.rank, self.world = dist.get_rank(), dist.get_world_size()
+    Host side: a star of TCP connections to rank 0 (world == 1 opens nothing), used for the
+    rendezvous and for collectives on NumPy arrays.  Device side (when a Context is given): an
+    RCCL communicator created from the id rank 0 drew; collectives on DeviceArrays then run on the
+    context's stream over xGMI and nothing is staged through the host.  Without it DeviceArrays
+    are staged through the host socket (two ranks sharing one GPU in a rehearsal: RCCL refuses
+    two ranks on one device).
 
-    def _tensor(self, a):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        return t.to(self.device) if self.device is not None else t
+    `port`: rank 0 listens on the first free port of [port, port + span); the others try them in
+    order until the handshake (magic + run tag) succeeds, so a busy port - e.g. torchrun's own
+    store on MASTER_PORT - is skipped."""
+
+    def __init__(self, rank=0, world=1, addr='127.0.0.1', port=None, ctx=None, rccl=None, tag='',
+                 timeout=120., span=32):
+        self.rank, self.world = int(rank), int(world)
+        self.ctx = ctx
+        self._peers = None        # rank 0: sockets of ranks 1..world-1
+        self._root = None         # others: socket to rank 0
+        self._server = None
+        self._nccl = None
+        self._libc = None
+        if self.world > 1:
+            if port is None:
+                raise ValueError('a port is needed for world > 1')
+            self._connect(addr, int(port), (tag or '').encode(), timeout, span)
+        want_rccl = (ctx is not None) if rccl is None else bool(rccl)
+        if want_rccl:
+            if ctx is None:
+                raise ValueError('the RCCL communicator needs a Context')
+            self._libc = _lib.load_comm()
+            ident = np.zeros(128, np.uint8)
+            if self.rank == 0:
+                _lib._check(self._libc.apmf_comm_unique_id(ident.ctypes.data))
+            ident = np.frombuffer(self.bcast_bytes(ident.tobytes()), np.uint8).copy()
+            import ctypes as C
+            h = C.c_void_p()
+            # a failure here is fatal for the caller: there is no host fallback for a broken fabric
+            _lib._check(self._libc.apmf_comm_create(ctx._h, self.rank, self.world, ident.ctypes.data,
+                                                    C.byref(h)))
+            self._nccl = h.value
+
+    # -- set-up / tear-down -------------------------------------------------------------------
+    def _connect(self, addr, port, tag, timeout, span):
+        hello = _MAGIC + tag
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            for p in range(port, port + span):
+                try:
+                    srv.bind((addr, p))
+                    break
+                except OSError:
+                    continue
+            else:
+                raise OSError('no free port in [%d, %d)' % (port, port + span))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            self._server = srv
+            peers = {}
+            while len(peers) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.settimeout(timeout)
+                try:
+                    msg = _recv_msg(conn)
+                    if not msg.startswith(hello + b':'):
+                        conn.close()
+                        continue
+                    r = int(msg[len(hello) + 1:])
+                    _send_msg(conn, hello)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    peers[r] = conn
+                except (OSError, ValueError):
+                    conn.close()
+            self._peers = [peers[r] for r in range(1, self.world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                for p in range(port, port + span):
+                    try:
+                        s = socket.create_connection((addr, p), timeout=2.)
+                        s.settimeout(5.)
+                        _send_msg(s, hello + b':%d' % self.rank)
+                        if _recv_msg(s) == hello:
+                            s.settimeout(timeout)
+                            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                            self._root = s
+                            return
+                        s.close()
+                    except (OSError, ConnectionError, struct.error):
+                        pass
+                if time.time() > deadline:
+                    raise TimeoutError('rank %d: no rank 0 on %s:[%d, %d)' % (self.rank, addr, port, port + span))
+                time.sleep(.05)
+
+    def close(self):
+        if self._nccl is not None and self._libc is not None:
+            self._libc.apmf_comm_destroy(self._nccl)
+            self._nccl = None
+        for s in (self._peers or []) + [self._root, self._server]:
+            if s is not None:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+        self._peers = self._root = self._server = None
+
+    @property
+    def has_rccl(self):
+        return self._nccl is not None
+
+    # -- host collectives ----------------------------------------------------------------------
+    def allgather_bytes(self, payload):
+        """Every rank's payload, in rank order, on every rank."""
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(s) for s in self._peers]
+            blob = b''.join(struct.pack('<Q', len(p)) + p for p in parts)
+            for s in self._peers:
+                _send_msg(s, blob)
+            return parts
+        _send_msg(self._root, payload)
+        blob = _recv_msg(self._root)
+        parts, off = [], 0
+        for _ in range(self.world):
+            (count,) = struct.unpack_from('<Q', blob, off)
+            parts.append(blob[off + 8:off + 8 + count])
+            off += 8 + count
+        return parts
+
+    def bcast_bytes(self, payload):
+        """Rank 0's payload on every rank."""
+        return self.allgather_bytes(payload if self.rank == 0 else b'')[0]
+
+    def barrier(self):
+        """All ranks have arrived; with a Context, their streams have drained first."""
+        if self.ctx is not None:
+            if self._nccl is not None:
+                _lib._check(self._libc.apmf_comm_barrier(self.ctx._h, self._nccl))
+            else:
+                self.ctx.sync()
+        if self.world > 1:
+            self.allgather_bytes(b'')
+
+    # -- collectives on arrays: NumPy -> NumPy (socket), DeviceArray -> DeviceArray (RCCL) ------
+    def all_gather_blocks(self, block):
+        """Equal-sized blocks -> one array of world x block on every rank (rank order)."""
+        if isinstance(block, _lib.DeviceArray):
+            out = self.ctx.empty((self.world,) + block.shape, block.dtype)
+            if self._nccl is not None:
+                _lib._check(self._libc.apmf_comm_allgather(self.ctx._h, self._nccl, block.ptr, out.ptr,
+                                                           block.nbytes))
+            elif self.world == 1:
+                self.ctx.copy(out, block, block.nbytes)
+            else:
+                out.upload(self.all_gather_blocks(block.to_host()))
+            return out
+        block = np.ascontiguousarray(block)
+        parts = self.allgather_bytes(block.tobytes())
+        return np.frombuffer(b''.join(parts), block.dtype).reshape((self.world,) + block.shape).copy()
 
     def all_gather_rows(self, block, n):
-        """Row blocks (block_range layout) of an (n, ...) array -> the full array on every rank."""
-        if self.world == 1:
-            return np.ascontiguousarray(block)
-        import torch
+        """Row blocks (block_range layout, each padded to block_size rows) of an (n, ...) array ->
+        the array on every rank: NumPy (n, ...) / DeviceArray (world * block_size, ...)."""
         bs = block_size(n, self.world)
-        tail = block.shape[1:]
-        padded = np.zeros((bs,) + tail, block.dtype)
+        if isinstance(block, _lib.DeviceArray):
+            if block.shape[0] != bs:
+                raise ValueError('device blocks must be padded to block_size rows')
+            full = self.all_gather_blocks(block)
+            full.shape = (self.world * bs,) + block.shape[1:]
+            return full
+        block = np.asarray(block)
+        padded = np.zeros((bs,) + block.shape[1:], block.dtype)
         padded[:block.shape[0]] = block
-        out = torch.empty((self.world * bs,) + tail, dtype=self._tensor(padded).dtype,
-                          device=self.device if self.device is not None else 'cpu')
-        self.dist.all_gather_into_tensor(out, self._tensor(padded))
-        return out.cpu().numpy()[:n]
+        return self.all_gather_blocks(padded).reshape((self.world * bs,) + block.shape[1:])[:n]
 
     def all_reduce_sum(self, a):
-        a = np.asarray(a, np.float64)
+        """Element-wise float64 sum over the ranks.  Host arrays are summed in rank order (the same
+        bits on every rank); a DeviceArray is reduced in place by RCCL."""
+        if isinstance(a, _lib.DeviceArray):
+            if self._nccl is not None:
+                _lib._check(self._libc.apmf_comm_allreduce_f64(self.ctx._h, self._nccl, a.ptr, a.ptr, a.size))
+            elif self.world > 1:
+                a.upload(self.all_reduce_sum(a.to_host()))
+            return a
+        a = np.ascontiguousarray(a, np.float64)
         if self.world == 1:
             return a
-        t = self._tensor(a.copy())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return t.cpu().numpy()
+        total = np.zeros_like(a)
+        for part in self.all_gather_blocks(a):
+            total += part
+        return total
 
     def all_gather_scalars(self, row):
         """One small float64 row per rank -> (world, len(row)) on every rank."""
-        row = np.asarray(row, np.float64).reshape(1, -1)
-        if self.world == 1:
-            return row
-        import torch
-        out = torch.empty((self.world, row.shape[1]), dtype=torch.float64,
-                          device=self.device if self.device is not None else 'cpu')
-        self.dist.all_gather_into_tensor(out, self._tensor(row))
-        return out.cpu().numpy()
+        row = np.asarray(row, np.float64).reshape(-1)
+        return self.all_gather_blocks(row)
 
 
+def comm_from_env(ctx=None, port_offset=1):
+    """Comm of a process started by `python -m torch.distributed.run` / torchrun (used purely as
+    a process launcher: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) or by hand.  The listening port
+    is searched from MASTER_PORT + port_offset on (MASTER_PORT itself belongs to the launcher)."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(os.environ.get('MASTER_PORT', '29500')) + port_offset
+    tag = os.environ.get('TORCHELASTIC_RUN_ID', '') + ':' + os.environ.get('MASTER_PORT', '')
+    return Comm(rank, world, addr, port, ctx=ctx, tag=tag)
+
+
+# ---------------------------------------------------------------------------- the product's engine
 class HipEngine(object):
-    """Row-block operations on this rank's GPU through libapmf_hip.so (no fallback)."""
+    """Block operations on this rank's GPU through libapmf_hip.so (no fallback).  Arrays are
+    DeviceArrays: factors stay resident on the device between the steps of a fit."""
 
     def __init__(self, ctx, ratings, n, m, d, sigma_sq=1., sigma_u_sq=10., sigma_v_sq=10.,
                  subtract_mean=False, mean_rating=0.):
@@ -97,32 +296,57 @@ class HipEngine(object):
         self.hyper = (float(sigma_sq), float(sigma_u_sq), float(sigma_v_sq), bool(subtract_mean),
                       float(mean_rating))
         self.rt = ctx.ratings(ratings, n, m) if ratings is not None else None
+        self._grad = {}
 
-    # K1
+    # -- residency
+    def put(self, host, rows=None):
+        """(n, d) host array -> device array with `rows` >= n rows (zero padded)."""
+        host = np.ascontiguousarray(host, np.float64)
+        rows = host.shape[0] if rows is None else rows
+        arr = self.ctx.zeros((rows,) + host.shape[1:])
+        self.ctx.write_bytes(arr, 0, host)
+        return arr
+
+    def get(self, arr, n):
+        return arr.to_host()[:n]
+
+    # -- K1
     def grad_rows(self, side, lo, hi, U, V):
+        """Rows [lo, hi) of grad_u (side 0) / grad_v (side 1) in a full-size device array."""
         ctx, d = self.ctx, self.d
         sig, su, sv, sub, mr = self.hyper
         rows = self.n if side == 0 else self.m
-        g = ctx.empty((rows, d))
-        ctx.pmf_gradient_rows(self.rt, side, lo, hi, ctx.array(U), ctx.array(V), d, sig, su, sv, sub,
-                              mr, g)
-        return g.to_host()[lo:hi]
+        g = self._grad.get(side)
+        if g is None:
+            g = self._grad[side] = ctx.empty((rows, d))
+        ctx.pmf_gradient_rows(self.rt, side, lo, hi, U, V, d, sig, su, sv, sub, mr, g)
+        return g
+
+    def trial_block(self, X, G, lo, hi, lr, bs):
+        """X[lo:hi] + lr * G[lo:hi] as a block of bs rows (zero padded), on the device."""
+        d = self.d
+        out = self.ctx.zeros((bs, d))
+        if hi > lo:
+            self.ctx.axpy(out, X, lr, G, (hi - lo) * d, 0, lo * d, lo * d)
+        return out
 
     def ll_terms(self, U, V, u_lo, u_hi, v_lo, v_hi):
         _, _, _, sub, mr = self.hyper
-        return self.ctx.pmf_ll_terms(self.rt, self.ctx.array(U), self.ctx.array(V), self.d, sub, mr,
-                                     u_lo, u_hi, v_lo, v_hi)
+        return self.ctx.pmf_ll_terms(self.rt, U, V, self.d, sub, mr, u_lo, u_hi, v_lo, v_hi)
 
-    # K3
-    def gibbs_rows(self, side, lo, hi, oth, alpha, mu, beta, mean_sub, z):
+    # -- K3
+    def gibbs_rows(self, side, lo, hi, oth, alpha, mu, beta, mean_sub, z, bs):
+        """The freshly sampled rows [lo, hi) of `side` as a block of bs rows."""
         ctx, d = self.ctx, self.d
         rows = self.n if side == 0 else self.m
-        out = ctx.empty((rows, d))
-        ctx.gibbs_half_sweep_rows(self.rt, side, lo, hi, ctx.array(oth), d, ctx.array(alpha),
-                                  ctx.array(mu), float(beta), float(mean_sub), ctx.array(z), out)
-        return out.to_host()[lo:hi]
+        out = ctx.zeros((max(rows, lo + bs), d))
+        ctx.gibbs_half_sweep_rows(self.rt, side, lo, hi, oth, d, ctx.array(alpha), ctx.array(mu),
+                                  float(beta), float(mean_sub), z, out)
+        blk = ctx.empty((bs, d))
+        ctx.copy(blk, out, bs * d * 8, src_off=lo * d * 8)
+        return blk
 
-    # K2: a block of user rows against all items, float64
+    # -- K2: a block of user rows against all items, float64
     def score_rows(self, mean_users, mean_items, cross_rows, diag_users, diag_items, omega, mask_rows,
                    want):
         ctx, d = self.ctx, self.d
@@ -162,32 +386,41 @@ def sharded_select(engine, comm, n, m, mean, cross, diag, omega, mask=None, want
 
 
 # ---------------------------------------------------------------------------- K1
-def sharded_log_likelihood(engine, comm, U, V, n, m, sigma_sq, sigma_u_sq, sigma_v_sq):
+def _ll(engine, comm, U, V, n, m, sigma_sq, sigma_u_sq, sigma_v_sq):
     u_lo, u_hi = block_range(n, comm.rank, comm.world)
     v_lo, v_hi = block_range(m, comm.rank, comm.world)
     t = comm.all_reduce_sum(engine.ll_terms(U, V, u_lo, u_hi, v_lo, v_hi))
     return -t[0] / (2. * sigma_sq) - t[1] / (2. * sigma_u_sq) - t[2] / (2. * sigma_v_sq)
 
 
+def sharded_log_likelihood(engine, comm, U, V, n, m, sigma_sq, sigma_u_sq, sigma_v_sq):
+    bu, bv = block_size(n, comm.world) * comm.world, block_size(m, comm.world) * comm.world
+    return _ll(engine, comm, engine.put(U, bu), engine.put(V, bv), n, m, sigma_sq, sigma_u_sq, sigma_v_sq)
+
+
 def sharded_fit_lls(engine, comm, U, V, n, m, sigma_sq=1., sigma_u_sq=10., sigma_v_sq=10.,
                     learning_rate=1e-4, min_learning_rate=1e-10, stop_thresh=1e-2, max_steps=-1):
     """fit_lls (pmf_cy.pyx:257-291) with users and items row-sharded over the ranks.  Every
-    rank runs the same control flow on the same all-reduced LL.  Returns (U, V, ll_trace)."""
-    u_lo, u_hi = block_range(n, comm.rank, comm.world)
-    v_lo, v_hi = block_range(m, comm.rank, comm.world)
-    ll = lambda A, B: sharded_log_likelihood(engine, comm, A, B, n, m, sigma_sq, sigma_u_sq, sigma_v_sq)
-    U, V = np.array(U, np.float64), np.array(V, np.float64)
-    lr, old_ll, trace, converged = learning_rate, ll(U, V), [], False
+    rank runs the same control flow on the same all-reduced LL; the factors live in the engine's
+    arrays (device-resident for HipEngine) for the whole fit and each trial's exchange is two
+    all-gathers of row blocks plus one 3-element all-reduce.  Returns (U, V, ll_trace)."""
+    world = comm.world
+    u_lo, u_hi = block_range(n, comm.rank, world)
+    v_lo, v_hi = block_range(m, comm.rank, world)
+    bs_u, bs_v = block_size(n, world), block_size(m, world)
+    ll = lambda A, B: _ll(engine, comm, A, B, n, m, sigma_sq, sigma_u_sq, sigma_v_sq)
+    hU, hV = engine.put(U, bs_u * world), engine.put(V, bs_v * world)
+    lr, old_ll, trace, converged = learning_rate, ll(hU, hV), [], False
     while not converged and (max_steps < 0 or len(trace) < max_steps):
-        gU_blk = engine.grad_rows(0, u_lo, u_hi, U, V)
-        gV_blk = engine.grad_rows(1, v_lo, v_hi, U, V)
+        gU = engine.grad_rows(0, u_lo, u_hi, hU, hV)
+        gV = engine.grad_rows(1, v_lo, v_hi, hU, hV)
         while True:
             # each rank updates its own blocks of the trial point; the exchange step
-            nU = comm.all_gather_rows(U[u_lo:u_hi] + lr * gU_blk, n)
-            nV = comm.all_gather_rows(V[v_lo:v_hi] + lr * gV_blk, m)
+            nU = comm.all_gather_rows(engine.trial_block(hU, gU, u_lo, u_hi, lr, bs_u), n)
+            nV = comm.all_gather_rows(engine.trial_block(hV, gV, v_lo, v_hi, lr, bs_v), m)
             new_ll = ll(nU, nV)
             if new_ll > old_ll:
-                U, V = nU, nV
+                hU, hV = nU, nV
                 lr *= 1.25
                 if new_ll - old_ll < stop_thresh:
                     converged = True
@@ -198,7 +431,7 @@ def sharded_fit_lls(engine, comm, U, V, n, m, sigma_sq=1., sigma_u_sq=10., sigma
             if lr < min_learning_rate:
                 converged = True
                 break
-    return U, V, np.array(trace)
+    return engine.get(hU, n), engine.get(hV, m), np.array(trace)
 
 
 # ---------------------------------------------------------------------------- K3
@@ -207,10 +440,14 @@ def sharded_gibbs_sweep(engine, comm, users, items, n, m, alpha_u, mu_u, alpha_v
     """One Gibbs sweep (bayes_pmf.py:280-296): users from the OLD items, all-gather, then
     items from the NEW users, all-gather.  z_* are the full (rows, d) host draws, identical on
     every rank (same seeded NumPy stream)."""
-    u_lo, u_hi = block_range(n, comm.rank, comm.world)
-    v_lo, v_hi = block_range(m, comm.rank, comm.world)
+    world = comm.world
+    u_lo, u_hi = block_range(n, comm.rank, world)
+    v_lo, v_hi = block_range(m, comm.rank, world)
+    bs_u, bs_v = block_size(n, world), block_size(m, world)
+    h_items = engine.put(items, bs_v * world)
+    hz_u, hz_v = engine.put(z_users), engine.put(z_items)
     new_users = comm.all_gather_rows(
-        engine.gibbs_rows(0, u_lo, u_hi, items, alpha_u, mu_u, beta, mean_sub, z_users), n)
+        engine.gibbs_rows(0, u_lo, u_hi, h_items, alpha_u, mu_u, beta, mean_sub, hz_u, bs_u), n)
     new_items = comm.all_gather_rows(
-        engine.gibbs_rows(1, v_lo, v_hi, new_users, alpha_v, mu_v, beta, mean_sub, z_items), m)
-    return new_users, new_items
+        engine.gibbs_rows(1, v_lo, v_hi, new_users, alpha_v, mu_v, beta, mean_sub, hz_v, bs_v), m)
+    return engine.get(new_users, n), engine.get(new_items, m)

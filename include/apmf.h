@@ -79,6 +79,10 @@ int apmf_h2d_2d(apmf_ctx *ctx, void *d_dst, size_t dpitch, const void *h_src, si
                 size_t width, size_t height);
 int apmf_d2h_2d(apmf_ctx *ctx, void *h_dst, size_t dpitch, const void *d_src, size_t spitch,
                 size_t width, size_t height);
+/* d_out = d_x + alpha * d_y, product and sum rounded separately like NumPy's `x + alpha * y`
+ * (the trial points of the learning-rate searches, pmf_cy.pyx:271-272); in place allowed */
+int apmf_axpy_f64(apmf_ctx *ctx, double *d_out, const double *d_x, double alpha, const double *d_y,
+                  size_t count);
 /* element-wise f64 -> f32 / f32 -> f64 conversion on the device */
 int apmf_cast_f64_f32(apmf_ctx *ctx, float *d_dst, const double *d_src, size_t count);
 int apmf_cast_f32_f64(apmf_ctx *ctx, double *d_dst, const float *d_src, size_t count);
@@ -351,6 +355,26 @@ int apmf_full_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const dou
  * uses it only with device_rng switched on (the reference draws np.random.normal per row,
  * bayes_pmf.py:212-215). */
 int apmf_fill_normal_f64(apmf_ctx *ctx, double *d_out, int64_t count, uint64_t seed, uint64_t offset);
+
+/* ---- exchange steps of the sharded path (libapmf_comm.so, RCCL over xGMI) -----------------------
+ * Replace the reference's multiprocessing.Pool pickling of whole models (active_pmf.py:739-770,
+ * bayes_pmf.py:385-422) by collectives on device pointers, enqueued on the context's stream.
+ * One process per GPU; rank 0 draws the 128-byte id (apmf_comm_unique_id) and the host side hands
+ * it to the other ranks (sharding.py does so over a TCP socket). */
+typedef struct apmf_comm apmf_comm;
+int apmf_comm_unique_id(void *h_id128);
+int apmf_comm_create(apmf_ctx *ctx, int rank, int world, const void *h_id128, apmf_comm **out);
+int apmf_comm_destroy(apmf_comm *c);
+int apmf_comm_rank(const apmf_comm *c, int *rank, int *world);
+/* d_recv (world x bytes_per_rank) <- every rank's d_send, in rank order: the row blocks of U, V,
+ * of the freshly sampled Gibbs side, of diag(Sigma); the per-rank (sum, value, index) records */
+int apmf_comm_allgather(apmf_ctx *ctx, apmf_comm *c, const void *d_send, void *d_recv,
+                        size_t bytes_per_rank);
+/* element-wise sum over the ranks (the three sums of log_likelihood, pmf_cy.pyx:191-193) */
+int apmf_comm_allreduce_f64(apmf_ctx *ctx, apmf_comm *c, const double *d_send, double *d_recv,
+                            size_t count);
+/* every rank's stream has reached this point; synchronises the calling host thread with it */
+int apmf_comm_barrier(apmf_ctx *ctx, apmf_comm *c);
 
 #ifdef __cplusplus
 }

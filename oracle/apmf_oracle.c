@@ -541,3 +541,21 @@ long orc_mn_score_rows(int n, int m, int d, const double *mean, const double *R,
         }
     return cnt;
 }
+
+/* The same per-candidate path with the rows dealt to `threads` OpenMP threads: the all-cores */
+/* leg of bench.py's cpu_baseline.  Candidates are independent, so this is   */
+/* what the reference's multiprocessing.Pool would give at best.                              */
+long orc_mn_score_rows_omp(int n, int m, int d, const double *mean, const double *R,
+                           const double *C, int row_lo, int row_hi, double *var_out, int threads)
+{
+    int nm = n + m;
+    int i;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (i = row_lo; i < row_hi; i++)
+        for (int j = 0; j < m; j++) {
+            double mn, var;
+            orc_mn_pred_mean_var(n, mean, R, C, nm, d, i, j, &mn, &var, 0);
+            var_out[(long)(i - row_lo) * m + j] = var;
+        }
+    return (long)(row_hi - row_lo) * m;
+}

@@ -66,6 +66,9 @@ def lib():
         L.orc_mn_pred_means_vars_compact.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
         L.orc_mn_score_rows.restype = C.c_long
         L.orc_mn_score_rows.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp]
+        L.orc_mn_score_rows_omp.restype = C.c_long
+        L.orc_mn_score_rows_omp.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, _dp,
+                                            C.c_int]
         for name, nl in (('orc_full_tripexpect', 3), ('orc_full_quadexpect', 4),
                          ('orc_full_exp_squared', 2), ('orc_full_exp_a2bc', 3)):
             f = getattr(L, name)
@@ -158,6 +161,15 @@ def mn_score_rows(n, m, mean, R, Cl, row_lo, row_hi):
     mean, R, Cl = _f64(mean), _f64(R), _f64(Cl)
     out = np.empty((row_hi - row_lo, m))
     lib().orc_mn_score_rows(n, m, mean.shape[1], _p(mean), _p(R), _p(Cl), row_lo, row_hi, _p(out))
+    return out
+
+
+def mn_score_rows_threads(n, m, mean, R, Cl, row_lo, row_hi, threads):
+    """mn_score_rows with the rows dealt to `threads` OpenMP threads (bench.py's all-cores leg)."""
+    mean, R, Cl = _f64(mean), _f64(R), _f64(Cl)
+    out = np.empty((row_hi - row_lo, m))
+    lib().orc_mn_score_rows_omp(n, m, mean.shape[1], _p(mean), _p(R), _p(Cl), row_lo, row_hi, _p(out),
+                                int(threads))
     return out
 
 

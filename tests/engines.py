@@ -13,20 +13,37 @@ class OracleEngine(object):
         self.kw = dict(sig=sigma_sq, sig_u=sigma_u_sq, sig_v=sigma_v_sq, subtract_mean=subtract_mean,
                        mean_rating=mean_rating)
 
+    # arrays are plain NumPy here (the product's HipEngine keeps DeviceArrays)
+    def put(self, host, rows=None):
+        host = np.array(host, np.float64)
+        if rows is not None and rows > host.shape[0]:
+            host = np.vstack([host, np.zeros((rows - host.shape[0],) + host.shape[1:])])
+        return host
+
+    def get(self, arr, n):
+        return np.array(arr[:n])
+
     def grad_rows(self, side, lo, hi, U, V):
-        gU, gV = orc.pmf_gradient(self.ratings, U, V, **self.kw)
-        return (gU if side == 0 else gV)[lo:hi]
+        gU, gV = orc.pmf_gradient(self.ratings, U[:self.n], V[:self.m], **self.kw)
+        return gU if side == 0 else gV
+
+    def trial_block(self, X, G, lo, hi, lr, bs):
+        out = np.zeros((bs, self.d))
+        out[:hi - lo] = X[lo:hi] + lr * G[lo:hi]
+        return out
 
     def ll_terms(self, U, V, u_lo, u_hi, v_lo, v_hi):
         r = self.ratings
+        U, V = U[:self.n], V[:self.m]
         sel = r[(r[:, 0] >= u_lo) & (r[:, 0] < u_hi)]
         sq = orc.pmf_sq_error(sel, U, V, self.kw['subtract_mean'], self.kw['mean_rating']) if len(sel) else 0.
         return np.array([sq, (U[u_lo:u_hi] ** 2).sum(), (V[v_lo:v_hi] ** 2).sum()])
 
-    def gibbs_rows(self, side, lo, hi, oth, alpha, mu, beta, mean_sub, z):
+    def gibbs_rows(self, side, lo, hi, oth, alpha, mu, beta, mean_sub, z, bs):
         rows = self.n if side == 0 else self.m
         ptr, idx, rat = orc.csr_by_row(self.ratings, side, rows)
-        out = np.empty((hi - lo, self.d))
+        oth = np.ascontiguousarray(oth[:(self.m if side == 0 else self.n)])
+        out = np.zeros((bs, self.d))
         for t in range(lo, hi):
             out[t - lo] = orc.sample_feature(oth, idx[ptr[t]:ptr[t + 1]], rat[ptr[t]:ptr[t + 1]], alpha,
                                              mu, beta, mean_sub, z[t])
