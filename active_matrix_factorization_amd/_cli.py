@@ -19,15 +19,43 @@ def _bool_opt(parser, name, default=False):
     parser.add_argument('--no-' + name, action='store_false', dest=name.replace('-', '_'))
 
 
+class _RestrictedUnpickler(pickle.Unpickler):
+    """Data and result files only ever need NumPy arrays, builtin containers, argparse.Namespace and
+    this package's own model classes; anything else in a pickle handed to the CLI is refused instead
+    of executed (--load-data / --load-model took arbitrary pickles)."""
+    _ALLOWED = {
+        ('numpy', 'ndarray'), ('numpy', 'dtype'), ('numpy.core.multiarray', '_reconstruct'),
+        ('numpy._core.multiarray', '_reconstruct'), ('numpy.core.multiarray', 'scalar'),
+        ('numpy._core.multiarray', 'scalar'), ('numpy._core.numeric', '_frombuffer'),
+        ('numpy.core.numeric', '_frombuffer'), ('argparse', 'Namespace'), ('builtins', 'set'),
+        ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'range'), ('builtins', 'complex'),
+        ('collections', 'OrderedDict'), ('copyreg', '_reconstructor'), ('builtins', 'object'),
+    }
+    _OWN_MODULES = ('pmf_cy', 'mn_active_pmf', 'active_pmf', 'bayes_pmf', '_active_base')
+
+    def find_class(self, module, name):
+        base = module.split('.')[-1]
+        own = base in self._OWN_MODULES and (module == base or module.startswith('active_matrix_factorization_amd.'))
+        if (module, name) in self._ALLOWED or own:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("refusing to load %s.%s from a pickle: only NumPy arrays, builtin "
+                                     "containers and this package's model classes are accepted (convert the "
+                                     "file to .npz)" % (module, name))
+
+
+def restricted_load(f):
+    return _RestrictedUnpickler(f).load()
+
+
 def _load_data(path):
-    """.npz/.npy via numpy, else the pickles choose_training.py / generate.py write (our own
-    or the user's files; reference-shipped pickles are never loaded by the tests)."""
+    """.npz/.npy via numpy (nothing is executed), else a pickle of plain arrays / containers such
+    as choose_training.py and generate.py write, through the restricted unpickler."""
     with open(path, 'rb') as f:
         try:
             data = np.load(f, allow_pickle=False)
         except Exception:
             f.seek(0)
-            data = pickle.load(f)
+            data = restricted_load(f)
         if isinstance(data, np.ndarray):
             data = {'_real': data}
         return {k: data[k] for k in ('_real', '_ratings', '_rating_vals', '_test_on', '_is_new_item')
@@ -143,7 +171,7 @@ def run_cli(key_funcs, compare, kind):
                        u_mean=args.u_mean, u_std=args.u_std, v_mean=args.v_mean, v_std=args.v_std)
         if args.load_model:
             with open(args.load_model, 'rb') as f:
-                apmf = pickle.load(f)['_initial_apmf']
+                apmf = restricted_load(f)['_initial_apmf']
         res = compare(args.keys, real_ratings_vals=real_ratings_vals, apmf=apmf, knowable=knowable,
                       **common, **gen)
     _save(res, args)

@@ -7,6 +7,7 @@ hipMalloc'd buffer, and each method maps 1:1 onto a C entry point.
 """
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -93,6 +94,9 @@ _DENSE_SIGS = {
     'apmf_mn_kl_value': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, C.POINTER(_dbl)]),
     'apmf_mn_kl_gradient': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     'apmf_full_kl_gradient': (_i, [_vp, _vp, _i, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp]),
+    'apmf_full_kl_value': (_i, [_vp, _vp, _i, _vp, _vp, _dbl, _dbl, _dbl, C.POINTER(_dbl)]),
+    'apmf_full_fit_normal': (_i, [_vp, _vp, _i, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.POINTER(_dbl),
+                                  C.POINTER(_dbl), _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
     'apmf_mn_fit_normal': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.POINTER(_dbl),
                                 C.POINTER(_dbl), _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
 }
@@ -195,9 +199,29 @@ def load():
     return _lib
 
 
+class _LateTorchGuard(object):
+    """libapmf_dense.so links the system rocBLAS / rocSOLVER.  PyTorch bundles its own copies
+    under the same SONAMEs; importing torch AFTER the system copies are loaded crashes inside
+    torch's static initialisers (a segmentation fault, not an exception).  The product itself never
+    imports torch; this import hook turns the one remaining way to hit the clash - user code
+    importing torch later in the same process - into an ImportError that says what to do.
+    (torch imported first is fine: the dense library then binds to the copies torch loaded.)"""
+
+    def find_spec(self, name, path=None, target=None):
+        if name == 'torch' and 'torch' not in sys.modules and os.environ.get('APMF_ALLOW_LATE_TORCH') != '1':
+            raise ImportError(
+                "import torch after active_matrix_factorization_amd has loaded libapmf_dense.so: PyTorch's "
+                "bundled rocBLAS / rocSOLVER clash with the system copies already loaded and the process "
+                "would crash.  Import torch BEFORE the first use of this package (or run the two in "
+                "separate processes); APMF_ALLOW_LATE_TORCH=1 disables this check.")
+        return None
+
+
 def _open_dense():
     global _dense
     if _dense is None and os.path.exists(DENSE_LIB_PATH):
+        if 'torch' not in sys.modules and not any(isinstance(f, _LateTorchGuard) for f in sys.meta_path):
+            sys.meta_path.insert(0, _LateTorchGuard())
         lib = C.CDLL(DENSE_LIB_PATH, mode=C.RTLD_GLOBAL)
         for name, (res, args) in _DENSE_SIGS.items():
             fn = getattr(lib, name)
@@ -619,6 +643,25 @@ class Context(object):
     def full_kl_gradient(self, rt, d, mean, cov, sig, sig_u, sig_v, g_mean, g_cov):
         _check(load_dense().apmf_full_kl_gradient(self._h, rt._h, d, _ptr(mean), _ptr(cov), sig, sig_u, sig_v,
                                                   _ptr(g_mean), _ptr(g_cov)))
+
+    def full_kl_value(self, rt, d, mean, cov, sig, sig_u, sig_v):
+        kl = _dbl(0.)
+        _check(load_dense().apmf_full_kl_value(self._h, rt._h, d, _ptr(mean), _ptr(cov), sig, sig_u, sig_v,
+                                               C.byref(kl)))
+        return kl.value
+
+    def full_fit_normal(self, rt, d, mean, cov, sig, sig_u, sig_v, min_eig, lr, old_kl=None, max_steps=-1,
+                        max_trace=1 << 16):
+        """Device-resident ActivePMF.fit_normal_kls steps; returns (kl_trace, steps, lr, converged, old_kl)."""
+        trace = np.empty(max(max_trace, 1), np.float64)
+        lr_io = _dbl(lr)
+        kl_io = _dbl(float('nan') if old_kl is None else old_kl)
+        steps, conv = _i64(0), _i(0)
+        _check(load_dense().apmf_full_fit_normal(self._h, rt._h, d, _ptr(mean), _ptr(cov), sig, sig_u, sig_v,
+                                                 float(min_eig), C.byref(lr_io), C.byref(kl_io), max_steps,
+                                                 trace.ctypes.data, max_trace, C.byref(steps), C.byref(conv)))
+        return (trace[:min(steps.value, max_trace)].copy(), steps.value, lr_io.value, bool(conv.value),
+                kl_io.value)
 
     def mn_fit_normal(self, rt, d, mean, cov_ui, cov_lat, sig, sig_u, sig_v, min_eig, lr, old_kl=None,
                       max_steps=-1, max_trace=1 << 16):

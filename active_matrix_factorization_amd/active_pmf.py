@@ -78,15 +78,35 @@ class ActivePMF(_ActiveBase):
         div += ((mean[vs] ** 2).sum() + cov[vs, vs].sum()) / (2 * self.sigma_v_sq)
         return div - logabsdet(cov) / 2
 
+    def _fit_normal_device(self, max_steps):
+        """fit_normal_kls with the approximation resident on the device (apmf_full_fit_normal):
+        gradient, trial point, projection, KL and the accept / reject decision of the search
+        (active_pmf.py:250-288) without the K x K covariance crossing PCIe per trial; the host
+        arrays are re-bound after every call, like the reference re-binds them per accepted step."""
+        if self.mean is None or self.cov is None:
+            raise ValueError("run initialize_approx first")
+        ctx, rt = self._device_ratings()
+        dm, dc = ctx.array(self.mean, np.float64), ctx.array(self.cov, np.float64)
+        lr, old_kl, converged = self.normal_learning_rate, None, False
+        while not converged:
+            trace, steps, lr, converged, old_kl = ctx.full_fit_normal(
+                rt, self.latent_d, dm, dc, float(self.sigma_sq), float(self.sigma_u_sq), float(self.sigma_v_sq),
+                self.min_eig, lr, old_kl, max_steps=max_steps)
+            if steps:
+                self.mean, self.cov = dm.to_host(), dc.to_host()
+            yield trace, converged
+
     def fit_normal_kls(self):
-        def step(cand):
-            self.mean, self.cov = cand
+        '''Projected gradient descent on the KL, yielding it after each accepted step
+        (active_pmf.py:250-288).'''
+        for trace, _ in self._fit_normal_device(max_steps=1):
+            for kl in trace:
+                yield float(kl)
 
-        def project(k, x):
-            return x if k == 0 else project_psd(x, min_eig=self.min_eig)
-
-        return self._descend(lambda: (self.mean, self.cov), lambda: normal_gradient(self), step,
-                             project, self.kl_divergence)
+    def fit_normal(self):
+        '''The whole fit in one device call (same steps as exhausting fit_normal_kls).'''
+        for _ in self._fit_normal_device(max_steps=-1):
+            pass
 
     def mean_meandiff(self):
         p = np.hstack((self.users.reshape(-1), self.items.reshape(-1)))

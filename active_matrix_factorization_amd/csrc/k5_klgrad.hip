@@ -573,6 +573,41 @@ __global__ __launch_bounds__(256) void k_full_grad_init(size_t K, size_t nd, dou
     }
 }
 
+// data and prior terms of ActivePMF.kl_divergence (active_pmf.py:202-246) from the swept grids:
+// out[0] = sum_ratings (var + mean^2 - 2 r mean + r^2), out[1] = sum_u (mean^2 + cov_ii), out[2] = same over v
+__global__ __launch_bounds__(256) void k_full_kl_terms(int n, int m, int d, int ld, const int64_t *__restrict__ ptr,
+                                                       const int32_t *__restrict__ idx,
+                                                       const double *__restrict__ val,
+                                                       const double *__restrict__ pvar,
+                                                       const double *__restrict__ pmean,
+                                                       const double *__restrict__ mean,
+                                                       const double *__restrict__ cov, double *__restrict__ out)
+{
+    __shared__ double sh[3][256];
+    const size_t K = (size_t)(n + m) * d, nd = (size_t)n * d;
+    double a = 0., bu = 0., bv = 0.;
+    for (int i = threadIdx.x; i < n; i += 256)
+        for (int64_t t = ptr[i]; t < ptr[i + 1]; t++) {
+            const size_t o = (size_t)i * ld + idx[t];
+            const double r = val[t], pm = pmean[o];
+            a += pvar[o] + pm * pm - 2. * r * pm + r * r;
+        }
+    for (size_t k = threadIdx.x; k < K; k += 256) {
+        const double v = mean[k] * mean[k] + cov[k * K + k];
+        if (k < nd) bu += v;
+        else bv += v;
+    }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = bu; sh[2][threadIdx.x] = bv;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int z = 0; z < 3; z++) sh[z][threadIdx.x] += sh[z][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int z = 0; z < 3; z++) out[z] = sh[z][0];
+}
+
 } // namespace
 
 extern "C" {
@@ -694,6 +729,103 @@ int apmf_full_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const dou
                        r->idx[1], r->val[1], d_mean, d_cov, inv_sig, d_g_mean, d_g_cov);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
+}
+
+// ActivePMF.kl_divergence (active_pmf.py:202-246): the K2-full sweep at the rated entries, the prior
+// terms, and log|det cov| / 2
+extern "C" int apmf_full_score_grid_f64(apmf_ctx *ctx, int n, int m, int d, int ld, const double *d_mean,
+                                        const double *d_cov, const uint8_t *d_mask, double *d_var,
+                                        double *d_pmean, double *d_sum, int want, double *d_best_val,
+                                        int64_t *d_best_idx);
+extern "C" int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, int *h_projected);
+
+int apmf_full_kl_value(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean, const double *d_cov,
+                       double sigma_sq, double sigma_u_sq, double sigma_v_sq, double *h_kl)
+{
+    APMF_REQUIRE(ctx && r && d_mean && d_cov && h_kl, "NULL operand");
+    APMF_REQUIRE(d >= 1 && d <= FG_D, "latent_d=%d unsupported by the full-covariance path (1..%d)", d, FG_D);
+    const int n = r->n, m = r->m, ld = round_up(m, APMF_GRID_ALIGN);
+    const size_t K = ((size_t)n + m) * d;
+    double *grids = nullptr;
+    APMF_TRY(apmf_malloc(ctx, (2 * (size_t)n * ld + 8) * sizeof(double), (void **)&grids));
+    double *pvar = grids, *pmean = grids + (size_t)n * ld, *out3 = pmean + (size_t)n * ld;
+    int rc = apmf_full_score_grid_f64(ctx, n, m, d, ld, d_mean, d_cov, nullptr, pvar, pmean, nullptr, 0, nullptr, nullptr);
+    double t3[3] = {0., 0., 0.}, ld_c = 0.;
+    if (rc == APMF_OK) {
+        hipLaunchKernelGGL(k_full_kl_terms, dim3(1), dim3(256), 0, ctx->stream, n, m, d, ld, r->ptr[0], r->idx[0],
+                           r->val[0], pvar, pmean, d_mean, d_cov, out3);
+        rc = apmf_d2h(ctx, t3, out3, sizeof(t3));
+    }
+    (void)apmf_free(ctx, grids);
+    if (rc == APMF_OK) rc = apmf_dense_inv_logdet(ctx, d_cov, (int)K, nullptr, &ld_c);
+    if (rc != APMF_OK) return rc;
+    *h_kl = t3[0] / (2. * sigma_sq) + t3[1] / (2. * sigma_u_sq) + t3[2] / (2. * sigma_v_sq) - ld_c / 2.;
+    return APMF_OK;
+}
+
+// ActivePMF.fit_normal_kls / fit_normal (active_pmf.py:250-288) with the approximation resident on
+// the device: gradient, trial point, projection, KL and the accept / reject decision of the
+// learning-rate search without the K x K covariance crossing PCIe (K = (n+m) d).  Same calling
+// convention as apmf_mn_fit_normal.
+int apmf_full_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_mean, double *d_cov,
+                         double sigma_sq, double sigma_u_sq, double sigma_v_sq, double min_eig, double *h_lr,
+                         double *h_old_kl, int64_t max_steps, double *h_kl_trace, int64_t trace_cap,
+                         int64_t *h_steps, int *h_converged)
+{
+    APMF_REQUIRE(ctx && r && d_mean && d_cov && h_lr && h_old_kl && h_steps && h_converged, "NULL operand");
+    APMF_REQUIRE(trace_cap == 0 || h_kl_trace, "h_kl_trace is NULL");
+    APMF_REQUIRE(d >= 1 && d <= FG_D, "latent_d=%d unsupported by the full-covariance path (1..%d)", d, FG_D);
+    const size_t K = ((size_t)r->n + r->m) * d;
+    const size_t cnt[2] = {K, K * K};
+    double *cur[2] = {d_mean, d_cov}, *grad[2] = {nullptr, nullptr}, *cand[2] = {nullptr, nullptr};
+    int rc = APMF_OK;
+    for (int k = 0; k < 2 && rc == APMF_OK; k++) {
+        rc = apmf_malloc(ctx, cnt[k] * sizeof(double), (void **)&grad[k]);
+        if (rc == APMF_OK) rc = apmf_malloc(ctx, cnt[k] * sizeof(double), (void **)&cand[k]);
+    }
+    double lr = *h_lr, old_kl = *h_old_kl;
+    int64_t steps = 0;
+    bool converged = false;
+    if (rc == APMF_OK && old_kl != old_kl)
+        rc = apmf_full_kl_value(ctx, r, d, cur[0], cur[1], sigma_sq, sigma_u_sq, sigma_v_sq, &old_kl);
+    while (rc == APMF_OK && !converged && (max_steps < 0 || steps < max_steps)) {
+        rc = apmf_full_kl_gradient(ctx, r, d, cur[0], cur[1], sigma_sq, sigma_u_sq, sigma_v_sq, grad[0], grad[1]);
+        while (rc == APMF_OK) {
+            for (int k = 0; k < 2; k++)
+                hipLaunchKernelGGL(k_trial_point, dim3((unsigned)((cnt[k] + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   cnt[k], cur[k], grad[k], lr, cand[k]);
+            if (hipGetLastError() != hipSuccess) { apmf_set_error("kernel launch failed"); rc = APMF_EHIP; break; }
+            if ((rc = apmf_dense_project_psd(ctx, cand[1], (int)K, min_eig, nullptr)) != APMF_OK) break;
+            double new_kl = 0.;
+            if ((rc = apmf_full_kl_value(ctx, r, d, cand[0], cand[1], sigma_sq, sigma_u_sq, sigma_v_sq, &new_kl)) != APMF_OK)
+                break;
+            if (new_kl < old_kl) {
+                for (int k = 0; k < 2; k++)
+                    (void)hipMemcpyAsync(cur[k], cand[k], cnt[k] * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+                lr *= 1.25;
+                if (old_kl - new_kl < .005) converged = true;
+                if (steps < trace_cap) h_kl_trace[steps] = new_kl;
+                steps++;
+                old_kl = new_kl;
+                break;
+            }
+            lr *= .5;
+            if (lr < 1e-10) { converged = true; break; }
+        }
+    }
+    if (rc == APMF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        apmf_set_error("stream synchronisation failed");
+        rc = APMF_EHIP;
+    }
+    for (int k = 0; k < 2; k++) {
+        if (grad[k]) (void)apmf_free(ctx, grad[k]);
+        if (cand[k]) (void)apmf_free(ctx, cand[k]);
+    }
+    *h_lr = lr;
+    *h_old_kl = old_kl;
+    *h_steps = steps;
+    *h_converged = converged ? 1 : 0;
+    return rc;
 }
 
 } // extern "C"

@@ -350,6 +350,17 @@ int apmf_full_kl_gradient(apmf_ctx *ctx, const apmf_ratings *r, int d, const dou
                           const double *d_cov, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
                           double *d_g_mean, double *d_g_cov);
 
+/* ActivePMF.kl_divergence (active_pmf.py:202-246) and fit_normal_kls / fit_normal (:250-288) of the
+ * full-covariance approximation, resident on the device: d_mean (K), d_cov (K x K), K = (n+m) d.
+ * Calling convention of apmf_mn_fit_normal. */
+int apmf_full_kl_value(apmf_ctx *ctx, const apmf_ratings *r, int d, const double *d_mean,
+                       const double *d_cov, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                       double *h_kl);
+int apmf_full_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_mean, double *d_cov,
+                         double sigma_sq, double sigma_u_sq, double sigma_v_sq, double min_eig,
+                         double *h_lr, double *h_old_kl, int64_t max_steps, double *h_kl_trace,
+                         int64_t trace_cap, int64_t *h_steps, int *h_converged);
+
 /* Optional device-side standard-normal draws for the Gibbs sweeps (Philox4x32-10 + Box-Muller,
  * counter = offset + index / 2): d_out[0..count) ~ N(0, 1).  Not NumPy's stream - BayesianPMF
  * uses it only with device_rng switched on (the reference draws np.random.normal per row,

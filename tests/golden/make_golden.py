@@ -77,6 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -118,6 +119,11 @@ def main():
                                    num_ratings=per_user, latent_dimension=d)
 
     timings = {}
+    if args.only == 'r2':
+        round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
+        if not args.keep:
+            shutil.rmtree(args.scratch)
+        return
 
     # ------------------------------------------------------------------ A. PMF
     def pmf_case(name, ratings, d, subtract_mean, fit=True, sig=None):
@@ -445,6 +451,8 @@ def main():
          exp_a2bc=mnx.exp_a2bc(M_, R_, C_, 1, 1, 2, 0, 4, 2),
          exp_dotprod_sq=mnx.exp_dotprod_sq(2, M_, R_, C_, 1, 2))
 
+    round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
+
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
         json.dump(dict(timings, host='build container, 1 thread',
@@ -453,6 +461,117 @@ def main():
 
     if not args.keep:
         shutil.rmtree(args.scratch)
+
+
+def round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print):
+    """Fixtures added in round 2: BASELINE.json configs[3] and configs[2] at their real sizes, and
+    the minibatch fit."""
+    from itertools import islice
+    MN = mn_active_pmf.MNActivePMF
+
+    # ---------------- G. configs[3]: DrugBank 94 x 425, rank 5, 500 known entries
+    # (results/drugbank-94x425/Makefile: choose_training.py --drugbank --n-pick 500; the matrix is
+    # the reference's own drugbank/subset_94x425.npy, read here, its values stored as data)
+    t0 = time.perf_counter()
+    real = np.load(os.path.join(REF, 'drugbank', 'subset_94x425.npy')).astype(float)
+    n, m = real.shape
+    seed(60)
+    # every row and column known at least once (the Gibbs and the fit need no empty rows), then
+    # uniformly up to 500
+    mask = np.zeros((n, m), bool)
+    mask[np.arange(n), np.random.randint(0, m, n)] = True
+    mask[np.random.randint(0, n, m), np.arange(m)] = True
+    free = np.flatnonzero(~mask.ravel())
+    mask.ravel()[np.random.choice(free, max(0, 500 - int(mask.sum())), replace=False)] = True
+    ii, jj = mask.nonzero()
+    perm = np.random.permutation(ii.size)
+    ii, jj = ii[perm], jj[perm]
+    ratings = np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+    seed(61)
+    a = MN(ratings.copy(), latent_d=5, rating_values=(0., 1.), discrete_expectations=True)
+    a.do_fit()
+    a.initialize_approx()
+    out = dict(real=real.astype(np.int8), ratings=ratings, users=a.users, items=a.items,
+               sigma=np.array([a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq]), kl0=a.kl_divergence())
+    pm, pv = a.approx_pred_means_vars()
+    out.update(p_mean0=pm, p_var0=pv, pick0=np.array(a.pick_query_point(key=MN.pred_variance)))
+    kls = list(islice(a.fit_normal_kls(), 3))
+    pm, pv = a.approx_pred_means_vars()
+    out.update(kl_trace3=np.array(kls), mean3=a.mean.copy(), cov_latents3=a.cov_latents.copy(),
+               cov_diag3=np.diag(a.cov_useritems).copy(), p_mean3=pm, p_var3=pv)
+    _print('c4: 3 steps done, %.0f s' % (time.perf_counter() - t0))
+    rest = list(a.fit_normal_kls())          # to convergence (a fresh search from the 3-step state)
+    pm, pv = a.approx_pred_means_vars()
+    out.update(fit_steps=len(rest), kl_fit=rest[-1], kl_trace_fit=np.array(rest), mean_fit=a.mean.copy(),
+               cov_useritems_fit=a.cov_useritems.copy(), cov_latents_fit=a.cov_latents.copy(),
+               p_mean_fit=pm, p_var_fit=pv, total_variance_fit=a._total_variance(),
+               pick_fit=np.array(a.pick_query_point(key=MN.pred_variance)),
+               entropy_fit=a._approx_entropy())
+    _print('c4: fitted in %d more steps, %.0f s' % (len(rest), time.perf_counter() - t0))
+    cand = sorted(a.unrated)[11]
+    out.update(cand=np.array(cand), exp_total_variance=a.exp_total_variance(cand))
+    _print('c4: lookahead done, %.0f s' % (time.perf_counter() - t0))
+    save('mn_c4_94x425_d5', **out)
+
+    # ---------------- H. minibatch fit (pmf_cy.pyx:308-381)
+    seed(70)
+    r, _, _ = fake(50, 40, 3, 8)
+    seed(71)
+    p = pmf_cy.ProbabilisticMatrixFactorization(r.copy(), latent_d=3)
+    U0, V0 = p.users.copy(), p.items.copy()
+    seed(72)
+    errs = list(islice(p.fit_minibatches(64), 2))
+    out = dict(ratings=r, U0=U0, V0=V0, batch_size=64, seed_fit=72, train_errs=np.array(errs, np.float64),
+               users=p.users.copy(), items=p.items.copy(), ratings_after=p.ratings.copy())
+    seed(73)
+    q = pmf_cy.ProbabilisticMatrixFactorization(r.copy(), latent_d=3)
+    q.users, q.items = U0.copy(), V0.copy()
+    seed(74)
+    q.fit_minibatches_until_validation(64, 60)
+    out.update(seed_valid=74, valid_size=60, users_valid=q.users.copy(), items_valid=q.items.copy())
+    seed(75)
+    q2 = pmf_cy.ProbabilisticMatrixFactorization(r.copy(), latent_d=3)
+    q2.users, q2.items = U0.copy(), V0.copy()
+    seed(76)
+    pairs = list(islice(q2.fit_minibatches_validation(64, 60), 3))
+    out.update(seed_pairs=76, valid_pairs=np.array(pairs, np.float64))
+    save('pmf_minibatch_50x40_d3', **out)
+
+    # ---------------- I. configs[2]: rank-15 Gibbs at 943 x 1682 (inputs regenerated from seed 0 by
+    # the test, exactly as c2_inputs() in tests/conftest.py; only sampled outputs are stored)
+    seed(0)
+    n, m, d, N = 943, 1682, 10, 100000
+    Ut = np.random.normal(0, 2, (n, d))
+    Vt = np.random.normal(0, 2, (m, d))
+    mask = np.zeros((n, m), bool)
+    mask[np.arange(n), np.random.randint(0, m, n)] = True
+    mask[np.random.randint(0, n, m), np.arange(m)] = True
+    free = np.flatnonzero(~mask.ravel())
+    extra = np.random.choice(free, N - int(mask.sum()), replace=False)
+    mask.ravel()[extra] = True
+    ii, jj = mask.nonzero()
+    perm = np.random.permutation(ii.size)
+    ii, jj = ii[perm], jj[perm]
+    vals = (Ut[ii] * Vt[jj]).sum(1) + np.random.normal(0, .25, ii.size)
+    ratings = np.column_stack([ii, jj, vals]).astype(float)
+    seed(80)
+    b = bayes_pmf.BayesianPMF(ratings.copy(), latent_d=15)
+    U0, V0 = b.users.copy(), b.items.copy()
+    seed(81)
+    samps = list(islice(b.samples(), 3))
+    rows_u = np.arange(0, n, 37)
+    rows_v = np.arange(0, m, 53)
+    pv = b.pred_variance(samps)
+    pr = b.predict(samps)
+    pi, pj = np.arange(0, n, 41), np.arange(0, m, 67)
+    save('bayes_c3_943x1682_d15', U0_sum=U0.sum(), V0_sum=V0.sum(), seed_ctor=80, seed_chain=81,
+         rows_u=rows_u, rows_v=rows_v,
+         chain_U_rows=np.array([u[rows_u] for u, v in samps]),
+         chain_V_rows=np.array([v[rows_v] for u, v in samps]),
+         chain_U_sum=np.array([u.sum() for u, v in samps]),
+         chain_V_sum=np.array([v.sum() for u, v in samps]),
+         pi=pi, pj=pj, pred_variance_sub=pv[np.ix_(pi, pj)], predict_sub=pr[np.ix_(pi, pj)],
+         pred_variance_sum=pv.sum(), pick_argmax=np.array(np.unravel_index(np.argmax(pv), pv.shape)))
 
 
 if __name__ == '__main__':

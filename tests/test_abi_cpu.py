@@ -23,9 +23,9 @@ def test_header_and_binding_agree(lib):
     declared -= {'apmf_status'}
     bound = set(lib.exported_symbols())
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
-    so, dense = lib.load(), lib.load_dense()
+    so, dense, comm = lib.load(), lib.load_dense(), lib.load_comm()
     for name in declared:
-        assert getattr(dense if name in lib._DENSE_SIGS else so, name) is not None
+        assert getattr(dense if name in lib._DENSE_SIGS else comm if name in lib._COMM_SIGS else so, name) is not None
 
 
 def test_no_gpu_fails_loudly(lib):
@@ -70,3 +70,67 @@ def test_modules_import_like_the_reference():
             % os.path.join(ROOT, 'active_matrix_factorization_amd'))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr
+
+
+def test_late_torch_import_is_a_clear_error():
+    """importing torch after libapmf_dense.so (system rocBLAS / rocSOLVER) crashed the
+    process inside torch's static initialisers.  The product no longer imports torch anywhere; a
+    user who does so afterwards gets an ImportError that names the ordering rule (checked in a
+    child process: the guard must fire BEFORE torch's libraries are touched)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from active_matrix_factorization_amd import _lib\n"
+            "_lib.load()\n"
+            "assert _lib._dense is not None, 'dense library not built'\n"
+            "assert 'torch' not in sys.modules\n"
+            "try:\n"
+            "    import torch\n"
+            "except ImportError as e:\n"
+            "    assert 'BEFORE' in str(e), e\n"
+            "    print('guarded')\n" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'guarded' in out.stdout, out.stdout + out.stderr
+    # the other order stays allowed: torch first, then the package
+    code2 = ("import sys; sys.path.insert(0, %r)\n"
+             "import torch\n"
+             "from active_matrix_factorization_amd import _lib\n"
+             "_lib.load(); import torch.nn; print('fine')\n" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code2], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'fine' in out.stdout, out.stdout + out.stderr
+
+
+def test_product_never_imports_torch():
+    pkg = os.path.join(ROOT, 'active_matrix_factorization_amd')
+    for fn in os.listdir(pkg) + ['../bench.py']:
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'import torch' not in src.replace("import torch AFTER", '').replace('"import torch', '') \
+                .replace("import torch after", '').replace('Import torch BEFORE', ''), fn
+
+
+def test_cli_refuses_arbitrary_pickles(tmp_path):
+    """--load-data / --load-model go through a restricted unpickler: arrays and builtin containers
+    load, anything that would run code on load is refused."""
+    import pickle
+    import numpy as np
+    from active_matrix_factorization_amd import _cli
+    good = tmp_path / 'data.pkl'
+    with open(good, 'wb') as f:
+        pickle.dump({'_real': np.eye(3), '_ratings': np.zeros((2, 3)), '_rating_vals': (1, 2)}, f)
+    d = _cli._load_data(str(good))
+    assert set(d) == {'_real', '_ratings', '_rating_vals'} and d['_real'].shape == (3, 3)
+
+    class Evil(object):
+        def __reduce__(self):
+            import os
+            return (os.system, ('echo pwned > %s' % (tmp_path / 'pwned'),))
+    bad = tmp_path / 'bad.pkl'
+    with open(bad, 'wb') as f:
+        pickle.dump({'_real': Evil()}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        _cli._load_data(str(bad))
+    assert not (tmp_path / 'pwned').exists()
+    npz = tmp_path / 'data.npz'
+    np.savez(npz, _real=np.eye(2), _ratings=np.zeros((1, 3)))
+    assert set(_cli._load_data(str(npz))) == {'_real', '_ratings'}

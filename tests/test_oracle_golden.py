@@ -233,3 +233,59 @@ def test_pmf_fit_with_sigmas_trace(name):
     got, U, V, st = _fit_with_sigmas_trace(g, want.size)
     assert got.size == want.size
     np.testing.assert_allclose(got, want, rtol=1e-9)
+
+
+# ---------------------------------------------------------------- round-2 fixtures (real sizes)
+def test_configs3_fixture_oracle():
+    """BASELINE.json configs[3] (DrugBank 94 x 425, rank 5, 500 known), recorded from the reference:
+    the oracle's per-candidate path reproduces the reference's grids at the identity start and at
+    the converged approximation, and the arg-max the reference picked."""
+    g = load_golden('mn_c4_94x425_d5')
+    n, m = g['users'].shape[0], g['items'].shape[0]
+    # 518 known entries: every one of the 94 rows and 425 columns at least once (the 500 of the
+    # Makefile's --n-pick would leave empty rows, which the reference's own Gibbs path rejects)
+    assert (n, m) == (94, 425) and g['ratings'].shape == (518, 3)
+    pm, pv = orc.mn_pred_means_vars(n, m, g['mean_fit'], g['cov_useritems_fit'], g['cov_latents_fit'])
+    np.testing.assert_allclose(pv, g['p_var_fit'], rtol=1e-9, atol=1e-12 * np.abs(g['p_var_fit']).max())
+    np.testing.assert_allclose(pm, g['p_mean_fit'], rtol=1e-10, atol=1e-12)
+    assert abs(pv.sum() - g['total_variance_fit']) <= 1e-10 * abs(g['total_variance_fit'])
+    mean0 = np.vstack((g['users'], g['items']))
+    pm0, pv0 = orc.mn_pred_means_vars(n, m, mean0, np.eye(n + m), np.eye(5))
+    np.testing.assert_allclose(pv0, g['p_var0'], rtol=1e-10)
+    # the reference's pick = first maximum over its unrated set; with distinct values that is the
+    # masked arg-max of the grid
+    rated = np.zeros((n, m), bool)
+    rated[g['ratings'][:, 0].astype(int), g['ratings'][:, 1].astype(int)] = True
+    for pv_, pick in ((pv0, g['pick0']), (pv, g['pick_fit'])):
+        cand = np.where(rated, -np.inf, pv_)
+        assert cand[tuple(pick)] == cand.max()
+
+
+def test_minibatch_fixture_oracle():
+    """fit_minibatches (pmf_cy.pyx:308-351) recorded from the reference: two epochs of the momentum
+    recipe composed from the oracle's gradient on the same shuffles give the reference's factors."""
+    g = load_golden('pmf_minibatch_50x40_d3')
+    import random as _random
+    r_host, U, V = g['ratings'].copy(), g['U0'].copy(), g['V0'].copy()
+    ui, vi = np.zeros_like(U), np.zeros_like(V)
+    np.random.seed(int(g['seed_fit']))
+    _random.seed(int(g['seed_fit']))
+    bs = int(g['batch_size'])
+    errs = []
+    for _ in range(2):
+        np.random.shuffle(r_host)
+        for s in range(0, r_host.shape[0], bs):
+            b = r_host[s:s + bs]
+            gU, gV = orc.pmf_gradient(b, U, V)
+            sc = float(np.float32(1.) / np.float32(b.shape[0]))     # lr = 1 default, C float arithmetic
+            ui = ui * float(np.float32(.8)) + gU * sc
+            U = U + ui
+            vi = vi * float(np.float32(.8)) + gV * sc
+            V = V + vi
+        ij = r_host[:, :2].astype(int)
+        pred = U @ V.T
+        errs.append(float(np.float32(np.sqrt(np.mean((pred[ij[:, 0], ij[:, 1]] - r_host[:, 2]) ** 2)))))
+    np.testing.assert_array_equal(r_host, g['ratings_after'])
+    np.testing.assert_allclose(U, g['users'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(V, g['items'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(errs, g['train_errs'], rtol=1e-6)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""K2-full (csrc/k2_full.hip): the full-covariance candidate sweep of ActivePMF, timed with the
+in-library events at BASELINE.json configs[3]'s shape (94 x 425, rank 5: everything cache resident)
+and at a size whose streamed cross block (400 MB) is past the 256 MB Infinity Cache.  Algorithmic
+bytes: 8 d^2 + 8 per candidate.  Prints JSON."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from active_matrix_factorization_amd import _lib  # noqa: E402
+
+
+def run(ctx, n, m, d, reps=10):
+    K = (n + m) * d
+    ld = _lib.grid_ld(m)
+    cov = ctx.empty((K, K))
+    ctx.fill_normal(cov, seed=1)
+    mean = ctx.empty(K)
+    ctx.fill_normal(mean, seed=2)
+    var, dsum, bv, bi = ctx.empty((n, ld)), ctx.empty(1), ctx.empty(1), ctx.empty(1, np.int64)
+    out = {}
+    for label, env in (('sweep', None), ('general', 'general')):
+        if env:
+            os.environ['APMF_K2FULL_KERNEL'] = env
+        else:
+            os.environ.pop('APMF_K2FULL_KERNEL', None)
+        ctx.full_score_grid(n, m, d, ld, mean, cov, var=var, dsum=dsum, want=1, best_val=bv, best_idx=bi)
+        ctx.profile_begin(reps)
+        for _ in range(reps):
+            ctx.full_score_grid(n, m, d, ld, mean, cov, var=var, dsum=dsum, want=1, best_val=bv, best_idx=bi)
+        ms = ctx.profile_end()
+        ms = float(ms[ms > 0].mean())
+        algo = (8. * d * d + 8.) * n * m
+        out[label] = {'kernel_ms': ms, 'algorithmic_GBs': algo / (ms * 1e-3) / 1e9, 'frac_of_8TBs': algo / (ms * 1e-3) / 8e12,
+                      'sum': float(dsum.to_host()[0]), 'argmax': int(bi.to_host()[0])}
+    os.environ.pop('APMF_K2FULL_KERNEL', None)
+    assert out['sweep']['argmax'] == out['general']['argmax']
+    assert abs(out['sweep']['sum'] - out['general']['sum']) <= 1e-10 * abs(out['general']['sum'])
+    return {'n': n, 'm': m, 'd': d, 'candidates': n * m, 'algorithmic_bytes': (8 * d * d + 8) * n * m, **out}
+
+
+def main():
+    ctx = _lib.Context(0)
+    res = [run(ctx, 94, 425, 5), run(ctx, 1000, 2000, 5), run(ctx, 600, 900, 10, reps=5)]
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    main()
