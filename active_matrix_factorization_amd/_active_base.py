@@ -203,6 +203,15 @@ class _Candidates(object):
 
     def __init__(self, model, ctx):
         n, m = model.num_users, model.num_items
+        rec = model.__dict__.get('_pairs_recipe')
+        if rec is not None:
+            # model built from dense arrays (from_dense): the mask is already there
+            self.host = rec.cand_mask.copy()
+            self.ld = _lib.grid_ld(m)
+            self.dev = ctx.upload_grid(self.host.view(np.uint8), np.uint8, ld=self.ld)
+            self.count = rec.n_unrated
+            self.set_id = None
+            return
         unrated, rated = model.unrated, model.rated
         host = None
         if len(unrated) + len(rated) == n * m:
@@ -301,12 +310,19 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
         if dev is not None and dev.cand is not None and dev.ctx is not None:
             extra = np.array(extra, ndmin=2)
             dev.cand.remove(dev.ctx, [(int(i), int(j)) for i, j in extra[:, :2]])
-            dev.cand.count = len(self.unrated)
+            dev.cand.count = self._n_unrated()
 
     def _candidates(self):
         dev = self._device()
         c = dev.cand
-        if c is None or c.count != len(self.unrated) or c.set_id != id(self.unrated):
+        lazy = self.__dict__.get('_pairs_recipe') is not None
+        stale = c is None or c.count != self._n_unrated()
+        if not stale and not lazy:
+            if c.set_id is None:
+                c.set_id = id(self.unrated)      # built from the masks; the sets exist by now
+            elif c.set_id != id(self.unrated):
+                stale = True
+        if stale:
             c = dev.cand = _Candidates(self, dev.ctx)
         return c
 
@@ -593,16 +609,16 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
     def pick_query_point(self, pool=None, key=None, procs=None, worker_pool=None):
         '''Next (i, j) to query: the first extremum of `key` over `pool` (default
         self.unrated) in the pool's iteration order, max or min per key.chooser.'''
-        full = pool is None or pool is self.unrated
-        if pool is None:
-            pool = self.unrated
+        lazy = self.__dict__.get('_pairs_recipe') is not None     # sets not built yet (from_dense)
+        full = pool is None or (not lazy and pool is self.unrated)
         if key is None:
             key = self._default_key()
         chooser = getattr(key, 'chooser', max)
-        if len(pool) == 0:
+        n_pool = self._n_unrated() if full else len(pool)
+        if n_pool == 0:
             raise ValueError("can't pick a query point from an empty pool")
-        elif len(pool) == 1:
-            return next(iter(pool))
+        elif n_pool == 1:
+            return next(iter(self.unrated if full else pool))
         if full and chooser in (max, min):
             # whole unrated set: the device holds it as a mask; no list of 10^6 tuples is built
             fast = getattr(self, '_pick_unrated_device', None)
@@ -612,7 +628,7 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             grid = getattr(key, 'grid', None)
             if grid is not None:
                 return self._pick_from_grid(np.asarray(getattr(self, grid)(), dtype=np.float64), chooser)
-        pool = list(pool)
+        pool = list(self.unrated if pool is None else pool)
         impl = getattr(key, 'batched', None)
         if impl is not None and chooser in (max, min):
             # one launch scores the pool; the first extremum in pool order (what max() / min() over
@@ -644,16 +660,15 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
 
     def get_key_evals(self, pool=None, key=None, procs=None, worker_pool=None):
         '''(n, m) matrix holding key's value at every element of pool, NaN elsewhere.'''
-        full = pool is None or pool is self.unrated
-        if pool is None:
-            pool = self.unrated
+        lazy = self.__dict__.get('_pairs_recipe') is not None
+        full = pool is None or (not lazy and pool is self.unrated)
         if key is None:
             key = self._default_key()
         grid = getattr(key, 'grid', None)
-        if full and grid is not None and len(pool) > 0:
+        if full and grid is not None and self._n_unrated() > 0:
             vals = np.asarray(getattr(self, grid)(), dtype=np.float64)
             return np.where(self._candidates().host, vals, np.nan)
-        pool = list(pool)
+        pool = list(self.unrated if pool is None else pool)
         evals = np.empty((self.num_users, self.num_items))
         evals.fill(np.nan)
         if pool:
@@ -705,12 +720,12 @@ def query_loop(apmf, real, picker_key, fit_normal, fit_sigmas, test_on=None, wit
             apmf.fit_normal()
     rmse = apmf.rmse(real, test_on) if test_on is not None else apmf.rmse(real)
     print("{:<40} Initial RMSE: {:.5}".format(name, rmse))
-    yield result(len(apmf.rated), rmse, None, None)
+    yield result(apmf._n_rated(), rmse, None, None)
 
-    while apmf.unrated:
-        n = len(apmf.rated) + 1
+    while apmf._n_unrated():
+        n = apmf._n_rated() + 1
         print("{:<40} Picking query point {}...".format(name, n))
-        if len(apmf.unrated) == 1:
+        if apmf._n_unrated() == 1:
             i, j = next(iter(apmf.unrated))
             if matrix_vals:
                 vals = np.empty((apmf.num_users, apmf.num_items))
@@ -729,7 +744,7 @@ def query_loop(apmf, real, picker_key, fit_normal, fit_sigmas, test_on=None, wit
             i, j = picker_key.chooser(zip(pool, vals), key=operator.itemgetter(1))[0]
 
         apmf.add_rating(i, j, real[i, j])
-        print("{:<40} Queried ({}, {}); {}/{} known".format(name, i, j, len(apmf.rated), total))
+        print("{:<40} Queried ({}, {}); {}/{} known".format(name, i, j, apmf._n_rated(), total))
         if refit_with_lls:
             # full_test refits with plain fit_lls/fit_normal_kls, never re-initialising
             for ll in apmf.fit_lls():
@@ -748,7 +763,7 @@ def query_loop(apmf, real, picker_key, fit_normal, fit_sigmas, test_on=None, wit
                 apmf.fit_normal()
         rmse = apmf.rmse(real, test_on) if test_on is not None else apmf.rmse(real)
         print("{:<40} RMSE {}: {:.5}".format(name, n, rmse))
-        yield result(len(apmf.rated), rmse, (i, j), vals)
+        yield result(apmf._n_rated(), rmse, (i, j), vals)
 
 
 def run_compare(cls, key_funcs, key_names, real, ratings, rating_vals, latent_d, knowable,
@@ -761,9 +776,25 @@ def run_compare(cls, key_funcs, key_names, real, ratings, rating_vals, latent_d,
         assert set(apmf.rating_values) == set(rating_vals)
         apmf.discrete_expectations = discrete_exp
     else:
-        apmf = cls(ratings, latent_d=latent_d, rating_values=rating_vals,
-                   discrete_expectations=discrete_exp, refit_lookahead=refit_lookahead,
-                   knowable=knowable, fit_type=fit_type)
+        kw = dict(latent_d=latent_d, rating_values=rating_vals, discrete_expectations=discrete_exp,
+                  refit_lookahead=refit_lookahead, fit_type=fit_type)
+        apmf = None
+        if isinstance(knowable, np.ndarray) and knowable.dtype == bool and knowable.shape == np.shape(real):
+            # the CLI hands the knowable MASK over: when `ratings` is what make_ratings() writes for
+            # this matrix (row-major order of the known mask, choose_training.py:13-17) the model is
+            # built from the dense arrays - device container, no 10^6-tuple sets up front
+            ratings = np.asarray(ratings, dtype=float)
+            ii, jj = ratings[:, 0].astype(np.int64), ratings[:, 1].astype(np.int64)
+            known = np.zeros(np.shape(real), bool)
+            known[ii, jj] = True
+            ki, kj = known.nonzero()
+            if ki.size == ii.size and np.array_equal(ki, ii) and np.array_equal(kj, jj) and \
+                    np.array_equal(np.asarray(real, float)[ii, jj], ratings[:, 2]):
+                apmf = cls.from_dense(real, known, knowable=knowable, **kw)
+            else:
+                knowable = zip(*knowable.nonzero())
+        if apmf is None:
+            apmf = cls(ratings, knowable=knowable, **kw)
         apmf.sig_u_mean, apmf.sig_u_var, apmf.sig_v_mean, apmf.sig_v_var = sig_priors
         print("Doing initial fit")
         if fit_sigmas:

@@ -146,7 +146,7 @@ def run_cli(key_funcs, compare, kind):
             print("using test set from file")
             knowable[test_on] = False
         res = compare(args.keys, real=real, ratings=data['_ratings'],
-                      rating_vals=data.get('_rating_vals'), knowable=zip(*knowable.nonzero()),
+                      rating_vals=data.get('_rating_vals'), knowable=knowable,
                       test_on=test_on, **common)
     else:
         real_ratings_vals, apmf, knowable, gen = None, None, None, {}

@@ -58,6 +58,7 @@ _SIGS = {
     'apmf_cast_f64_f32': (_i, [_vp, _vp, _vp, _sz]),
     'apmf_cast_f32_f64': (_i, [_vp, _vp, _vp, _sz]),
     'apmf_ratings_create': (_i, [_vp, _vp, _i64, _i, _i, C.POINTER(_vp)]),
+    'apmf_ratings_create_dense': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, C.POINTER(_vp)]),
     'apmf_ratings_destroy': (_i, [_vp, _vp]),
     'apmf_ratings_count': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i), C.POINTER(_i)]),
     'apmf_pmf_gradient': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, _vp, _vp]),
@@ -322,6 +323,27 @@ class Ratings(object):
         _check(ctx._lib.apmf_ratings_create(ctx._h, ratings.ctypes.data, self.N, self.n, self.m,
                                             C.byref(h)))
         self._h = h.value
+
+    @classmethod
+    def from_dense(cls, ctx, real, known):
+        """Container built on the device from a dense (n, m) matrix and its boolean `known` mask,
+        entries in row-major order (what choose_training.py's make_ratings() produces)."""
+        real = np.ascontiguousarray(real, dtype=np.float64)
+        known = np.ascontiguousarray(known, dtype=bool)
+        if real.ndim != 2 or known.shape != real.shape:
+            raise TypeError('real and known must be (n, m) arrays of the same shape')
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.n, self.m = real.shape
+        d_real, d_known = ctx.array(real), ctx.array(known.view(np.uint8), np.uint8)
+        h = _vp()
+        _check(ctx._lib.apmf_ratings_create_dense(ctx._h, d_real.ptr, self.m, d_known.ptr, self.m, self.n,
+                                                  self.m, C.byref(h)))
+        self._h = h.value
+        cnt = _i64(0)
+        _check(ctx._lib.apmf_ratings_count(self._h, C.byref(cnt), None, None))
+        self.N = cnt.value
+        return self
 
     def free(self):
         if getattr(self, '_h', None):

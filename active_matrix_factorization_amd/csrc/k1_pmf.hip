@@ -532,6 +532,58 @@ int launch_ll(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, double s
 
 } // namespace
 
+// ---- ratings container straight from a dense matrix + "known" mask ----------
+// The input contract of the reference's drivers is a dense `_real` matrix plus the list `_ratings`
+// that choose_training.py's make_ratings() writes in row-major order of the known mask
+// (choose_training.py:13-17, 215-259).  For such data the container can be built on the device from
+// the dense arrays: per-row / per-column counts, prefix sums (host: n + m integers), then an ordered
+// compaction - one wave per row walks its columns 64 at a time and places the known entries by
+// ballot prefix (ascending j), one wave per column likewise (ascending i).  That is exactly the
+// stable order apmf_ratings_create gives the row-major list, so every sum downstream is
+// bit-identical.
+namespace {
+
+__global__ __launch_bounds__(64) void k_dense_count(int n, int m, const uint8_t *__restrict__ known, int ldk,
+                                                    int *__restrict__ cnt)      // cnt[n + m], zeroed
+{
+    const int i = blockIdx.x, lane = threadIdx.x;
+    int c = 0;
+    for (int j0 = 0; j0 < m; j0 += 64) {
+        const int j = j0 + lane;
+        const bool k = j < m && known[(size_t)i * ldk + j];
+        if (k) atomicAdd(&cnt[n + j], 1);
+        c += __popcll(__ballot(k));
+    }
+    if (lane == 0) cnt[i] = c;
+}
+
+// side 0: wave per user row; side 1: wave per item column
+template <int SIDE>
+__global__ __launch_bounds__(64) void k_dense_fill(int n, int m, const double *__restrict__ real, int ldr,
+                                                   const uint8_t *__restrict__ known, int ldk,
+                                                   const int64_t *__restrict__ ptr, int32_t *__restrict__ idx,
+                                                   double *__restrict__ val)
+{
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const int len = SIDE == 0 ? m : n;
+    int64_t at = ptr[row];
+    for (int t0 = 0; t0 < len; t0 += 64) {
+        const int t = t0 + lane;
+        const size_t ek = SIDE == 0 ? (size_t)row * ldk + t : (size_t)t * ldk + row;
+        const size_t er = SIDE == 0 ? (size_t)row * ldr + t : (size_t)t * ldr + row;
+        const bool k = t < len && known[ek];
+        const unsigned long long b = __ballot(k);
+        if (k) {
+            const int64_t o = at + __popcll(b & ((1ull << lane) - 1ull));
+            idx[o] = t;
+            val[o] = real[er];
+        }
+        at += __popcll(b);
+    }
+}
+
+} // namespace
+
 extern "C" {
 
 int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n, int m,
@@ -608,6 +660,71 @@ int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n
         if (rc == APMF_OK && N) rc = apmf_h2d(ctx, r->val[s], val[s].data(), (size_t)N * 8);
     }
     if (rc == APMF_OK) rc = apmf_h2d(ctx, r->order, order.data(), order.size() * 4);
+    if (rc != APMF_OK) { (void)hipFree(r->block); delete r; return rc; }
+    *out = r;
+    return APMF_OK;
+}
+
+int apmf_ratings_create_dense(apmf_ctx *ctx, const double *d_real, int ld_real, const uint8_t *d_known,
+                              int ld_known, int n, int m, apmf_ratings **out)
+{
+    APMF_REQUIRE(ctx && out && d_real && d_known, "NULL operand");
+    *out = nullptr;
+    APMF_REQUIRE(n >= 1 && m >= 1 && ld_real >= m && ld_known >= m, "bad shape n=%d m=%d", n, m);
+    int *d_cnt = nullptr;
+    APMF_TRY(apmf_malloc(ctx, (size_t)(n + m) * sizeof(int), (void **)&d_cnt));
+    int rc = apmf_memset(ctx, d_cnt, 0, (size_t)(n + m) * sizeof(int));
+    std::vector<int> cnt((size_t)n + m);
+    if (rc == APMF_OK) {
+        hipLaunchKernelGGL(k_dense_count, dim3(n), dim3(64), 0, ctx->stream, n, m, d_known, ld_known, d_cnt);
+        rc = apmf_d2h(ctx, cnt.data(), d_cnt, cnt.size() * sizeof(int));
+    }
+    (void)apmf_free(ctx, d_cnt);
+    if (rc != APMF_OK) return rc;
+    std::vector<int64_t> ptr0((size_t)n + 1, 0), ptr1((size_t)m + 1, 0);
+    for (int i = 0; i < n; i++) ptr0[i + 1] = ptr0[i] + cnt[i];
+    for (int j = 0; j < m; j++) ptr1[j + 1] = ptr1[j] + cnt[n + j];
+    const int64_t N = ptr0[n];
+    std::vector<int32_t> order((size_t)n + m);
+    for (int t = 0; t < n + m; t++) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
+
+    apmf_ratings *r = new (std::nothrow) apmf_ratings();
+    if (!r) { apmf_set_error("out of host memory"); return APMF_ENOMEM; }
+    memset(r, 0, sizeof(*r));
+    r->N = N; r->n = n; r->m = m;
+    for (int t = 0; t < n; t++) if (cnt[t] == 0) r->has_empty[0] = 1;
+    for (int t = n; t < n + m; t++) if (cnt[t] == 0) r->has_empty[1] = 1;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_ptr0 = al((size_t)(n + 1) * 8), b_ptr1 = al((size_t)(m + 1) * 8);
+    const size_t b_idx = al((size_t)N * 4 + 4), b_val = al((size_t)N * 8 + 8), b_ord = al((size_t)(n + m) * 4);
+    const size_t total = b_ptr0 + b_ptr1 + 2 * b_idx + 2 * b_val + b_ord;
+    APMF_CHECK_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(&r->block, total);
+    if (e != hipSuccess) {
+        delete r;
+        apmf_set_error("hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+        return APMF_ENOMEM;
+    }
+    char *base = (char *)r->block;
+    r->ptr[0] = (int64_t *)base; base += b_ptr0;
+    r->ptr[1] = (int64_t *)base; base += b_ptr1;
+    r->idx[0] = (int32_t *)base; base += b_idx;
+    r->idx[1] = (int32_t *)base; base += b_idx;
+    r->val[0] = (double *)base; base += b_val;
+    r->val[1] = (double *)base; base += b_val;
+    r->order = (int32_t *)base;
+    rc = apmf_h2d(ctx, r->ptr[0], ptr0.data(), ptr0.size() * 8);
+    if (rc == APMF_OK) rc = apmf_h2d(ctx, r->ptr[1], ptr1.data(), ptr1.size() * 8);
+    if (rc == APMF_OK) rc = apmf_h2d(ctx, r->order, order.data(), order.size() * 4);
+    if (rc == APMF_OK && N > 0) {
+        hipLaunchKernelGGL((k_dense_fill<0>), dim3(n), dim3(64), 0, ctx->stream, n, m, d_real, ld_real, d_known,
+                           ld_known, r->ptr[0], r->idx[0], r->val[0]);
+        hipLaunchKernelGGL((k_dense_fill<1>), dim3(m), dim3(64), 0, ctx->stream, n, m, d_real, ld_real, d_known,
+                           ld_known, r->ptr[1], r->idx[1], r->val[1]);
+        if (hipGetLastError() != hipSuccess) { apmf_set_error("kernel launch failed"); rc = APMF_EHIP; }
+        if (rc == APMF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { apmf_set_error("sync failed"); rc = APMF_EHIP; }
+    }
     if (rc != APMF_OK) { (void)hipFree(r->block); delete r; return rc; }
     *out = r;
     return APMF_OK;

@@ -33,6 +33,37 @@ def rmse_on(exp, obs, on):
     return float(np.float32(np.sqrt(np.mean((obs[on] - exp[on]) ** 2))))  # pmf_cy.pyx:28-29
 
 
+class _PairsRecipe(object):
+    """How to build the `rated` / `unrated` sets of a model that was created from dense arrays
+    (from_dense): the construction the reference performs (pmf_cy.pyx:69-72) and every
+    add_ratings() since, replayed on first access - the sets' iteration order, which breaks ties
+    in the selection loop, comes out as if they had been built eagerly.  Until then the masks
+    below answer everything the accelerated paths ask (counts, candidate mask, membership)."""
+    __slots__ = ('pairs0', 'knowable', 'adds', 'rated_mask', 'cand_mask', 'n_rated', 'n_unrated')
+
+    def __init__(self, pairs0, knowable, n, m):
+        self.pairs0 = pairs0                  # (N0, 2) float64: ratings[:, :2] at construction
+        self.knowable = knowable              # None (everything) or a bool (n, m) mask
+        self.adds = []
+        self.rated_mask = np.zeros((n, m), bool)
+        self.rated_mask[pairs0[:, 0].astype(np.int64), pairs0[:, 1].astype(np.int64)] = True
+        self.cand_mask = ~self.rated_mask if knowable is None else (knowable & ~self.rated_mask)
+        self.n_rated = int(self.rated_mask.sum())
+        self.n_unrated = int(self.cand_mask.sum())
+
+    def build(self, n, m):
+        rated = set(map(tuple, self.pairs0))
+        if self.knowable is None:
+            knowable = itertools.product(range(n), range(m))
+        else:
+            knowable = zip(*self.knowable.nonzero())       # what the reference's CLIs pass
+        unrated = set(knowable).difference(rated)
+        for new_items in self.adds:
+            rated.update(new_items)
+            unrated.difference_update(new_items)
+        return rated, unrated
+
+
 class _DeviceCache(object):
     """Per-object device state: never part of __getstate__, rebuilt lazily after copy/unpickle."""
     __slots__ = ('ctx', 'ratings', 'ratings_key', 'resident', 'cand')
@@ -93,13 +124,69 @@ class ProbabilisticMatrixFactorization(object):
 
         # built exactly as the reference builds them (pmf_cy.pyx:69-72): set iteration order
         # decides ties in the selection loop, so the construction sequence is part of the API
-        self.rated = set(map(tuple, self.ratings[:, :2]))
-        if knowable is None:
-            knowable = itertools.product(range(n), range(m))
-        self.unrated = set(knowable).difference(self.rated)
+        # (from_dense() defers this very construction until somebody looks at the sets)
+        if isinstance(knowable, _PairsRecipe):
+            self.__dict__['_pairs_recipe'] = knowable
+        else:
+            self.rated = set(map(tuple, self.ratings[:, :2]))
+            if knowable is None:
+                knowable = itertools.product(range(n), range(m))
+            self.unrated = set(knowable).difference(self.rated)
 
         self.users = np.random.random((n, self.latent_d))
         self.items = np.random.random((m, self.latent_d))
+
+    # ------------------------------------------------------------------ the rated / unrated sets
+    def _materialize_pairs(self):
+        rec = self.__dict__.get('_pairs_recipe')
+        if rec is not None:
+            self.__dict__['_pairs_recipe'] = None
+            self.__dict__['_rated_set'], self.__dict__['_unrated_set'] = rec.build(self.num_users, self.num_items)
+
+    def _pairs_get(name):
+        def get(self):
+            self._materialize_pairs()
+            return self.__dict__.get(name)
+
+        def set_(self, value):
+            self._materialize_pairs()
+            self.__dict__[name] = value
+        return property(get, set_)
+
+    rated = _pairs_get('_rated_set')
+    unrated = _pairs_get('_unrated_set')
+    del _pairs_get
+
+    def _n_rated(self):
+        rec = self.__dict__.get('_pairs_recipe')
+        return rec.n_rated if rec is not None else len(self.rated)
+
+    def _n_unrated(self):
+        rec = self.__dict__.get('_pairs_recipe')
+        return rec.n_unrated if rec is not None else len(self.unrated)
+
+    @classmethod
+    def from_dense(cls, real, known, knowable=None, **kwargs):
+        """Model from the dense inputs of the reference's drivers: `real` (n, m) and the boolean
+        mask `known` of the initially observed entries; `knowable` an optional (n, m) mask of the
+        entries that may be queried (default: all).  `ratings` is the list make_ratings() writes
+        (choose_training.py:13-17: row-major order of the mask), the device container is built from
+        the dense arrays by device kernels (apmf_ratings_create_dense) and the `rated` / `unrated`
+        sets - 10^6 tuples at 943 x 1682 - are only built if something asks for them."""
+        real = np.asarray(real)
+        known = np.asarray(known, dtype=bool)
+        if real.ndim != 2 or known.shape != real.shape:
+            raise TypeError("real and known must be (n, m) arrays of the same shape")
+        ii, jj = known.nonzero()
+        ratings = np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+        n, m = int(ii.max()) + 1, int(jj.max()) + 1          # the reference's rule (pmf_cy.pyx:66-67)
+        kn = None if knowable is None else np.asarray(knowable, dtype=bool)[:n, :m]
+        recipe = _PairsRecipe(ratings[:, :2].copy(), kn, n, m)
+        self = cls(ratings, knowable=recipe, **kwargs)
+        dev = self._device()
+        dev.ratings = _lib.Ratings.from_dense(dev.ctx, np.asarray(real, float)[:n, :m], known[:n, :m])
+        dev.ratings_key = self._ratings_key()
+        return self
 
     # ------------------------------------------------------------------ copying / pickling
     def __copy__(self):
@@ -146,14 +233,18 @@ class ProbabilisticMatrixFactorization(object):
         (add_ratings rebinds self.ratings, fit_minibatches shuffles it in place)."""
         dev = self._device()
         r = self.ratings
-        key = (id(r), r.shape[0], float(r[:, 2].sum()), float(r[-1, 0]), float(r[-1, 1]),
-               self.num_users, self.num_items)
+        key = self._ratings_key()
         if dev.ratings is None or dev.ratings_key != key:
             if dev.ratings is not None:
                 dev.ratings.free()
             dev.ratings = dev.ctx.ratings(r, self.num_users, self.num_items)
             dev.ratings_key = key
         return dev.ctx, dev.ratings
+
+    def _ratings_key(self):
+        r = self.ratings
+        return (id(r), r.shape[0], float(r[:, 2].sum()), float(r[-1, 0]), float(r[-1, 1]),
+                self.num_users, self.num_items)
 
     def _hyper(self):
         return (self.latent_d, float(self.sigma_sq), float(self.sigma_u_sq), float(self.sigma_v_sq),
@@ -185,10 +276,22 @@ class ProbabilisticMatrixFactorization(object):
                 raise ValueError("got ratings with bad values")
 
         new_items = set((int(i), int(j)) for i, j in extra[:, :2])
-        if not new_items.isdisjoint(self.rated):
-            raise ValueError("can't rate already rated items")
-        self.rated.update(new_items)
-        self.unrated.difference_update(new_items)
+        rec = self.__dict__.get('_pairs_recipe')
+        if rec is not None:
+            # the sets have not been asked for yet: keep the masks and the replay list up to date
+            ni = np.array(sorted(new_items), dtype=np.int64).reshape(-1, 2)
+            if rec.rated_mask[ni[:, 0], ni[:, 1]].any():
+                raise ValueError("can't rate already rated items")
+            rec.adds.append(new_items)
+            rec.n_unrated -= int(rec.cand_mask[ni[:, 0], ni[:, 1]].sum())
+            rec.rated_mask[ni[:, 0], ni[:, 1]] = True
+            rec.cand_mask[ni[:, 0], ni[:, 1]] = False
+            rec.n_rated += len(new_items)
+        else:
+            if not new_items.isdisjoint(self.rated):
+                raise ValueError("can't rate already rated items")
+            self.rated.update(new_items)
+            self.unrated.difference_update(new_items)
 
         self.ratings = np.append(self.ratings, extra, 0)
         self.mean_rating = float(np.mean(self.ratings[:, 2]))

@@ -95,6 +95,13 @@ int apmf_cast_f32_f64(apmf_ctx *ctx, double *d_dst, const float *d_src, size_t c
  * the reference's order. */
 int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n, int m,
                         apmf_ratings **out);
+/* The same container straight from the dense inputs of the reference's drivers: d_real (n, ld_real)
+ * float64 and d_known (n, ld_known) uint8 on the device, known entries taken in row-major order -
+ * the order choose_training.py's make_ratings() writes `_ratings` in (choose_training.py:13-17),
+ * so the result is identical to apmf_ratings_create on that list.  Built by device kernels
+ * (counts, ordered compaction per row and per column); no (N, 3) list, no Python sets. */
+int apmf_ratings_create_dense(apmf_ctx *ctx, const double *d_real, int ld_real, const uint8_t *d_known,
+                              int ld_known, int n, int m, apmf_ratings **out);
 int apmf_ratings_destroy(apmf_ctx *ctx, apmf_ratings *r);
 int apmf_ratings_count(const apmf_ratings *r, int64_t *N, int *n, int *m);
 

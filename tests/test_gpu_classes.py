@@ -637,7 +637,10 @@ def test_cli_entry_points(tmp_path, pkg, monkeypatch):
         ns, rmses = np.asarray(ns), np.asarray(rmses)
         assert ns.dtype.kind == 'i' and np.all(np.diff(ns) == 1) and np.all(np.isfinite(rmses))
         assert ijs[0] is None and evals[0] is None            # the initial record
-        assert np.asarray(evals[1]).shape == r['_real'].shape and np.isnan(np.asarray(evals[1])).any()
+        # --no-threading records the values as a list over the pool (full_test, mn_active_pmf.py:795-846);
+        # the threaded loop records the (n, m) NaN-filled matrix (:867-894)
+        ev = np.asarray(evals[1])
+        assert ev.shape == (r['_real'].size - ns[0],) or (ev.shape == r['_real'].shape and np.isnan(ev).any())
         assert preds[1].shape == r['_real'].shape
     assert isinstance(r['_initial_apmf'], pkg.mn.MNActivePMF) and r['_initial_apmf'].mean is not None
     out = tmp_path / 'bayes.pkl'
@@ -955,3 +958,86 @@ def test_configs2_gibbs_golden(pkg):
     np.testing.assert_allclose(pr[sub], g['predict_sub'], rtol=1e-6, atol=1e-8)
     assert abs(pv.sum() - g['pred_variance_sum']) <= 1e-6 * abs(g['pred_variance_sum'])
     assert tuple(np.unravel_index(np.argmax(pv), pv.shape)) == tuple(g['pick_argmax'])
+
+
+def test_ratings_container_from_dense(pkg):
+    """apmf_ratings_create_dense (device build from the dense matrix + known mask) == the container
+    built from the list make_ratings() writes (choose_training.py:13-17): K1 gradient / LL and a K3
+    half-sweep are bit-identical."""
+    from active_matrix_factorization_amd import _lib
+    seed(5)
+    n, m, d = 37, 130, 6
+    real = np.round(np.random.normal(3, 1, (n, m)))
+    known = np.random.rand(n, m) < .2
+    known[np.arange(n), np.random.randint(0, m, n)] = True
+    known[np.random.randint(0, n, m), np.arange(m)] = True
+    ii, jj = known.nonzero()
+    ratings = np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+    ctx = _lib.default_context()
+    a, b = ctx.ratings(ratings, n, m), _lib.Ratings.from_dense(ctx, real, known)
+    assert (b.N, b.n, b.m) == (ratings.shape[0], n, m)
+    U, V = np.random.normal(size=(n, d)), np.random.normal(size=(m, d))
+    dU, dV = ctx.array(U), ctx.array(V)
+    outs = []
+    for rt in (a, b):
+        gU, gV = ctx.empty((n, d)), ctx.empty((m, d))
+        ctx.pmf_gradient(rt, dU, dV, d, 1., 10., 10., False, 0., gU, gV)
+        ll = ctx.pmf_log_likelihood(rt, dU, dV, d, 1., 10., 10., False, 0.)
+        z, out = ctx.array(np.random.RandomState(1).normal(size=(m, d))), ctx.empty((m, d))
+        ctx.gibbs_half_sweep(rt, 1, dU, d, ctx.array(np.eye(d)), ctx.array(np.zeros(d)), 2., 0., z, out)
+        outs.append((gU.to_host(), gV.to_host(), ll, out.to_host()))
+    for x, y in zip(*outs):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_from_dense_defers_the_sets(pkg):
+    """A model built from the dense inputs (from_dense) selects, scores and takes new ratings
+    without ever building the rated / unrated sets; when something finally asks for them they come
+    out as the eager construction would have left them - same contents, same iteration order."""
+    seed(8)
+    n, m, d = 30, 45, 4
+    real = np.round(np.clip(np.random.normal(3, 1.2, (n, m)), 1, 5))
+    known = np.random.rand(n, m) < .15
+    known[np.arange(n), np.random.randint(0, m, n)] = True
+    known[np.random.randint(0, n, m), np.arange(m)] = True
+    knowable = np.random.rand(n, m) < .9
+    knowable |= known
+    ii, jj = known.nonzero()
+    ratings = np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+    MN = pkg.mn.MNActivePMF
+    seed(9)
+    a = MN.from_dense(real, known, knowable=knowable, latent_d=d, rating_values=(1, 2, 3, 4, 5))
+    seed(9)
+    b = MN(ratings.copy(), latent_d=d, rating_values=(1, 2, 3, 4, 5), knowable=zip(*knowable.nonzero()))
+    np.testing.assert_array_equal(a.ratings, b.ratings)
+    np.testing.assert_array_equal(a.users, b.users)
+    for x in (a, b):
+        x.do_fit()
+        x.initialize_approx()
+        for _ in islice(x.fit_normal_kls(), 4):
+            pass
+    np.testing.assert_array_equal(a.mean, b.mean)          # same device container -> same fit
+    for key in (MN.pred_variance, MN.pred, MN.prob_ge_3_5):
+        assert a.pick_query_point(key=key) == b.pick_query_point(key=key)
+        np.testing.assert_array_equal(a.get_key_evals(key=key), b.get_key_evals(key=key))
+    pick = a.pick_query_point()
+    a.add_rating(pick[0], pick[1], real[pick])
+    b.add_rating(pick[0], pick[1], real[pick])
+    with pytest.raises(ValueError):
+        a.add_rating(pick[0], pick[1], 3.)
+    assert a.pick_query_point() == b.pick_query_point()
+    assert a.__dict__.get('_pairs_recipe') is not None     # nobody needed the sets so far
+    assert a._n_rated() == len(b.rated) and a._n_unrated() == len(b.unrated)
+    assert list(a.unrated) == list(b.unrated) and a.rated == b.rated
+    assert a.__dict__.get('_pairs_recipe') is None
+    c = copy.deepcopy(a)
+    assert c.unrated == b.unrated and c.pick_query_point() == b.pick_query_point()
+    # the experiment loop over such a model (compare() with the knowable mask, like the CLI)
+    seed(10)
+    res_a = pkg.mn.compare(['pred-variance'], real, ratings, rating_vals=(1, 2, 3, 4, 5), latent_d=d,
+                           knowable=knowable, steps=3, do_threading=True)
+    seed(10)
+    res_b = pkg.mn.compare(['pred-variance'], real, ratings, rating_vals=(1, 2, 3, 4, 5), latent_d=d,
+                           knowable=zip(*knowable.nonzero()), steps=3, do_threading=True)
+    assert [s[2] for s in res_a['pred-variance']] == [s[2] for s in res_b['pred-variance']]
+    assert [s[1] for s in res_a['pred-variance']] == [s[1] for s in res_b['pred-variance']]
