@@ -101,7 +101,14 @@ def _parallel_map(fn, items, procs=None):
     if width <= 1 or getattr(_worker_state, 'inside', False):
         return [fn(x) for x in items]
     if _workers is None:
-        _workers = concurrent.futures.ThreadPoolExecutor(max_workers=16, thread_name_prefix='apmf-lookahead')
+        # as many threads as the widest map ever asked for (each worker thread keeps one Context:
+        # a stream, workspaces, a rocBLAS handle and its block cache - _lib.release_thread_contexts()
+        # gives them back)
+        _workers = concurrent.futures.ThreadPoolExecutor(max_workers=max(width, 4),
+                                                         thread_name_prefix='apmf-lookahead')
+    elif _workers._max_workers < width:
+        _workers.shutdown(wait=True)
+        _workers = concurrent.futures.ThreadPoolExecutor(max_workers=width, thread_name_prefix='apmf-lookahead')
 
     def run(x):
         _worker_state.inside = True

@@ -84,6 +84,8 @@ _SIGS = {
     'apmf_gibbs_half_sweep': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     'apmf_gibbs_half_sweep_rows': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     'apmf_sample_stats_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
+    'apmf_gibbs_sample_hyperparam': (_i, [_vp, _vp, _i, _i, _vp, _dbl, _dbl, _vp, _vp, C.c_uint64, C.c_uint64, _vp,
+                                          _vp, _vp]),
     'apmf_fill_normal_f64': (_i, [_vp, _vp, _i64, C.c_uint64, C.c_uint64]),
     'apmf_grid_gather_f64': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _vp]),
     'apmf_pool_argext_f64': (_i, [_vp, _vp, _i64, _i, C.POINTER(_i64), C.POINTER(_dbl)]),
@@ -709,6 +711,14 @@ class Context(object):
                                                     _ptr(alpha), _ptr(mu), beta, mean_sub, _ptr(z),
                                                     _ptr(out)))
 
+    def gibbs_sample_hyperparam(self, feats, N, d, wi, b0, df, mu0, mu, alpha, variates=None, seed=0, offset=0,
+                                status=None):
+        """(mu, alpha) ~ Gaussian-Wishart posterior on the device (bayes_pmf.py:157-186)."""
+        _check(self._lib.apmf_gibbs_sample_hyperparam(self._h, _ptr(feats), int(N), int(d), _ptr(wi), float(b0),
+                                                      float(df), _ptr(mu0), _ptr(variates),
+                                                      int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
+                                                      _ptr(mu), _ptr(alpha), _ptr(status)))
+
     def fill_normal(self, out, seed, offset=0):
         """out[...] ~ N(0, 1) from the device generator (Philox4x32-10 + Box-Muller); not NumPy's stream."""
         _check(self._lib.apmf_fill_normal_f64(self._h, _ptr(out), out.size, int(seed) & (2 ** 64 - 1),
@@ -735,6 +745,19 @@ def default_device():
     process per GPU under torch.distributed.run), else 0 - modulo the visible devices."""
     want = int(os.environ.get('APMF_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     return want % max(device_count(), 1)
+
+
+def release_thread_contexts(keep_current=True):
+    """Close the per-thread default Contexts of threads other than the caller's (worker threads of
+    the lookahead map keep theirs alive between calls: stream, workspaces, rocBLAS handle and a
+    block cache each).  Only call this when no other thread is inside a library call."""
+    me = (os.getpid(), threading.get_ident())
+    for key in list(_default_ctx):
+        if keep_current and key[:2] == me:
+            continue
+        ctx = _default_ctx.pop(key, None)
+        if ctx is not None and key[0] == os.getpid():
+            ctx.close()
 
 
 def default_context(device=None):

@@ -167,11 +167,28 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
         device_rng = getattr(self, 'device_rng', False)
         if device_rng:      # seeded from NumPy's generator: np.random.seed still fixes the chain
             rng_seed, rng_ctr = int(np.random.randint(0, 2 ** 31 - 1)) * 2654435761 + 1, 0
+        device_hyper = device_rng and d <= 32
+        if device_hyper:
+            # hyper-priors and outputs resident: the whole yield is enqueued without a host hop
+            hp_u = tuple(ctx.array(np.asarray(x, np.float64)) for x in (self.u_hyperparams[0], self.u_hyperparams[3]))
+            hp_v = tuple(ctx.array(np.asarray(x, np.float64)) for x in (self.v_hyperparams[0], self.v_hyperparams[3]))
+            d_mu_u, d_al_u, d_mu_v, d_al_v = ctx.empty(d), ctx.empty((d, d)), ctx.empty(d), ctx.empty((d, d))
+            d_status = ctx.zeros(1, np.int32)
         while True:
-            mu_u, alpha_u = self.sample_hyperparam(user_sample, True)
-            mu_v, alpha_v = self.sample_hyperparam(item_sample, False)
-            d_mu_u, d_al_u = ctx.array(mu_u, np.float64), ctx.array(alpha_u, np.float64)
-            d_mu_v, d_al_v = ctx.array(mu_v, np.float64), ctx.array(alpha_v, np.float64)
+            if device_hyper:
+                # sample_hyperparam (bayes_pmf.py:157-186) on the device, from the resident samples
+                ctx.gibbs_sample_hyperparam(d_users, n, d, hp_u[0], self.u_hyperparams[1], self.u_hyperparams[2],
+                                            hp_u[1], d_mu_u, d_al_u, seed=rng_seed ^ 0x5DEECE66D, offset=rng_ctr,
+                                            status=d_status)
+                ctx.gibbs_sample_hyperparam(d_items, m, d, hp_v[0], self.v_hyperparams[1], self.v_hyperparams[2],
+                                            hp_v[1], d_mu_v, d_al_v, seed=rng_seed ^ 0x5DEECE66D,
+                                            offset=rng_ctr + 1024, status=d_status)
+                rng_ctr += 2048
+            else:
+                mu_u, alpha_u = self.sample_hyperparam(user_sample, True)
+                mu_v, alpha_v = self.sample_hyperparam(item_sample, False)
+                d_mu_u, d_al_u = ctx.array(mu_u, np.float64), ctx.array(alpha_u, np.float64)
+                d_mu_v, d_al_v = ctx.array(mu_v, np.float64), ctx.array(alpha_v, np.float64)
             for gibbs in range(num_gibbs):
                 # one N(0,1)^d per user in user order == one (n, d) draw
                 if device_rng:
@@ -192,6 +209,8 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
                 ctx.gibbs_half_sweep(rt, 1, d_users, d, d_al_v, d_mu_v, beta, sub, d_z_v, new_items)
                 d_items = new_items
             user_sample, item_sample = d_users.to_host(), d_items.to_host()
+            if device_hyper and int(d_status.to_host()[0]):
+                raise np.linalg.LinAlgError("a matrix of the hyper-parameter step is not positive definite")
             yield user_sample, item_sample
 
     def samples_parallel(self, num_gibbs=2, pool=None, multiproc_mode=None, fit_first=False):

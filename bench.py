@@ -99,7 +99,11 @@ def main():
     rehearsal = bool(os.environ.get('APMF_BENCH_SHARE_GPU'))   # N > 1 on a one-GPU box only
     dev = local_rank % max(_lib.device_count(), 1) if rehearsal else local_rank
     ctx = _lib.Context(dev)
-    # the communicator: a failure here ends the run (no silent single-rank numbers)
+    # the communicator: a failure here ends the run (no silent single-rank numbers).  RCCL prints a
+    # version banner when it initialises: keep stdout for the ONE JSON line
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if rehearsal:
@@ -109,6 +113,10 @@ def main():
             comm = sharding.comm_from_env(ctx)
     else:
         comm = sharding.Comm(0, 1, ctx=ctx, rccl=bool(os.environ.get('APMF_BENCH_FORCE_EXCHANGE')))
+    comm.barrier()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     strong = args.scaling == 'strong'
 
     def max_over_ranks(x):

@@ -394,6 +394,20 @@ int apmf_comm_allreduce_f64(apmf_ctx *ctx, apmf_comm *c, const double *d_send, d
 /* every rank's stream has reached this point; synchronises the calling host thread with it */
 int apmf_comm_barrier(apmf_ctx *ctx, apmf_comm *c);
 
+/* ---- the Gaussian-Wishart hyper-parameter step of the Gibbs sampler on the device ----------------
+ * BayesianPMF.sample_hyperparam + sample_wishart (bayes_pmf.py:157-186, 41-59; the scalar-inner-
+ * product quirk of :171-176 kept): (mu, alpha) given the feature matrix d_feats (N, d), d <= 32,
+ * hyper-prior d_wi (d, d), b0, df, d_mu0 (d).  Wishart draw by Bartlett's decomposition.
+ * d_variates: NULL = draw from the Philox stream (seed, offset; a call consumes < 1024 counters), or
+ * [chi-squares (d) | N(0,1) of the strict lower triangle, row-major (d (d-1) / 2) | z (d)] - what NumPy
+ * draws, in this order, in the Bartlett branch of sample_wishart and for mu.
+ * d_status: device int (zeroed by the caller), set to 1 on a non-positive-definite matrix, no host
+ * synchronisation; NULL: the call synchronises and returns APMF_ENOTPD itself. */
+int apmf_gibbs_sample_hyperparam(apmf_ctx *ctx, const double *d_feats, int N, int d, const double *d_wi,
+                                 double b0, double df, const double *d_mu0, const double *d_variates,
+                                 uint64_t seed, uint64_t offset, double *d_mu, double *d_alpha,
+                                 int *d_status);
+
 #ifdef __cplusplus
 }
 #endif

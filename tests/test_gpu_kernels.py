@@ -779,3 +779,71 @@ def test_fill_normal_device_generator(ctx):
     odd = ctx.empty(7)
     ctx.fill_normal(odd, 1, 0)
     assert np.all(np.isfinite(odd.to_host()))
+
+
+# ---------------------------------------------------------------------------- K7 (Gibbs hyper-parameters)
+@pytest.mark.parametrize('shape', [(40, 3), (943, 15), (300, 32)])
+def test_device_hyperparam_step_vs_numpy(ctx, shape):
+    """apmf_gibbs_sample_hyperparam with SUPPLIED variates == the host arithmetic of
+    BayesianPMF.sample_hyperparam + the Bartlett branch of sample_wishart (bayes_pmf.py:41-59,
+    157-186) on the same chi-square / normal draws - including the reference's quirk of adding the
+    scalar <mu0 - x_bar, mu0 - x_bar> to every element."""
+    N, d = shape
+    rs = np.random.RandomState(N + d)
+    F = rs.normal(0.3, 1.5, (N, d)) @ (np.eye(d) + .2 * rs.normal(size=(d, d)))
+    wi, b0, df, mu0 = np.eye(d) + .1 * np.ones((d, d)), 2., float(d), rs.normal(size=d) * .1
+    dof = df + N
+    chi = rs.chisquare(dof - np.arange(d))
+    low = rs.normal(size=d * (d - 1) // 2)
+    z = rs.normal(size=d)
+    # host restatement
+    x_bar = F.mean(0)
+    S_bar = np.cov(F, rowvar=0).reshape(d, d)
+    diff = mu0 - x_bar
+    WI = np.linalg.inv(np.linalg.inv(wi) + N * S_bar + (b0 * N) / (b0 + N) * np.dot(diff, diff.T))
+    WI /= 2
+    WI = WI + WI.T
+    A = np.diag(np.sqrt(chi))
+    A[np.tri(d, k=-1, dtype=bool)] = low
+    X = np.linalg.cholesky(WI) @ A
+    alpha = X @ X.T
+    lam = np.linalg.cholesky(np.linalg.inv((b0 + N) * alpha))
+    mu = lam @ z + (b0 * mu0 + N * x_bar) / (b0 + N)
+    d_mu, d_alpha = ctx.empty(d), ctx.empty((d, d))
+    ctx.gibbs_sample_hyperparam(ctx.array(F), N, d, ctx.array(wi), b0, df, ctx.array(mu0), d_mu, d_alpha,
+                                variates=ctx.array(np.concatenate([chi, low, z])))
+    np.testing.assert_allclose(d_alpha.to_host(), alpha, rtol=1e-9, atol=1e-12 * np.abs(alpha).max())
+    np.testing.assert_allclose(d_mu.to_host(), mu, rtol=1e-9, atol=1e-11)
+
+
+def test_device_hyperparam_generator_moments(ctx):
+    """The same step drawing its own variates (Philox: Box-Muller normals, Marsaglia-Tsang
+    chi-squares): E[alpha] = dof * WI for a Wishart draw, mu centred on the posterior mean;
+    reproducible per (seed, offset), different across offsets."""
+    N, d = 200, 4
+    rs = np.random.RandomState(3)
+    F = rs.normal(0.5, 1., (N, d))
+    wi, b0, df, mu0 = np.eye(d), 2., float(d), np.zeros(d)
+    x_bar = F.mean(0)
+    S_bar = np.cov(F, rowvar=0)
+    diff = mu0 - x_bar
+    WI = np.linalg.inv(np.linalg.inv(wi) + N * S_bar + (b0 * N) / (b0 + N) * np.dot(diff, diff))
+    WI = WI / 2 + (WI / 2).T
+    dF, dW, dm0 = ctx.array(F), ctx.array(wi), ctx.array(mu0)
+    d_mu, d_alpha = ctx.empty(d), ctx.empty((d, d))
+    alphas, mus = [], []
+    for k in range(600):
+        ctx.gibbs_sample_hyperparam(dF, N, d, dW, b0, df, dm0, d_mu, d_alpha, seed=1234, offset=1024 * k)
+        alphas.append(d_alpha.to_host())
+        mus.append(d_mu.to_host())
+    alphas, mus = np.array(alphas), np.array(mus)
+    mean_alpha = alphas.mean(0)
+    expect = (df + N) * WI
+    # Wishart: Var[alpha_ij] = dof (WI_ij^2 + WI_ii WI_jj); 600 draws -> ~4 sigma band
+    sd = np.sqrt((df + N) * (WI ** 2 + np.outer(np.diag(WI), np.diag(WI))) / 600)
+    assert np.all(np.abs(mean_alpha - expect) < 4.5 * sd), (mean_alpha, expect)
+    mu_mean = (b0 * mu0 + N * x_bar) / (b0 + N)
+    assert np.all(np.abs(mus.mean(0) - mu_mean) < 5 * mus.std(0) / np.sqrt(600))
+    assert np.all(np.array([np.linalg.eigvalsh(a).min() for a in alphas[:20]]) > 0)
+    ctx.gibbs_sample_hyperparam(dF, N, d, dW, b0, df, dm0, d_mu, d_alpha, seed=1234, offset=1024 * 7)
+    assert np.array_equal(d_alpha.to_host(), alphas[7]) and not np.array_equal(alphas[7], alphas[8])
