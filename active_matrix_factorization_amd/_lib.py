@@ -83,6 +83,7 @@ _SIGS = {
     'apmf_full_score_grid_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'apmf_gibbs_half_sweep': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
     'apmf_gibbs_half_sweep_rows': (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _dbl, _dbl, _vp, _vp]),
+    'apmf_gibbs_half_sweep_batched': (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _dbl, _vp, _vp, _vp, _vp, _vp, _vp]),
     'apmf_sample_stats_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
     'apmf_gibbs_sample_hyperparam': (_i, [_vp, _vp, _i, _i, _vp, _dbl, _dbl, _vp, _vp, C.c_uint64, C.c_uint64, _vp,
                                           _vp, _vp]),
@@ -718,6 +719,12 @@ class Context(object):
                                                       float(df), _ptr(mu0), _ptr(variates),
                                                       int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
                                                       _ptr(mu), _ptr(alpha), _ptr(status)))
+
+    def gibbs_half_sweep_batched(self, rt, side, H, oth, d, alpha, mu, beta, mean_sub, z, out, ei=None, ej=None,
+                                 ev=None):
+        _check(self._lib.apmf_gibbs_half_sweep_batched(self._h, rt._h, side, int(H), _ptr(oth), d, _ptr(alpha),
+                                                       _ptr(mu), float(beta), _ptr(mean_sub), _ptr(z), _ptr(out),
+                                                       _ptr(ei), _ptr(ej), _ptr(ev)))
 
     def fill_normal(self, out, seed, offset=0):
         """out[...] ~ N(0, 1) from the device generator (Philox4x32-10 + Box-Muller); not NumPy's stream."""

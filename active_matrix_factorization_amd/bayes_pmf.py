@@ -32,18 +32,31 @@ except ImportError:      # top-level import (package directory on sys.path, like
     from pmf_cy import ProbabilisticMatrixFactorization, rmse, parse_fit_type  # noqa: F401
 
 
+def _wishart_variates(n, dof):
+    """The random numbers sample_wishart consumes, drawn with the reference's calls in its order
+    (they do not depend on the scale matrix, so a whole chain's draws can be made ahead of time)."""
+    if dof <= 81 + n and dof == round(dof):
+        return ('direct', np.random.normal(size=(n, int(dof))))
+    chi = np.random.chisquare(dof - np.arange(0, n), size=n)
+    return ('bartlett', chi, np.random.normal(size=(n * (n - 1) // 2)))
+
+
+def _wishart_from_variates(sigma, variates):
+    n = sigma.shape[0]
+    chol = np.linalg.cholesky(sigma)
+    if variates[0] == 'direct':
+        X = np.dot(chol, variates[1])
+    else:
+        A = np.diag(np.sqrt(variates[1]))
+        A[np.tri(n, k=-1, dtype=bool)] = variates[2]
+        X = np.dot(chol, A)
+    return np.dot(X, X.T)
+
+
 def sample_wishart(sigma, dof):
     '''A draw from the Wishart distribution (bayes_pmf.py:41-59, after M. J. Johnson); the
     direct scheme for small integer dof, Bartlett's otherwise - same RNG call sequence.'''
-    n = sigma.shape[0]
-    chol = np.linalg.cholesky(sigma)
-    if dof <= 81 + n and dof == round(dof):
-        X = np.dot(chol, np.random.normal(size=(n, int(dof))))
-    else:
-        A = np.diag(np.sqrt(np.random.chisquare(dof - np.arange(0, n), size=n)))
-        A[np.tri(n, k=-1, dtype=bool)] = np.random.normal(size=(n * (n - 1) // 2))
-        X = np.dot(chol, A)
-    return np.dot(X, X.T)
+    return _wishart_from_variates(sigma, _wishart_variates(sigma.shape[0], dof))
 
 
 def iter_mean(iterable):
@@ -113,6 +126,15 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
         (bayes_pmf.py:157-186).  Host d x d work, arithmetic as in the reference - including
         np.dot of the two 1-D vectors mu0 - x_bar, which is their INNER product (:171-176).'''
         wi, b0, df, mu0 = self.u_hyperparams if do_users else self.v_hyperparams
+        return self._hyper_from_variates(feats, do_users, self._hyper_variates(feats.shape[0], do_users))
+
+    def _hyper_variates(self, N, do_users):
+        """What one sample_hyperparam call draws, in its order: the Wishart's variates, then N(0,1)^d."""
+        df = (self.u_hyperparams if do_users else self.v_hyperparams)[2]
+        return _wishart_variates(self.latent_d, df + N), np.random.normal(0, 1, self.latent_d)
+
+    def _hyper_from_variates(self, feats, do_users, variates):
+        wi, b0, df, mu0 = self.u_hyperparams if do_users else self.v_hyperparams
         N = feats.shape[0]
         x_bar = np.mean(feats, axis=0).T
         S_bar = np.cov(feats, rowvar=0)
@@ -121,10 +143,10 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
                                 + (b0 * N) / (b0 + N) * np.dot(mu0_xbar, mu0_xbar.T))
         WI_post /= 2
         WI_post = WI_post + WI_post.T
-        alpha = sample_wishart(WI_post, df + N)
+        alpha = _wishart_from_variates(WI_post, variates[0])
         mu_temp = (b0 * mu0 + N * x_bar) / (b0 + N)
         lam = np.linalg.cholesky(np.linalg.inv((b0 + N) * alpha))
-        mu = np.dot(lam, np.random.normal(0, 1, self.latent_d)) + mu_temp
+        mu = np.dot(lam, variates[1]) + mu_temp
         return mu, alpha
 
     def _mean_sub(self):
@@ -293,13 +315,125 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
                 warnings.warn("have no rating_values; doing continuous")
             discrete = False
             params = zip(np.mean(vals, 0).flat, np.var(vals, 0).flat)
-        exps = map(fn, zip(repeat(self), i_indices.flat, j_indices.flat, repeat(discrete), params,
-                           repeat(fit_first), repeat(num_samps)))
         res = np.empty(np.shape(vals)[1:])
         res.fill(np.nan)
+        if discrete and fn is _exp_variance_helper and self.fit_type == ('batch',) and \
+                os.environ.get('APMF_LOOKAHEAD_BATCH', '1') != '0':
+            # every hypothesis (candidate x rating value) of the pool in one batch on the device
+            exps = self._exp_variance_batched(list(zip(i_indices.flat, j_indices.flat)), list(params),
+                                              fit_first, num_samps)
+        else:
+            exps = map(fn, zip(repeat(self), i_indices.flat, j_indices.flat, repeat(discrete), params,
+                               repeat(fit_first), repeat(num_samps)))
         for idx, exp in enumerate(exps):
             res.flat[idx] = exp
         return res
+
+    def _exp_variance_batched(self, cands, params, fit_first, num_samps, num_gibbs=2):
+        """E[total variance | R_ij] for every candidate (bayes_pmf.py:457-525, 560-598), all
+        hypotheses "R_ij = v" sampled TOGETHER: their Gibbs chains advance by batched half-sweeps
+        (K3 with the hypothesis as a grid dimension; each hypothesis is the shared ratings container
+        plus one rating), their statistics come from K4 on the device-resident chain history.
+        The random numbers are NumPy's, drawn per hypothesis in the order the reference's one-at-a-
+        time evaluation consumes them (deep copy's constructor, then per yield: both hyper-parameter
+        draws, then the sweeps' normals) - they do not depend on the state, so a chain's draws are
+        made ahead of time and a seeded run gives what the sequential evaluation gives."""
+        ctx = self._device().ctx
+        n, m, d = self.num_users, self.num_items, self.latent_d
+        values = list(self.rating_values)
+        beta = float(self.beta)
+        base = np.ascontiguousarray(self.ratings, np.float64)
+        rt = ctx.ratings(base, n, m)
+        out = [np.nan] * len(cands)
+        hyps = []                      # (candidate index, value index, i, j, v)
+        for c, (i, j) in enumerate(cands):
+            i, j = int(i), int(j)
+            if (i, j) in self.rated:
+                warnings.warn("Asked to check a known entry; returning NaN")
+                continue
+            hyps.extend((c, k, i, j, float(v)) for k, v in enumerate(values))
+        evals = np.zeros((len(cands), len(values)))
+        per_hyp = num_samps * (num_gibbs * (n + m) * d * 8 + 4096) + (n + m) * d * 8 * (num_samps + 4)
+        chunk = max(1, min(len(hyps), int(float(os.environ.get('APMF_LOOKAHEAD_HOST_GB', '4')) * 2 ** 30) // per_hyp,
+                           4096))
+        ld = _lib.grid_ld(m)
+        sig = (float(self.sigma_sq), float(self.sigma_u_sq), float(self.sigma_v_sq))
+        for lo in range(0, len(hyps), chunk):
+            part = hyps[lo:lo + chunk]
+            H = len(part)
+            # ---- all random numbers of these chains, hypothesis by hypothesis (the reference's order)
+            draws = []
+            for _ in part:
+                np.random.random((n, d))      # deepcopy -> BayesianPMF(...) draws its initial factors
+                np.random.random((m, d))
+                chain = []
+                for s in range(num_samps):
+                    hu = self._hyper_variates(n, True)
+                    hv = self._hyper_variates(m, False)
+                    zs = [(np.random.normal(0, 1, (n, d)), np.random.normal(0, 1, (m, d))) for _g in range(num_gibbs)]
+                    chain.append((hu, hv, zs))
+                draws.append(chain)
+            # ---- starting points: the model's MAP factors, re-fitted with the extra rating if fit_first
+            U0 = np.empty((H, n, d))
+            V0 = np.empty((H, m, d))
+            mean_sub = np.zeros(H)
+            for h, (_c, _k, i, j, v) in enumerate(part):
+                plus = np.vstack([base, [i, j, v]])
+                mr = float(np.mean(plus[:, 2]))
+                mean_sub[h] = mr if self.subtract_mean else 0.
+                if fit_first:
+                    rth = ctx.ratings(plus, n, m)
+                    dU, dV = ctx.array(self.users, np.float64), ctx.array(self.items, np.float64)
+                    ctx.pmf_fit_lls(rth, dU, dV, d, sig[0], sig[1], sig[2], self.subtract_mean, mr,
+                                    float(self.learning_rate), float(self.min_learning_rate),
+                                    float(self.stop_thresh), max_steps=-1, max_trace=0)
+                    U0[h], V0[h] = dU.to_host(), dV.to_host()
+                    rth.free()
+                else:
+                    U0[h], V0[h] = self.users, self.items
+            d_users, d_items = ctx.array(U0), ctx.array(V0)
+            d_ms = ctx.array(mean_sub)
+            d_ei = ctx.array(np.array([p[2] for p in part], np.int32), np.int32)
+            d_ej = ctx.array(np.array([p[3] for p in part], np.int32), np.int32)
+            d_ev = ctx.array(np.array([p[4] for p in part], np.float64))
+            hist_U, hist_V = ctx.empty((H, num_samps, n, d)), ctx.empty((H, num_samps, m, d))
+            users_h, items_h = U0, V0
+            for s in range(num_samps):
+                mus_u, als_u, mus_v, als_v = np.empty((H, d)), np.empty((H, d, d)), np.empty((H, d)), np.empty((H, d, d))
+                for h in range(H):
+                    mus_u[h], als_u[h] = self._hyper_from_variates(users_h[h], True, draws[h][s][0])
+                    mus_v[h], als_v[h] = self._hyper_from_variates(items_h[h], False, draws[h][s][1])
+                d_mu_u, d_al_u, d_mu_v, d_al_v = ctx.array(mus_u), ctx.array(als_u), ctx.array(mus_v), ctx.array(als_v)
+                for g in range(num_gibbs):
+                    zu = ctx.array(np.stack([draws[h][s][2][g][0] for h in range(H)]))
+                    new_users = ctx.empty((H, n, d))
+                    ctx.gibbs_half_sweep_batched(rt, 0, H, d_items, d, d_al_u, d_mu_u, beta, d_ms, zu, new_users,
+                                                 d_ei, d_ej, d_ev)
+                    d_users = new_users
+                    zv = ctx.array(np.stack([draws[h][s][2][g][1] for h in range(H)]))
+                    new_items = ctx.empty((H, m, d))
+                    ctx.gibbs_half_sweep_batched(rt, 1, H, d_users, d, d_al_v, d_mu_v, beta, d_ms, zv, new_items,
+                                                 d_ei, d_ej, d_ev)
+                    d_items = new_items
+                for h in range(H):
+                    ctx.copy(hist_U, d_users, n * d * 8, dst_off=((h * num_samps + s) * n * d) * 8, src_off=h * n * d * 8)
+                    ctx.copy(hist_V, d_items, m * d * 8, dst_off=((h * num_samps + s) * m * d) * 8, src_off=h * m * d * 8)
+                if s + 1 < num_samps:
+                    users_h, items_h = d_users.to_host(), d_items.to_host()
+            # ---- total variance over the samples of every hypothesis (K4), from the device history
+            var = ctx.empty((n, ld))
+            for h, (c, k, i, j, v) in enumerate(part):
+                ctx.sample_stats(num_samps, n, m, d, ld, hist_U.ptr + h * num_samps * n * d * 8,
+                                 hist_V.ptr + h * num_samps * m * d * 8, float(mean_sub[h]), 0., var=var)
+                evals[c, k] = ctx.download_grid(var, m).sum()
+        rt.free()
+        for c, (i, j) in enumerate(cands):
+            if (int(i), int(j)) in self.rated:
+                continue
+            est = (evals[c] * params[c]).sum()
+            print("\t{:>20}({},{}) {}: {: 10.2f}".format('total_variance', int(i), int(j), "summed", est))
+            out[c] = est
+        return out
 
 
 def _integrate_lookahead(fn, bpmf, i, j, discrete, params, fit_first, num_samps):

@@ -43,6 +43,16 @@ __device__ __forceinline__ bool chol_lds(double *A, int d, int lda, int lane)
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
+// per-hypothesis layout of a batched half-sweep (all zero / NULL for the plain one)
+struct GibbsBatch {
+    size_t oth_stride;      // doubles between the hypotheses' other-side feature matrices
+    size_t row_stride;      // rows * d: between their z and out arrays
+    const double *mean_sub; // (H) or NULL: the scalar argument
+    const int *ei, *ej;     // (H) extra rating, or NULL
+    const double *ev;
+    int side;
+};
+
 // TL = ceil(d / 16): F'F is built as TL x TL tiles of v_mfma_f64_16x16x4_f64 (upper triangle
 // only).  For the tile (ti, tj) and 4 consecutive ratings r0..r0+3, lane l supplies
 // F[r0 + (l >> 4)][16 t + (l & 15)] - the same element pattern for the A and the B operand - so
@@ -56,12 +66,29 @@ __global__ __launch_bounds__(64) void k_gibbs_rows(int row_lo, int rows, int d, 
                                                    const double *__restrict__ alpha,
                                                    const double *__restrict__ mu, double beta,
                                                    double mean_sub, const double *__restrict__ z,
-                                                   double *__restrict__ out, int *__restrict__ status)
+                                                   double *__restrict__ out, int *__restrict__ status,
+                                                   const GibbsBatch gb)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     const int row = row_lo + blockIdx.x;
     if (row >= rows) return;
+    // hypothesis of a batched half-sweep (blockIdx.y): its own operands, and ONE rating on top of the
+    // shared container - taken as the last entry of its row, where add_rating() + a rebuilt container
+    // would put it (bayes_pmf.py:490-500: deepcopy, add_rating, samples)
+    const int h = blockIdx.y;
+    oth += (size_t)h * gb.oth_stride;
+    alpha += (size_t)h * d * d;
+    mu += (size_t)h * d;
+    z += (size_t)h * gb.row_stride;
+    out += (size_t)h * gb.row_stride;
+    if (gb.mean_sub) mean_sub = gb.mean_sub[h];
+    int xsrc = -1;
+    double xval = 0.;
+    if (gb.ei) {
+        const int own = gb.side == 0 ? gb.ei[h] : gb.ej[h];
+        if (own == row) { xsrc = gb.side == 0 ? gb.ej[h] : gb.ei[h]; xval = gb.ev[h]; }
+    }
     const int lda = d + 1;
     double *A = smem;                     // d x lda : A, then its Cholesky factor, then chol(cov)
     double *X = A + d * lda;              // d x lda : L^-1, then cov
@@ -78,12 +105,14 @@ __global__ __launch_bounds__(64) void k_gibbs_rows(int row_lo, int rows, int d, 
 #pragma unroll
     for (int t = 0; t < TL; t++) racc[t] = 0.;
 
-    const int64_t beg = ptr[row], end = ptr[row + 1];
+    const int64_t beg = ptr[row], end0 = ptr[row + 1];
+    const int64_t end = end0 + (xsrc >= 0 ? 1 : 0);
     for (int64_t r0 = beg; r0 < end; r0 += 4) {
         const int64_t r = r0 + q;
         const bool ok = r < end;
-        const int32_t src = ok ? idx[r] : 0;
-        const double rv = ok ? val[r] - mean_sub : 0.;
+        const bool ex = ok && r == end0;          // only reachable with an extra rating
+        const int32_t src = ok ? (ex ? xsrc : idx[r]) : 0;
+        const double rv = ok ? (ex ? xval : val[r]) - mean_sub : 0.;
         double f[TL];
 #pragma unroll
         for (int t = 0; t < TL; t++) {
@@ -212,7 +241,9 @@ __global__ __launch_bounds__(256) void k_fill_normal(double *__restrict__ out, i
 
 static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo, int row_hi,
                       const double *d_oth, int d, const double *d_alpha, const double *d_mu, double beta,
-                      double mean_sub, const double *d_z, double *d_out);
+                      double mean_sub, const double *d_z, double *d_out, int H = 1,
+                      const double *d_mean_sub = nullptr, const int *d_ei = nullptr, const int *d_ej = nullptr,
+                      const double *d_ev = nullptr);
 
 extern "C" int apmf_gibbs_half_sweep(apmf_ctx *ctx, const apmf_ratings *r, int side, const double *d_oth,
                                      int d, const double *d_alpha, const double *d_mu, double beta,
@@ -239,7 +270,8 @@ extern "C" int apmf_gibbs_half_sweep_rows(apmf_ctx *ctx, const apmf_ratings *r, 
 
 static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo, int row_hi,
                       const double *d_oth, int d, const double *d_alpha, const double *d_mu, double beta,
-                      double mean_sub, const double *d_z, double *d_out)
+                      double mean_sub, const double *d_z, double *d_out, int H, const double *d_mean_sub,
+                      const int *d_ei, const int *d_ej, const double *d_ev)
 {
     APMF_REQUIRE(ctx && r, "ctx/ratings is NULL");
     APMF_REQUIRE(side == 0 || side == 1, "side must be 0 (users) or 1 (items)");
@@ -248,7 +280,15 @@ static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo
     // bayes_pmf.py:287,296: items_by_user[user_id] raises KeyError for a row without ratings
     APMF_REQUIRE(!r->has_empty[side], "a %s has no rating: the Gibbs sweep needs >= 1 per row",
                  side == 0 ? "user" : "item");
+    APMF_REQUIRE(H >= 1 && H <= 65535, "bad hypothesis count %d", H);
     if (row_hi == row_lo) return APMF_OK;
+    GibbsBatch gb;
+    const int rows_own = side == 0 ? r->n : r->m, rows_oth = side == 0 ? r->m : r->n;
+    gb.oth_stride = H > 1 ? (size_t)rows_oth * d : 0;
+    gb.row_stride = H > 1 ? (size_t)rows_own * d : 0;
+    gb.mean_sub = d_mean_sub;
+    gb.ei = d_ei; gb.ej = d_ej; gb.ev = d_ev;
+    gb.side = side;
     void *w;
     APMF_TRY(apmf_ws(ctx, 2, 64, &w));
     int *d_status = (int *)w;
@@ -256,9 +296,9 @@ static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo
     const int tl = (d + 15) / 16;
     const size_t smem = gibbs_smem(d);
 #define LAUNCH_GIBBS(TLV)                                                                         \
-    hipLaunchKernelGGL((k_gibbs_rows<TLV>), dim3(row_hi - row_lo), dim3(64), smem, ctx->stream,   \
+    hipLaunchKernelGGL((k_gibbs_rows<TLV>), dim3(row_hi - row_lo, H), dim3(64), smem, ctx->stream, \
                        row_lo, row_hi, d, r->ptr[side], r->idx[side], r->val[side], d_oth, d_alpha, \
-                       d_mu, beta, mean_sub, d_z, d_out, d_status)
+                       d_mu, beta, mean_sub, d_z, d_out, d_status, gb)
     if (smem > 64 * 1024)
         APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_gibbs_rows<4>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -275,6 +315,21 @@ static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo
         return APMF_ENOTPD;
     }
     return APMF_OK;
+}
+
+// H half-sweeps in one launch: the hypotheses of BayesianPMF.exp_variance (bayes_pmf.py:457-525, 560-598)
+extern "C" int apmf_gibbs_half_sweep_batched(apmf_ctx *ctx, const apmf_ratings *r, int side, int H,
+                                             const double *d_oth, int d, const double *d_alpha, const double *d_mu,
+                                             double beta, const double *d_mean_sub, const double *d_z, double *d_out,
+                                             const int32_t *d_ei, const int32_t *d_ej, const double *d_ev)
+{
+    APMF_REQUIRE(ctx && r, "ctx/ratings is NULL");
+    APMF_REQUIRE(side == 0 || side == 1, "side must be 0 (users) or 1 (items)");
+    APMF_REQUIRE(d_mean_sub, "d_mean_sub is NULL");
+    APMF_REQUIRE((d_ei == nullptr) == (d_ej == nullptr) && (d_ei == nullptr) == (d_ev == nullptr),
+                 "the extra rating needs all of d_ei, d_ej, d_ev");
+    return gibbs_rows(ctx, r, side, 0, side == 0 ? r->n : r->m, d_oth, d, d_alpha, d_mu, beta, 0., d_z, d_out, H,
+                      d_mean_sub, d_ei, d_ej, d_ev);
 }
 
 extern "C" int apmf_fill_normal_f64(apmf_ctx *ctx, double *d_out, int64_t count, uint64_t seed, uint64_t offset)

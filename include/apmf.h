@@ -234,6 +234,17 @@ int apmf_gibbs_half_sweep_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, i
                                const double *d_mu, double beta, double mean_sub,
                                const double *d_z, double *d_out);
 
+/* H half-sweeps in one launch (the hypothesis is a grid dimension): the lookahead of
+ * BayesianPMF.exp_variance (bayes_pmf.py:457-525, 560-598), where every hypothesis "R_ij = v" is
+ * deepcopy -> add_rating -> samples().  All arrays carry a leading H: d_oth (H, other rows, d),
+ * d_alpha (H, d, d), d_mu (H, d), d_mean_sub (H), d_z / d_out (H, rows, d).  d_ei / d_ej / d_ev (H,
+ * nullable together): ONE rating per hypothesis on top of the shared container, taken as the last
+ * entry of its row - where add_rating() (pmf_cy.pyx:128-156) + a rebuilt container puts it. */
+int apmf_gibbs_half_sweep_batched(apmf_ctx *ctx, const apmf_ratings *r, int side, int H,
+                                  const double *d_oth, int d, const double *d_alpha, const double *d_mu,
+                                  double beta, const double *d_mean_sub, const double *d_z, double *d_out,
+                                  const int32_t *d_ei, const int32_t *d_ej, const double *d_ev);
+
 /* ---- K4: statistics over S posterior samples (bayes_pmf.py:433-448, 528-538) -----------
  * predict / pred_variance / prob_ge_cutoff: per (i, j) the mean, the variance (ddof 0) and
  * the fraction >= cutoff of  U_s[i] . V_s[j] + add  over s < S.

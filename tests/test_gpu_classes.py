@@ -1041,3 +1041,34 @@ def test_from_dense_defers_the_sets(pkg):
                            knowable=zip(*knowable.nonzero()), steps=3, do_threading=True)
     assert [s[2] for s in res_a['pred-variance']] == [s[2] for s in res_b['pred-variance']]
     assert [s[1] for s in res_a['pred-variance']] == [s[1] for s in res_b['pred-variance']]
+
+
+def test_bayes_exp_variance_batched_equals_sequential(pkg, monkeypatch):
+    """BayesianPMF.exp_variance (bayes_pmf.py:457-525, 560-598): all hypotheses (candidate x rating
+    value) sampled together - batched K3 half-sweeps with the hypothesis' extra rating, K4 on the
+    device-resident chain history, random numbers pre-drawn in the reference's one-at-a-time order -
+    give what evaluating them one deep copy at a time gives under the same seed."""
+    g = load_golden('bayes_c1_10x10_d2')
+    b = pkg.bayes.BayesianPMF(g['ratings'].copy(), latent_d=2, subtract_mean=False, rating_values=(1, 2, 3, 4, 5))
+    b.users, b.items = g['users'].copy(), g['items'].copy()
+    seed(5)
+    samps = list(islice(b.samples(), 5))
+    unr = np.array(sorted(b.unrated)[:4]).T
+    which = tuple(unr)
+    for fit_first in (True, False):
+        seed(6)
+        batched = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
+        state = np.random.get_state()[1][:8].copy()
+        monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', '0')
+        seed(6)
+        alone = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
+        monkeypatch.delenv('APMF_LOOKAHEAD_BATCH')
+        assert batched.shape == (4,) and np.all(np.isfinite(batched))
+        np.testing.assert_allclose(batched, alone, rtol=1e-12)
+        assert np.array_equal(state, np.random.get_state()[1][:8])       # the same random stream was consumed
+    # a rated entry among the candidates: NaN, like the reference
+    r0 = tuple(int(x) for x in g['ratings'][0, :2])
+    both = (np.array([r0[0], unr[0, 0]]), np.array([r0[1], unr[1, 0]]))
+    with pytest.warns(UserWarning):
+        res = b.exp_variance(samps, which=both, num_samps=2)
+    assert np.isnan(res[0]) and np.isfinite(res[1])
