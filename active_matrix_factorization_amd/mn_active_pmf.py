@@ -350,11 +350,27 @@ class MNActivePMF(_ActiveBase):
                 batch = ctx.mn_batch(rt, d, H)
             models = None
             if self.refit_lookahead:
-                # MAP re-fit per hypothesis, then initialize_approx(): mean = MAP, identity covariances
-                models = [self._hypothesis_model(i, j, v) for i, j, v in part]
-                for apmf in models:
-                    apmf.do_fit()
-                means = np.stack([np.vstack((apmf.users, apmf.items)) for apmf in models])
+                # MAP re-fit per hypothesis (do_fit), then initialize_approx(): mean = MAP, identity
+                # covariances.  The batch fit needs no model objects: fit_lls runs straight on a
+                # container with the hypothesis' rating appended (other fit types, or a criterion
+                # that wants the models, take the deep copies the reference makes)
+                if self.fit_type == ('batch',) and special is not None:
+                    means = np.empty((H, n_all, d))
+                    dd_, s_, su_, sv_, sub_, _mr = self._hyper()
+                    for k, (i, j, v) in enumerate(part):
+                        plus = np.vstack([self.ratings, [i, j, v]])
+                        rth = ctx.ratings(plus, self.num_users, self.num_items)
+                        dU, dV = ctx.array(self.users, np.float64), ctx.array(self.items, np.float64)
+                        ctx.pmf_fit_lls(rth, dU, dV, d, s_, su_, sv_, sub_, float(np.mean(plus[:, 2])),
+                                        float(self.learning_rate), float(self.min_learning_rate),
+                                        float(self.stop_thresh), max_steps=-1, max_trace=0)
+                        means[k, :self.num_users], means[k, self.num_users:] = dU.to_host(), dV.to_host()
+                        rth.free()
+                else:
+                    models = [self._hypothesis_model(i, j, v) for i, j, v in part]
+                    for apmf in models:
+                        apmf.do_fit()
+                    means = np.stack([np.vstack((apmf.users, apmf.items)) for apmf in models])
                 batch.set_state(ctx.array(means), ctx.array(np.eye(n_all)), ctx.array(np.eye(d)),
                                 per_hypothesis=1)
             else:
