@@ -186,24 +186,49 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
 {
     const ChJob job = ch_job(J, blockIdx.y);
     double *__restrict__ A = job.A;
-    __shared__ double Pi[64][TP], Pj[64][TP];
+    // the panel is staged 32 columns at a time: 35 KB of LDS per block -> 4 blocks (16 waves) per CU
+    // instead of 2; this kernel is latency-bound (PMC: ~1.7 TB/s of HBM traffic), occupancy is what helps
+    constexpr int KS = 32, KP = KS + 2;
+    __shared__ double Pi[64][KP], Pj[64][KP];
     if (*job.info != 0) return;
     const int nb = min(CH_NB, N - k);
     const int base = k + nb;
     int ti, tj;
     tri_tile((int)blockIdx.x, ti, tj);
     const int i0 = base + ti * 64, j0 = base + tj * 64;
-    for (int e = threadIdx.x; e < 64 * CH_NB; e += 256) {
-        const int r = e / CH_NB, c = e % CH_NB;
-        Pi[r][c] = (i0 + r < N && c < nb) ? A[(size_t)(i0 + r) * N + k + c] : 0.;
-        Pj[r][c] = (j0 + r < N && c < nb) ? A[(size_t)(j0 + r) * N + k + c] : 0.;
-    }
-    __syncthreads();
-    f64x4 acc[2][2] = {};
-    tile_mfma<MM_NT>(acc, Pi, Pj, (nb + 3) & ~3);
+    f64x4 old[2][2];
     TILE_FOR_EACH(u, v, r) {
         const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
-        if (i < N && j <= i) A[(size_t)i * N + j] -= acc[u][v][r];
+        old[u][v][r] = (i < N && j <= i) ? A[(size_t)i * N + j] : 0.;
+    }
+    f64x4 acc[2][2] = {};
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int r0 = 32 * (w >> 1) + li, c0 = 32 * (w & 1) + li;
+    for (int ks = 0; ks < nb; ks += KS) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * KS; e += 256) {
+            const int r = e / KS, c = e % KS;
+            Pi[r][c] = (i0 + r < N && ks + c < nb) ? A[(size_t)(i0 + r) * N + k + ks + c] : 0.;
+            Pj[r][c] = (j0 + r < N && ks + c < nb) ? A[(size_t)(j0 + r) * N + k + ks + c] : 0.;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += 4) {
+            const int kk = k0 + g;
+            double a[2], b[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) { a[u] = Pi[r0 + 16 * u][kk]; b[u] = Pj[c0 + 16 * u][kk]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int v = 0; v < 2; v++)
+                    acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+        }
+    }
+    TILE_FOR_EACH(u, v, r) {
+        const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
+        if (i < N && j <= i) A[(size_t)i * N + j] = old[u][v][r] - acc[u][v][r];
     }
 }
 

@@ -766,6 +766,12 @@ __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__
     const double *__restrict__ L = tabp(R, T_S_F, h);
     double *__restrict__ W = tabp(R, T_S_W, h);
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
+    // the tile being updated first: its loads fly while the operands are staged and multiplied
+    f64x4 old[2][2];
+    TILE_FOR_EACH(u, v, r) {
+        const int rr = i * 64 + tile_row(u, r), cc = j * 64 + tile_col(v);
+        old[u][v][r] = (j < k && rr < N && cc < N) ? W[(size_t)rr * N + cc] : 0.;
+    }
     tile_load(A, L, N, i * 64, k * 64);                                    // L_ik
     if (j == k) tile_load_dense(B, linv + (size_t)k * CH_NB * CH_NB);      // W_kk = Linv_kk
     else tile_load(B, W, N, k * 64, j * 64);                               // W_kj (final)
@@ -774,11 +780,7 @@ __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__
     tile_mfma<MM_NN>(acc, A, B, 64);
     __syncthreads();
     // out = (j < k ? W_ij : 0) - acc
-    TILE_FOR_EACH(u, v, r) {
-        const int rr = i * 64 + tile_row(u, r), cc = j * 64 + tile_col(v);
-        const double old = (j < k && rr < N && cc < N) ? W[(size_t)rr * N + cc] : 0.;
-        acc[u][v][r] = old - acc[u][v][r];
-    }
+    TILE_FOR_EACH(u, v, r) acc[u][v][r] = old[u][v][r] - acc[u][v][r];
     if (i == k + 1) {
         // row k + 1 becomes final: multiply by Linv_{k+1,k+1} from the left
         TILE_FOR_EACH(u, v, r) B[tile_row(u, r)][tile_col(v)] = acc[u][v][r];
