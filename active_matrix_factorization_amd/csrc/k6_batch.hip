@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *_
 
 // ---- factorisation jobs --------------------------------------------------------------------------
 // mode 2: certificate (W) + factor (F) per selected hypothesis; mode 1: factor only
-__global__ void kb_make_jobs(const Refs R, const int *__restrict__ sel, int nsel, int mode)
+__global__ void kb_make_jobs(const Refs R, const int *__restrict__ sel, int nsel, int mode, ChJob *__restrict__ jobs)
 {
     const int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= nsel) return;
@@ -266,11 +266,11 @@ __global__ void kb_make_jobs(const Refs R, const int *__restrict__ sel, int nsel
         w.linv = R.linvW + (size_t)h * blk;
         w.linv_keep = 0;
         R.info[2 * h] = 0;
-        R.jobs[2 * y] = w;
-        R.jobs[2 * y + 1] = f;
+        jobs[2 * y] = w;
+        jobs[2 * y + 1] = f;
     } else {
         R.info[2 * h] = 0;
-        R.jobs[y] = f;
+        jobs[y] = f;
     }
 }
 
@@ -982,6 +982,8 @@ int dp6_for(int d)
 } // namespace
 
 // ---- the batch object -------------------------------------------------------------------------------------
+constexpr int SEL_SLOTS = 5;       // 0 active, 1 gradient, 2 scratch (synchronous paths), 3 / 4 slow lane
+
 struct apmf_mn_batch {
     apmf_ctx *ctx;
     const apmf_ratings *r;
@@ -989,8 +991,13 @@ struct apmf_mn_batch {
     void *blocks[32];             // every device allocation, for destroy
     int nblocks;
     HypState *hs_host;            // pinned mirror
-    int *sel_host;                // pinned, 3 * H ints
-    int *sel_dev;                 // 3 * H ints
+    int *sel_host;                // pinned, SEL_SLOTS * H ints
+    int *sel_dev;                 // SEL_SLOTS * H ints
+    // the slow lane: eigen-projections of parked hypotheses run on a second stream, beside the fast
+    // path of the others
+    hipStream_t aux;
+    hipEvent_t ev_lane;
+    ChJob *jobs2;                 // [H] job list of the lane's re-factorisations
     std::vector<char> fvalid;     // F holds the factor of the current cov_useritems
     std::vector<char> fvalid_cand;
     std::vector<char> oivalid;    // OI_CUR holds the inverse of the current cov_latents
@@ -1068,14 +1075,15 @@ int launch_decide(apmf_mn_batch *b, const int *sel, int nsel, int mode, int forc
 size_t small_smem(int d) { return 2 * (size_t)d * (d + 1) * sizeof(double); }
 
 // factor the matrices already placed in F (and W when mode == 2) of the selected hypotheses
-int launch_factor(apmf_mn_batch *b, const int *sel, int nsel, int mode)
+int launch_factor(apmf_mn_batch *b, const int *sel, int nsel, int mode, ChJob *jobs = nullptr)
 {
     const Refs &R = b->R;
-    hipLaunchKernelGGL(kb_make_jobs, dim3((nsel + 63) / 64), dim3(64), 0, b->ctx->stream, R, sel, nsel, mode);
+    if (!jobs) jobs = R.jobs;
+    hipLaunchKernelGGL(kb_make_jobs, dim3((nsel + 63) / 64), dim3(64), 0, b->ctx->stream, R, sel, nsel, mode, jobs);
     APMF_CHECK_LAUNCH();
     ChJobs J;
     memset(&J, 0, sizeof(J));
-    J.list = R.jobs;
+    J.list = jobs;
     APMF_TRY(chol_lower_jobs(b->ctx, J, mode == 2 ? 2 * nsel : nsel, R.N));
     hipLaunchKernelGGL(kb_logdet, dim3(nsel), dim3(256), 0, b->ctx->stream, R, sel);
     APMF_CHECK_LAUNCH();
@@ -1094,28 +1102,32 @@ int write_ld(apmf_mn_batch *b, int h, const double *ld_s, const double *ld_o)
 // finish the projection / factorisation.  cov_useritems projections of all of them are batched;
 // what is rarer still (a d x d projection, a factorisation that fails on a projected matrix) goes
 // through the single-matrix routines of dense.hip, one hypothesis at a time.
-int slow_fix_all(apmf_mn_batch *b, const std::vector<int> &slow, bool trial, double min_eig)
+// S part, enqueued on the CURRENT stream of the context (the aux stream when called for the lane) with
+// no host synchronisation: eigen-projection of the hypotheses whose certificate failed, then the
+// factorisation of every listed hypothesis' (projected) matrix.  slot0 / slot0 + 1: selection-list
+// slots, jobs: job-list buffer - private to the caller's stream.
+int slow_S_enqueue(apmf_mn_batch *b, const std::vector<int> &list, const std::vector<int> &masks, bool trial,
+                   double min_eig, int slot0, ChJob *jobs)
 {
     const Refs &R = b->R;
-    const int H = R.H, N = R.N, d = R.d;
+    const int N = R.N;
     hipStream_t st = b->ctx->stream;
-    const int tS = trial ? T_S_CAND : T_S_CUR, tO = trial ? T_O_CAND : T_O_CUR, tOI = trial ? T_OI_CAND : T_OI_CUR;
+    const int tS = trial ? T_S_CAND : T_S_CUR;
     std::vector<int> proj, refac;
-    for (int h : slow) {
-        const int f = b->hs_host[h].slow;
-        if (f & SLOW_CERT_S) proj.push_back(h);
-        if (f & (SLOW_CERT_S | SLOW_FACT_S)) refac.push_back(h);
+    for (size_t q = 0; q < list.size(); q++) {
+        if (masks[q] & SLOW_CERT_S) proj.push_back(list[q]);
+        if (masks[q] & (SLOW_CERT_S | SLOW_FACT_S)) refac.push_back(list[q]);
     }
     const size_t nn = (size_t)N * N;
     if (!proj.empty()) {
         const int np = (int)proj.size();
         const int *dsel;
-        APMF_TRY(upload_sel(b, 2, proj, &dsel));
+        APMF_TRY(upload_sel(b, slot0, proj, &dsel));
         hipLaunchKernelGGL(kb_copy, g2(nn, np, 256), dim3(256), 0, st, R, dsel, (int)T_S_CAND, (int)T_S_W, nn);
         hipLaunchKernelGGL(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
         APMF_CHECK_LAUNCH();
         void *hv = nullptr;
-        APMF_TRY(apmf_dense_handle(b->ctx, &hv));
+        APMF_TRY(apmf_dense_handle(b->ctx, &hv));      // binds the handle to the current stream
         const rocblas_status rs = rocsolver_dsyevd_batched((rocblas_handle)hv, rocblas_evect_original,
                                                            rocblas_fill_lower, N, R.ptrs, N, R.evals, N, R.evE, N,
                                                            R.evinfo, np);
@@ -1125,26 +1137,49 @@ int slow_fix_all(apmf_mn_batch *b, const std::vector<int> &slow, bool trial, dou
         }
         hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, np), dim3(256), 0, st, R, dsel, min_eig);
         APMF_CHECK_LAUNCH();
+    }
+    if (!refac.empty()) {
+        const int nr = (int)refac.size();
+        const int *dsel;
+        APMF_TRY(upload_sel(b, slot0 + 1, refac, &dsel));
+        hipLaunchKernelGGL(kb_copy, g2(nn, nr, 256), dim3(256), 0, st, R, dsel, tS, (int)T_S_F, nn);
+        APMF_CHECK_LAUNCH();
+        APMF_TRY(launch_factor(b, dsel, nr, 1, jobs));
+    }
+    return APMF_OK;
+}
+
+// Host side of the same, once the enqueued work has completed: convergence of the eigensolver, LU
+// fallback for a factorisation that still fails, and the (rare) d x d parts through dense.hip.
+int slow_finish(apmf_mn_batch *b, const std::vector<int> &list, const std::vector<int> &masks, bool trial,
+                double min_eig)
+{
+    const Refs &R = b->R;
+    const int H = R.H, N = R.N, d = R.d;
+    const int tS = trial ? T_S_CAND : T_S_CUR, tO = trial ? T_O_CAND : T_O_CUR, tOI = trial ? T_OI_CAND : T_OI_CUR;
+    int np = 0;
+    bool any_refac = false, any_o = false;
+    for (size_t q = 0; q < list.size(); q++) {
+        if (masks[q] & SLOW_CERT_S) np++;
+        if (masks[q] & (SLOW_CERT_S | SLOW_FACT_S)) any_refac = true;
+        if (masks[q] & (SLOW_CERT_O | SLOW_INV_O)) any_o = true;
+    }
+    if (np) {
         std::vector<int> info(np);
         APMF_TRY(apmf_d2h(b->ctx, info.data(), R.evinfo, (size_t)np * sizeof(int)));
         for (int y = 0; y < np; y++)
             if (info[y] != 0) {
-                apmf_set_error("rocsolver_dsyevd_batched did not converge (hypothesis %d, info=%d)", proj[y], info[y]);
+                apmf_set_error("rocsolver_dsyevd_batched did not converge (slot %d, info=%d)", y, info[y]);
                 return APMF_EHIP;
             }
     }
-    if (!refac.empty()) {
-        // factor the (projected) matrices again
-        const int nr = (int)refac.size();
-        const int *dsel;
-        APMF_TRY(upload_sel(b, 2, refac, &dsel));
-        hipLaunchKernelGGL(kb_copy, g2(nn, nr, 256), dim3(256), 0, st, R, dsel, tS, (int)T_S_F, nn);
-        APMF_CHECK_LAUNCH();
-        APMF_TRY(launch_factor(b, dsel, nr, 1));
+    bool tables = false;
+    if (any_refac) {
         std::vector<int> info(2 * (size_t)H);
         APMF_TRY(apmf_d2h(b->ctx, info.data(), R.info, info.size() * sizeof(int)));
-        bool tables = false;
-        for (int h : refac) {
+        for (size_t q = 0; q < list.size(); q++) {
+            if (!(masks[q] & (SLOW_CERT_S | SLOW_FACT_S))) continue;
+            const int h = list[q];
             char &fv = trial ? b->fvalid_cand[h] : b->fvalid[h];
             fv = 1;
             if (info[2 * h + 1] != 0) {
@@ -1156,18 +1191,26 @@ int slow_fix_all(apmf_mn_batch *b, const std::vector<int> &slow, bool trial, dou
             }
         }
     }
-    bool tables = false;
-    for (int h : slow) {
-        const int f = b->hs_host[h].slow;
-        if (!(f & (SLOW_CERT_O | SLOW_INV_O))) continue;
-        if (!tables) { APMF_TRY(read_tables(b)); tables = true; }
-        double *O = b->tab_host[(size_t)tO * H + h], *OI = b->tab_host[(size_t)tOI * H + h];
-        if (f & SLOW_CERT_O) APMF_TRY(apmf_dense_project_psd(b->ctx, O, d, min_eig, nullptr));
-        double ld = 0.;
-        APMF_TRY(apmf_dense_inv_logdet(b->ctx, O, d, OI, &ld));
-        APMF_TRY(write_ld(b, h, nullptr, &ld));
-    }
+    if (any_o)
+        for (size_t q = 0; q < list.size(); q++) {
+            if (!(masks[q] & (SLOW_CERT_O | SLOW_INV_O))) continue;
+            const int h = list[q];
+            if (!tables) { APMF_TRY(read_tables(b)); tables = true; }
+            double *O = b->tab_host[(size_t)tO * H + h], *OI = b->tab_host[(size_t)tOI * H + h];
+            if (masks[q] & SLOW_CERT_O) APMF_TRY(apmf_dense_project_psd(b->ctx, O, d, min_eig, nullptr));
+            double ld = 0.;
+            APMF_TRY(apmf_dense_inv_logdet(b->ctx, O, d, OI, &ld));
+            APMF_TRY(write_ld(b, h, nullptr, &ld));
+        }
     return APMF_OK;
+}
+
+int slow_fix_all(apmf_mn_batch *b, const std::vector<int> &slow, bool trial, double min_eig)
+{
+    std::vector<int> masks;
+    for (int h : slow) masks.push_back(b->hs_host[h].slow);
+    APMF_TRY(slow_S_enqueue(b, slow, masks, trial, min_eig, 3, b->jobs2));
+    return slow_finish(b, slow, masks, trial, min_eig);
 }
 
 // after a batch of evaluations: deal with the hypotheses that left the fast path, then decide them
@@ -1179,9 +1222,10 @@ int handle_slow(apmf_mn_batch *b, const std::vector<int> &evaluated, bool trial,
         if (b->hs_host[h].status == ST_SLOW) slow.push_back(h);
     if (slow.empty()) return APMF_OK;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int h : slow)
-        for (int k = 0; k < 4; k++)
-            if (b->hs_host[h].slow & (1 << k)) b->st_slow[k]++;
+    if (!trial)
+        for (int h : slow)
+            for (int k = 0; k < 4; k++)
+                if (b->hs_host[h].slow & (1 << k)) b->st_slow[k]++;
     APMF_TRY(slow_fix_all(b, slow, trial, min_eig));
     const int *dsel;
     APMF_TRY(upload_sel(b, 2, slow, &dsel));
@@ -1250,6 +1294,8 @@ int apmf_mn_batch_destroy(apmf_ctx *ctx, apmf_mn_batch *b)
     (void)ctx;
     (void)hipStreamSynchronize(b->ctx->stream);
     for (int i = 0; i < b->nblocks; i++) (void)apmf_free(b->ctx, b->blocks[i]);
+    if (b->aux) { (void)hipStreamSynchronize(b->aux); (void)hipStreamDestroy(b->aux); }
+    if (b->ev_lane) (void)hipEventDestroy(b->ev_lane);
     if (b->hs_host) (void)hipHostFree(b->hs_host);
     if (b->sel_host) (void)hipHostFree(b->sel_host);
     delete b;
@@ -1271,6 +1317,9 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     b->nblocks = 0;
     b->hs_host = nullptr;
     b->sel_host = nullptr;
+    b->aux = nullptr;
+    b->ev_lane = nullptr;
+    b->jobs2 = nullptr;
     Refs &R = b->R;
     memset(&R, 0, sizeof(R));
     R.H = H; R.n = r->n; R.m = r->m; R.d = d; R.N = r->n + r->m;
@@ -1309,12 +1358,15 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     BA(R.ei, (size_t)H * sizeof(int));
     BA(R.ej, (size_t)H * sizeof(int));
     BA(R.ev, (size_t)H * sizeof(double));
-    BA(b->sel_dev, (size_t)3 * H * sizeof(int));
+    BA(b->sel_dev, (size_t)SEL_SLOTS * H * sizeof(int));
+    BA(b->jobs2, (size_t)H * sizeof(ChJob));
 #undef BA
     if (rc == APMF_OK && hipHostMalloc((void **)&b->hs_host, (size_t)H * sizeof(HypState), hipHostMallocDefault) != hipSuccess)
         rc = APMF_ENOMEM;
-    if (rc == APMF_OK && hipHostMalloc((void **)&b->sel_host, (size_t)3 * H * sizeof(int), hipHostMallocDefault) != hipSuccess)
+    if (rc == APMF_OK && hipHostMalloc((void **)&b->sel_host, (size_t)SEL_SLOTS * H * sizeof(int), hipHostMallocDefault) != hipSuccess)
         rc = APMF_ENOMEM;
+    if (rc == APMF_OK && hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking) != hipSuccess) rc = APMF_EHIP;
+    if (rc == APMF_OK && hipEventCreateWithFlags(&b->ev_lane, hipEventDisableTiming) != hipSuccess) rc = APMF_EHIP;
     if (rc != APMF_OK) {
         if (rc == APMF_ENOMEM) apmf_set_error("out of memory for a batch of %d hypotheses (N=%zu)", H, N);
         apmf_mn_batch_destroy(ctx, b);
@@ -1479,12 +1531,23 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     }
     if (max_steps == 0)
         for (int h = 0; h < H; h++) b->hs_host[h].status = ST_PAUSED;
-    // Hypotheses whose trial left the fast path (a projection that really clips eigenvalues) are
-    // PARKED: the others keep iterating, and the parked ones' eigendecompositions run as one
-    // batched call once enough of them have gathered (or nothing else is left to do).  The
-    // hypotheses are independent, so the order in which they advance changes nothing.
-    std::vector<int> active, grad, parked, decided;
+    // Hypotheses whose trial left the fast path (a projection that really clips eigenvalues; the
+    // trial matrix is then indefinite) are PARKED while the others keep iterating, and their
+    // eigendecompositions run as ONE batched call on a second stream - the slow lane - beside the fast
+    // path: when the lane is free it takes everything that is parked.  The hypotheses are
+    // independent, so the order in which they advance changes nothing.  APMF_BATCH_ASYNC=0: the
+    // parked hypotheses are dealt with on the main stream instead (debugging).
+    const bool use_lane = !(getenv("APMF_BATCH_ASYNC") && getenv("APMF_BATCH_ASYNC")[0] == '0');
+    std::vector<int> active, grad, parked, decided, lane, lane_masks, osync;
     std::vector<char> is_parked(H, 0);
+    bool lane_busy = false;
+    auto lane_wait = [&]() {
+        if (lane_busy) (void)hipEventSynchronize(b->ev_lane);
+    };
+    auto finish_decided = [&](const std::vector<int> &list) {
+        // F holds the factor of the trial point: the current one's only if the trial was accepted
+        for (int h : list) b->fvalid[h] = b->hs_host[h].accepted ? b->fvalid_cand[h] : 0;
+    };
     for (;;) {
         active.clear();
         grad.clear();
@@ -1493,13 +1556,43 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 active.push_back(h);
                 if (b->hs_host[h].need_grad) grad.push_back(h);
             }
-        if (active.empty() && parked.empty()) break;
+        if (lane_busy) {
+            bool done = hipEventQuery(b->ev_lane) == hipSuccess;
+            (void)hipGetLastError();             // hipErrorNotReady is not an error
+            if (!done && active.empty()) {
+                APMF_CHECK_HIP(hipEventSynchronize(b->ev_lane));
+                done = true;
+            }
+            if (done) {
+                const auto t0 = std::chrono::steady_clock::now();
+                APMF_CHECK_HIP(hipStreamWaitEvent(st, b->ev_lane, 0));
+                APMF_TRY(slow_finish(b, lane, lane_masks, true, min_eig));
+                const int *dsel;
+                APMF_TRY(upload_sel(b, 2, lane, &dsel));
+                APMF_TRY(launch_value(b, dsel, (int)lane.size(), T_M_CAND, T_S_CAND, T_O_CAND));
+                APMF_TRY(launch_decide(b, dsel, (int)lane.size(), 0, 1, sigma_sq, sigma_u_sq));
+                APMF_TRY(read_status(b));
+                finish_decided(lane);
+                for (int h : lane) is_parked[h] = 0;
+                lane.clear();
+                lane_busy = false;
+                b->st_slow_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                continue;                        // rebuild the active list with the returned hypotheses
+            }
+        }
+        if (active.empty() && parked.empty() && !lane_busy) break;
         decided.clear();
+        osync.clear();
         if (!active.empty()) {
             b->st_iters++;
             b->st_trials += (long)active.size();
             b->st_grads += (long)grad.size();
-            if (!grad.empty()) APMF_TRY(launch_gradient(b, grad, sigma_sq, sigma_u_sq, sigma_v_sq));
+            if (!grad.empty()) {
+                bool need_sync = false;
+                for (int h : grad) need_sync |= !b->fvalid[h];
+                if (need_sync) lane_wait();      // the LU route of such a gradient uses rocSOLVER too
+                APMF_TRY(launch_gradient(b, grad, sigma_sq, sigma_u_sq, sigma_v_sq));
+            }
             const int na = (int)active.size();
             const int *dsel;
             APMF_TRY(upload_sel(b, 0, active, &dsel));
@@ -1516,27 +1609,51 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             APMF_TRY(read_status(b));
             for (int h : active) {
                 b->fvalid_cand[h] = 1;
-                if (b->hs_host[h].status == ST_SLOW) {
+                if (b->hs_host[h].status != ST_SLOW) {
+                    decided.push_back(h);
+                    continue;
+                }
+                for (int k = 0; k < 4; k++)
+                    if (b->hs_host[h].slow & (1 << k)) b->st_slow[k]++;
+                if (b->hs_host[h].slow & (SLOW_CERT_S | SLOW_FACT_S)) {
                     parked.push_back(h);
                     is_parked[h] = 1;
                 } else {
-                    decided.push_back(h);
+                    osync.push_back(h);          // only the d x d part left the fast path: rare, synchronous
                 }
             }
         }
-        const size_t running = decided.size();      // hypotheses that stay on the fast path
-        const size_t want = std::min<size_t>(256, std::max<size_t>(1, running / 4));
-        if (!parked.empty() && (running == 0 || parked.size() >= want)) {
-            // hs_host still holds the parked hypotheses' slow masks: nothing has touched them since
-            APMF_TRY(handle_slow(b, parked, true, min_eig, sigma_sq, sigma_u_sq));
-            for (int h : parked) {
-                decided.push_back(h);
-                is_parked[h] = 0;
-            }
-            parked.clear();
+        if (!osync.empty()) {
+            lane_wait();
+            APMF_TRY(handle_slow(b, osync, true, min_eig, sigma_sq, sigma_u_sq));
+            for (int h : osync) decided.push_back(h);
         }
-        // F holds the factor of the trial point: the current one's only if the trial was accepted
-        for (int h : decided) b->fvalid[h] = b->hs_host[h].accepted ? b->fvalid_cand[h] : 0;
+        if (!parked.empty() && !lane_busy) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (use_lane) {
+                lane.swap(parked);
+                parked.clear();
+                lane_masks.clear();
+                for (int h : lane) lane_masks.push_back(b->hs_host[h].slow);
+                // the main stream is idle here (read_status synchronised it): the lane may start at once
+                hipStream_t saved = ctx->stream;
+                ctx->stream = b->aux;
+                int rc = slow_S_enqueue(b, lane, lane_masks, true, min_eig, 3, b->jobs2);
+                if (rc == APMF_OK && hipEventRecord(b->ev_lane, b->aux) != hipSuccess) rc = APMF_EHIP;
+                ctx->stream = saved;
+                if (rc != APMF_OK) return rc;
+                lane_busy = true;
+            } else {
+                APMF_TRY(handle_slow(b, parked, true, min_eig, sigma_sq, sigma_u_sq));
+                for (int h : parked) {
+                    decided.push_back(h);
+                    is_parked[h] = 0;
+                }
+                parked.clear();
+            }
+            b->st_slow_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        finish_decided(decided);
     }
     if (const char *e = getenv("APMF_BATCH_STATS"))
         if (e[0] == '1')
