@@ -293,6 +293,7 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
     def __getstate__(self):
         state = super(_ActiveBase, self).__getstate__()
         state['__dict__'] = self._extra_dict()
+        state['__dict__'].pop('lookahead_comm', None)       # a communicator is not model state
         return state
 
     rating_values = property(lambda self: self._rating_values)

@@ -311,7 +311,33 @@ class MNActivePMF(_ActiveBase):
         return self._first_in_pool_order(pi.to_host()[:count], pj.to_host()[:count])
 
     # ------------------------------------------------------------------ batched one-step lookahead
+    # Multi-GPU (BASELINE.json configs[3] "candidates sharded 8 x MI355X"): with a
+    # sharding.Comm of world > 1 attached (one process per GPU, every rank holding the same model)
+    # the hypotheses of a lookahead are dealt to the ranks in contiguous blocks and the values
+    # all-gathered - RCCL on device buffers when the Comm has a communicator.
+    lookahead_comm = None
+
     def _lookahead_batch(self, hyps, fn, pass_v):
+        comm = self.lookahead_comm
+        if comm is None or comm.world == 1 or len(hyps) < comm.world:
+            return self._lookahead_batch_local(hyps, fn, pass_v)
+        try:
+            from . import sharding
+        except ImportError:
+            import sharding
+        bs = sharding.block_size(len(hyps), comm.world)
+        lo, hi = sharding.block_range(len(hyps), comm.rank, comm.world)
+        mine = np.full(bs, np.nan)
+        if hi > lo:
+            mine[:hi - lo] = self._lookahead_batch_local(hyps[lo:hi], fn, pass_v)
+        ctx = self._device().ctx
+        if comm.ctx is ctx:
+            out = comm.all_gather_blocks(ctx.array(mine)).to_host()      # RCCL (or staged in a rehearsal)
+        else:
+            out = comm.all_gather_blocks(mine)
+        return out.reshape(-1)[:len(hyps)].tolist()
+
+    def _lookahead_batch_local(self, hyps, fn, pass_v):
         """fn(model refitted with R_ij = v) for every hypothesis (i, j, v), all fitted together
         on the device (mn_active_pmf.py:660-672 for the whole pool at once): the hypotheses are
         H approximations starting from this model's, each with one extra rating, advanced by one

@@ -81,3 +81,51 @@ def test_hip_engine_two_ranks_one_gpu():
     for p in procs:
         p.join(30)
     assert all(msg == 'ok' for _, msg in res), '\n'.join(str(x) for x in res)
+
+
+def _lookahead_worker(rank, world, port, q):
+    try:
+        import random
+        from active_matrix_factorization_amd import _lib, sharding as sh, mn_active_pmf as mn
+        from conftest import load_golden
+        g = load_golden('lookahead_c1_mn')
+        ctx = _lib.default_context()
+        comm = sh.Comm(rank, world, '127.0.0.1', port, ctx=ctx, rccl=False) if world > 1 else None
+        a = mn.MNActivePMF(g['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5), discrete_expectations=True)
+        a.users, a.items = g['users'].copy(), g['items'].copy()
+        a.mean, a.cov_useritems, a.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+        a.lookahead_comm = comm
+        pool = sorted(a.unrated)[:5]
+        vals = a._get_key_vals(pool, mn.KEY_FUNCS['total-variance'])
+        if comm is not None:
+            comm.barrier()
+            comm.close()
+        assert 'torch' not in sys.modules
+        q.put((rank, vals))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_lookahead_hypotheses_sharded_over_ranks():
+    """BASELINE.json configs[3] shards the lookahead's candidates over the GPUs: the hypotheses are
+    dealt to the ranks in blocks and the values all-gathered; two ranks (sharing the one GPU of the
+    test box, exchange staged through the host) return on every rank what one rank computes."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_lookahead_worker, args=(0, 1, 0, q))
+    p.start()
+    _, single = q.get(timeout=300)
+    p.join(30)
+    assert isinstance(single, list), single
+    port = _free_port()
+    procs = [ctx.Process(target=_lookahead_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(30)
+    for r in range(2):
+        assert isinstance(res[r], list), res[r]
+        assert res[r] == single
