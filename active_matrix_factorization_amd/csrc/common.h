@@ -60,6 +60,8 @@ struct apmf_ratings {
     int32_t *idx[2];   // (N) index on the other side
     double *val[2];    // (N)
     int32_t *order;    // (n+m) rows by descending nnz; entries >= n are item rows + n
+    void *desc;        // (n+m) RowDesc records in that order (k1_pmf.hip)
+    int max_len;       // longest row of either side
     int has_empty[2];  // some row on that side has no rating
     void *block;       // single allocation backing everything above
 };

@@ -34,8 +34,9 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v)
 {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    // every lane has a valid source under these controls, so no "old" value has to be set up
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
@@ -52,6 +53,15 @@ __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
+// fl(x + fl(lr * g)): the trial point with numpy's two roundings (`users + lr * grad_u`,
+// pmf_cy.pyx:271-272) - never contracted into one fma, and the same bits wherever it is formed
+__device__ __forceinline__ double trial_value(double x, double lr, double g)
+{
+#pragma clang fp contract(off)
+    const double step = lr * g;
+    return x + step;
+}
+
 template <int DP>
 __device__ __forceinline__ double cross_group_sum(double v)
 {
@@ -65,40 +75,45 @@ struct PmfParams {
     double sig;          // sigma_sq (divided by, like the reference: pmf_cy.pyx:220-221)
     double sig_u, sig_v; // prior variances
     double mean_add;     // mean_rating if subtract_mean else 0
+    double inv_sig;      // 1 / sig, exact when sig_pow2
+    int sig_pow2;        // sig is a normal power of two well inside the exponent range
 };
 
 // ---- fit_lls state kept on the device (apmf_pmf_fit_lls) -----------------------------------
-// One iteration of the search is two launches, enqueued back to back without host round trips:
-//   A: trial point fl(cur + fl(lr * grad)) into the other factor pair + its three LL sums;
-//   B: accept / reject (one block)  ||  gradient AT THE TRIAL POINT into the other gradient
-//      pair (speculative: it is the next step's gradient whenever the trial is accepted).
-// The state is double-buffered (B reads st[it & 1], its decide block writes st[(it+1) & 1]), so
-// the gradient blocks of B never see the state change under them.
+// One iteration of the search is ONE launch (k_fit_iter), enqueued back to back without host
+// round trips: it decides the previous launch's trial from that launch's partial sums, then
+// evaluates the next trial.  The state is double-buffered (launch `it` reads st[it & 1], its
+// block 0 writes st[(it + 1) & 1]), and so are the partial sums.
+constexpr int FIT_GRID_MAX = 1024;
+
 struct FitState {
     double lr, old_ll, min_lr, stop_thresh;
     long long steps, max_steps, max_trace;
     int cur;        // which factor buffer pair holds the current point (0: caller's arrays)
     int gsel;       // which gradient buffer pair holds the gradient at the current point
     int converged;
-    int pad;
+    int pending;    // a trial has been evaluated (its partials are in part[]) and not yet decided
 };
 
-__device__ __forceinline__ bool fit_done(const FitState *s)
-{
-    return s->converged || (s->max_steps >= 0 && s->steps >= s->max_steps);
-}
+// a row slot of the whole-model launches: rows in descending-nnz order
+struct RowDesc {
+    int32_t row_all;    // user row, or n + item row
+    int32_t len;        // its number of ratings
+    int64_t beg;        // first entry in the CSR of its side
+};
+static_assert(sizeof(RowDesc) == 16, "RowDesc is one 16-byte load");
 
 // One pass over (a share of) one CSR row.  The row's own vector is xk (lane k of every
-// group); for each rating the other side's row y is gathered - at the trial point
-// fl(Y + fl(lr * gY)) when TRIAL - and the prediction formed with a DP-lane reduce.
+// group); for each rating the other side's row y is gathered and the prediction formed with a
+// DP-lane reduce.
 //   GRAD : returns this wave's share of  sum_t y_t * (r_t - pred_t) / sigma^2   (lane k)
 //   !GRAD: returns this wave's share of  sum_t (r_t - pred_t)^2                 (lanes k == 0)
 // WPR waves share a row: wave `sub` takes ratings sub*G + g, + WPR*G, ...
-template <int DP, int WPR, bool TRIAL, bool GRAD>
+template <int DP, int WPR, bool GRAD>
 __device__ __forceinline__ double row_pass(const PmfParams &p, int lane, int sub, int64_t beg, int64_t end,
                                            const int32_t *__restrict__ idx,
                                            const double *__restrict__ val, double xk,
-                                           const double *Y, const double *gY, double lr)
+                                           const double *__restrict__ Y)
 {
     constexpr int G = 64 / DP;
     constexpr int STRIDE = WPR * G;
@@ -118,11 +133,7 @@ __device__ __forceinline__ double row_pass(const PmfParams &p, int lane, int sub
             r[u] = ok[u] ? val[t] : 0.;
         }
 #pragma unroll
-        for (int u = 0; u < UN; u++) {
-            const size_t oy = (size_t)c[u] * d + k;
-            if (TRIAL) y[u] = (ok[u] && kok) ? __dadd_rn(Y[oy], __dmul_rn(lr, gY[oy])) : 0.;
-            else y[u] = (ok[u] && kok) ? Y[oy] : 0.;
-        }
+        for (int u = 0; u < UN; u++) y[u] = (ok[u] && kok) ? Y[(size_t)c[u] * d + k] : 0.;
 #pragma unroll
         for (int u = 0; u < UN; u++) {
             const double pred = group_sum<DP>(xk * y[u]) + p.mean_add;
@@ -171,9 +182,8 @@ __device__ __forceinline__ void grad_block(const PmfParams &p, int block, int fi
         const int64_t *ptr = is_user ? ptr_u : ptr_v;
         const double *X = is_user ? U : V;
         xk = kok ? X[(size_t)row * d + k] : 0.;
-        acc = row_pass<DP, WPR, false, true>(p, lane, sub, ptr[row], ptr[row + 1],
-                                             is_user ? idx_u : idx_v, is_user ? val_u : val_v, xk,
-                                             is_user ? V : U, nullptr, 0.);
+        acc = row_pass<DP, WPR, true>(p, lane, sub, ptr[row], ptr[row + 1], is_user ? idx_u : idx_v,
+                                      is_user ? val_u : val_v, xk, is_user ? V : U);
         acc = cross_group_sum<DP>(acc);
     }
     if (WPR > 1) {
@@ -206,21 +216,15 @@ __global__ __launch_bounds__(256) void k_grad(const PmfParams p, int first_row, 
 
 // The three sums of log_likelihood() (pmf_cy.pyx:170-193) as per-wave partials: squared error
 // over the ratings of users [u_lo, u_hi) (each rating once) and the squared norms of the user
-// and item rows of the launched ranges.  TRIAL (fit_lls): the point is
-// fl(cur + fl(lr * grad)) (two roundings, like numpy's `users + lr * grad_u`,
-// pmf_cy.pyx:271-272), evaluated on the fly and written to the other buffer pair.
-template <int DP, int WPR, bool TRIAL>
-__global__ __launch_bounds__(256) void k_sqerr(const PmfParams p, const FitState *__restrict__ st, int u_lo,
-                                               int u_hi, int v_lo, int v_hi,
+// and item rows of the launched ranges.
+template <int DP, int WPR>
+__global__ __launch_bounds__(256) void k_sqerr(const PmfParams p, int u_lo, int u_hi, int v_lo, int v_hi,
                                                const int64_t *__restrict__ ptr_u,
                                                const int32_t *__restrict__ idx_u,
-                                               const double *__restrict__ val_u, double *U0, double *V0,
-                                               double *U1, double *V1, const double *gU0,
-                                               const double *gV0, const double *gU1, const double *gV1,
+                                               const double *__restrict__ val_u,
+                                               const double *__restrict__ U, const double *__restrict__ V,
                                                double *__restrict__ part /* (nslots * WPR, 3) */)
 {
-    if (TRIAL && fit_done(st)) return;
-    const double *gU = (TRIAL && st->gsel) ? gU1 : gU0, *gV = (TRIAL && st->gsel) ? gV1 : gV0;
     constexpr int RPB = 4 / WPR;
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
@@ -228,30 +232,18 @@ __global__ __launch_bounds__(256) void k_sqerr(const PmfParams p, const FitState
     const int sub = wave % WPR;
     const int nrows = max(u_hi - u_lo, v_hi - v_lo);
     if (slot >= nrows) return;
-    const double lr = TRIAL ? st->lr : 0.;
-    const bool cur1 = TRIAL && st->cur;
-    const double *U = cur1 ? U1 : U0, *V = cur1 ? V1 : V0;
-    double *tU = cur1 ? U0 : U1, *tV = cur1 ? V0 : V1;
     const int d = p.d;
     const int k = lane % DP, g = lane / DP;
     const bool kok = k < d;
     double sq = 0., un = 0., vn = 0.;
     if (u_lo + slot < u_hi) {
         const int urow = u_lo + slot;
-        const size_t o = (size_t)urow * d + k;
-        double xk = 0.;
-        if (kok) xk = TRIAL ? __dadd_rn(U[o], __dmul_rn(lr, gU[o])) : U[o];
-        if (sub == 0 && g == 0 && kok) {
-            if (TRIAL) tU[o] = xk;
-            un = xk * xk;
-        }
-        sq = row_pass<DP, WPR, TRIAL, false>(p, lane, sub, ptr_u[urow], ptr_u[urow + 1], idx_u, val_u, xk,
-                                             V, gV, lr);
+        const double xk = kok ? U[(size_t)urow * d + k] : 0.;
+        if (sub == 0 && g == 0 && kok) un = xk * xk;
+        sq = row_pass<DP, WPR, false>(p, lane, sub, ptr_u[urow], ptr_u[urow + 1], idx_u, val_u, xk, V);
     }
     if (sub == 0 && v_lo + slot < v_hi && g == 0 && kok) {
-        const size_t o = (size_t)(v_lo + slot) * d + k;
-        const double vk = TRIAL ? __dadd_rn(V[o], __dmul_rn(lr, gV[o])) : V[o];
-        if (TRIAL) tV[o] = vk;
+        const double vk = V[(size_t)(v_lo + slot) * d + k];
         vn = vk * vk;
     }
     sq = wave_sum(sq);
@@ -300,56 +292,332 @@ __global__ __launch_bounds__(256) void k_ll_finish(int nparts, const double *__r
     }
 }
 
-// launch B of a search iteration (see FitState): blocks [0, g_blocks) = gradient at the trial
-// point (factor pair 1 - cur) into gradient pair 1 - gsel; block g_blocks = accept / reject
-// exactly as pmf_cy.pyx:275-291, reading st_in and writing st_out.
-template <int DP, int WPR>
-__global__ __launch_bounds__(256) void k_fit_step(const PmfParams p, const FitState *__restrict__ st_in,
-                                                  FitState *__restrict__ st_out, int g_blocks,
-                                                  const int32_t *__restrict__ order,
-                                                  const int64_t *__restrict__ ptr_u,
+// ---- one search iteration in ONE launch ------------------------------------------------------
+// Every row (users then items, heaviest first) is visited once at the trial point
+// t = fl(cur + fl(lr * grad)), formed on the fly for the row itself and for every gathered row of
+// the other side.  The one pass yields both  sum (r - pred)^2  (user rows: each rating once) and
+// the gradient at t (speculative: it is the next step's gradient whenever the trial is accepted),
+// and leaves three partial sums per block.  The accept / reject decision on that trial is taken at
+// the START of the next launch, by every block for itself from the partials (a fixed-order sum, so
+// all agree): no atomics, no fences, no second launch.  (A last-block-done ticket was measured
+// first: 2625 device-scope atomics on one address serialise to 44 us per launch.)
+//
+// What bounds the launch is the chain of dependent loads, each a round trip of 0.7 us (L2) to
+// 2.5 us (data another XCD wrote in the previous launch): state -> partials -> [decision] ->
+// row -> ptr -> idx -> gather.  So everything that does not need the decision is requested
+// BEFORE it is known: the row descriptor (one 16-byte record per slot instead of order -> ptr),
+// the row's first entries, and the first trip's gathers from BOTH factor / gradient pairs - the
+// decision then only selects among values already in registers.
+template <int DP, int WPR, int UNT>
+__device__ __forceinline__ void trip_compute(const PmfParams &p, bool kok, int k, double xk, double lr,
+                                             const double (&y)[UNT], const double (&gy)[UNT],
+                                             const double (&r)[UNT], const bool (&ok)[UNT], double &acc_g,
+                                             double &acc_sq)
+{
+#pragma unroll
+    for (int u = 0; u < UNT; u++) {
+        const double yt = (ok[u] && kok) ? trial_value(y[u], lr, gy[u]) : 0.;
+        const double pred = group_sum<DP>(xk * yt) + p.mean_add;
+        const double e = ok[u] ? (r[u] - pred) : 0.;
+        // (r - pred) / sigma^2 like the reference; a power-of-two sigma^2 (the default 1)
+        // divides exactly by multiplying with its reciprocal
+        acc_g += yt * (p.sig_pow2 ? e * p.inv_sig : e / p.sig);
+        if (k == 0) acc_sq += e * e;
+    }
+}
+
+// entries t0 + u*STRIDE of a row; past the end they are read at the last entry and masked (a
+// predicated load is a branch around the instruction, and a trip of those is a chain of waits
+// instead of UNT loads in flight)
+template <int STRIDE, int UNT>
+__device__ __forceinline__ void load_entries(int64_t t0, int64_t end, const int32_t *__restrict__ idx,
+                                             const double *__restrict__ val, int32_t (&c)[UNT],
+                                             double (&r)[UNT], bool (&ok)[UNT])
+{
+#pragma unroll
+    for (int u = 0; u < UNT; u++) {
+        const int64_t t = t0 + (int64_t)u * STRIDE;
+        ok[u] = t < end;
+        const int64_t tc = ok[u] ? t : end - 1;
+        c[u] = idx[tc];
+        r[u] = val[tc];
+    }
+}
+
+// The rest of a row whose first trip's entries (c, r, ok) and gathers (y, gy) are in registers.
+template <int DP, int WPR, int UNT>
+__device__ __forceinline__ void row_pass_trial(const PmfParams &p, int lane, int sub, int64_t beg,
+                                               int64_t end, const int32_t *__restrict__ idx,
+                                               const double *__restrict__ val, double xk, const double *Y,
+                                               const double *gY, double lr, int32_t (&c)[UNT],
+                                               double (&r)[UNT], bool (&ok)[UNT], double (&y)[UNT],
+                                               double (&gy)[UNT], double &acc_g, double &acc_sq)
+{
+    constexpr int G = 64 / DP;
+    constexpr int STRIDE = WPR * G;
+    const int d = p.d;
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    const int kc = kok ? k : 0;
+    // wave-uniform trip count (the groups of a wave differ by at most one rating): every lane
+    // takes part in the DPP reductions of every trip
+    const int64_t span = end - (beg + sub * G);
+    int64_t t0 = beg + sub * G + g;
+    for (int64_t done = 0; done < span; done += (int64_t)STRIDE * UNT) {
+        // the next trip's entries are requested before this trip's gathers are consumed
+        int32_t cn[UNT];
+        double rn[UNT];
+        bool okn[UNT];
+        t0 += (int64_t)STRIDE * UNT;
+        load_entries<STRIDE, UNT>(t0, end, idx, val, cn, rn, okn);
+        trip_compute<DP, WPR, UNT>(p, kok, k, xk, lr, y, gy, r, ok, acc_g, acc_sq);
+        if (done + (int64_t)STRIDE * UNT < span) {
+#pragma unroll
+            for (int u = 0; u < UNT; u++) {
+                const size_t oy = (size_t)cn[u] * d + kc;
+                y[u] = Y[oy];
+                gy[u] = gY[oy];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNT; u++) {
+            c[u] = cn[u];
+            r[u] = rn[u];
+            ok[u] = okn[u];
+        }
+    }
+}
+
+#ifdef APMF_K1_TIMING
+__device__ unsigned long long g_k1_stamps[8 * 16384];
+#define K1_STAMP(i)                                                                         \
+    do {                                                                                    \
+        if ((threadIdx.x & 63) == 0) {                                                      \
+            const unsigned wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                      \
+            if (wid < 16384) g_k1_stamps[wid * 8 + (i)] = wall_clock64();                   \
+            if ((i) == 1 && wid < 16384) g_k1_stamps[wid * 8] = k1_t_start;                 \
+        }                                                                                   \
+    } while (0)
+#define K1_START() const unsigned long long k1_t_start = wall_clock64()
+#else
+#define K1_STAMP(i)
+#define K1_START()
+#endif
+
+// A block is RPB rows x WPR waves.
+template <int DP, int WPR, int RPB, int UNT>
+__global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, const FitState *__restrict__ st_in,
+                                                  FitState *__restrict__ st_out, int nparts_in,
+                                                  const double *__restrict__ part_in,
+                                                  double *__restrict__ part_out,
+                                                  const RowDesc *__restrict__ desc,
                                                   const int32_t *__restrict__ idx_u,
                                                   const double *__restrict__ val_u,
-                                                  const int64_t *__restrict__ ptr_v,
                                                   const int32_t *__restrict__ idx_v,
-                                                  const double *__restrict__ val_v, const double *U0,
-                                                  const double *V0, const double *U1, const double *V1,
-                                                  double *gU0, double *gV0, double *gU1, double *gV1,
-                                                  int nparts, const double *__restrict__ part, double sig,
+                                                  const double *__restrict__ val_v, double *U0, double *V0,
+                                                  double *U1, double *V1, double *gU0, double *gV0,
+                                                  double *gU1, double *gV1, double sig,
                                                   double *__restrict__ trace)
 {
-    __shared__ double sh_g[4][64];
-    __shared__ double sh_d[3][256];
-    const FitState s = *st_in;
+    constexpr int NW = RPB * WPR;
+    __shared__ double sh_g[NW][64];
+    __shared__ double sh_p[NW][3];
+    constexpr int G = 64 / DP;
+    constexpr int STRIDE = WPR * G;
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const int sub = wave % WPR;
+    const int d = p.d;
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    const int kc = kok ? k : 0;
+    const int nrows = p.n + p.m;
+    K1_START();
+
+    // ---- (0) requested before the decision is known ----------------------------------------
+    // partials of the previous launch (wave 0; zeros before the first trial)
+    double a0 = 0., a1 = 0., a2 = 0.;
+    if (wave == 0) {
+        // all loads of a chunk in flight together (a plain loop is one round trip per 64 partials)
+        constexpr int CH = 8;
+        for (int base = 0; base < nparts_in; base += 64 * CH) {
+            double v0[CH], v1[CH], v2[CH];
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                const int t = base + q * 64 + lane;
+                const int tc = t < nparts_in ? t : 0;
+                v0[q] = part_in[tc];
+                v1[q] = part_in[FIT_GRID_MAX + tc];
+                v2[q] = part_in[2 * FIT_GRID_MAX + tc];
+            }
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                const bool in = base + q * 64 + lane < nparts_in;
+                a0 += in ? v0[q] : 0.;
+                a1 += in ? v1[q] : 0.;
+                a2 += in ? v2[q] : 0.;
+            }
+        }
+    }
+    // this wave's first row: descriptor, first entries, own vector and first gathers from both
+    // buffer pairs
+    int slot = blockIdx.x * RPB + wave / WPR;
+    bool valid = slot < nrows;
+    RowDesc rd = desc[valid ? slot : 0];
+    int row_all = __builtin_amdgcn_readfirstlane(rd.row_all);
+    bool is_user = row_all < p.n;
+    int row = is_user ? row_all : row_all - p.n;
+    int64_t beg = ((int64_t)__builtin_amdgcn_readfirstlane((int)(rd.beg >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)rd.beg);
+    int64_t end = beg + __builtin_amdgcn_readfirstlane(rd.len);
+    bool has = valid && end - (beg + sub * G) > 0;      // wave-uniform
+    int32_t c[UNT];
+    double r[UNT], y[UNT], gy[UNT], y1[UNT], gy1[UNT];
+    bool ok[UNT];
+#pragma unroll
+    for (int u = 0; u < UNT; u++) { c[u] = 0; r[u] = 0.; ok[u] = false; y[u] = gy[u] = y1[u] = gy1[u] = 0.; }
+    double x0 = 0., x1 = 0., gx0 = 0., gx1 = 0.;
+    if (valid) {
+        const size_t o = (size_t)row * d + kc;
+        x0 = (is_user ? U0 : V0)[o];
+        x1 = (is_user ? U1 : V1)[o];
+        gx0 = (is_user ? gU0 : gV0)[o];
+        gx1 = (is_user ? gU1 : gV1)[o];
+    }
+    if (has) {
+        load_entries<STRIDE, UNT>(beg + sub * G + g, end, is_user ? idx_u : idx_v, is_user ? val_u : val_v, c, r,
+                                  ok);
+#pragma unroll
+        for (int u = 0; u < UNT; u++) {
+            const size_t oy = (size_t)c[u] * d + kc;
+            y[u] = (is_user ? V0 : U0)[oy];
+            y1[u] = (is_user ? V1 : U1)[oy];
+            gy[u] = (is_user ? gV0 : gU0)[oy];
+            gy1[u] = (is_user ? gV1 : gU1)[oy];
+        }
+    }
+
+    // ---- (1) the decision on the trial of the previous launch ---------------------------------
+    FitState s = *st_in;
+    if (s.pending) {          // block-uniform
+        if (wave == 0) {
+            a0 = wave_sum(a0);
+            a1 = wave_sum(a1);
+            a2 = wave_sum(a2);
+            if (lane == 0) { sh_p[0][0] = a0; sh_p[0][1] = a1; sh_p[0][2] = a2; }
+        }
+        __syncthreads();
+        const double b0 = sh_p[0][0], b1 = sh_p[0][1], b2 = sh_p[0][2];
+        __syncthreads();      // sh_p is reused for the partials of this launch
+        const double ll = -b0 / (2. * sig) - b1 / (2. * p.sig_u) - b2 / (2. * p.sig_v);
+        const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+        if (ll > s.old_ll) {      // pmf_cy.pyx:275-285
+            if (first && s.steps < s.max_trace) trace[s.steps] = ll;
+            if (ll - s.old_ll < s.stop_thresh) s.converged = 1;
+            s.cur ^= 1;
+            s.gsel ^= 1;
+            s.lr = s.lr * 1.25;
+            s.steps += 1;
+            s.old_ll = ll;
+        } else {                  // pmf_cy.pyx:286-291
+            s.lr = s.lr * .5;
+            if (s.lr < s.min_lr) s.converged = 1;
+        }
+    }
     const bool done = s.converged || (s.max_steps >= 0 && s.steps >= s.max_steps);
-    if ((int)blockIdx.x < g_blocks) {
-        if (done) return;
-        grad_block<DP, WPR>(p, blockIdx.x, 0, p.n + p.m, order, ptr_u, idx_u, val_u, ptr_v, idx_v, val_v,
-                            s.cur ? U0 : U1, s.cur ? V0 : V1, s.gsel ? gU0 : gU1, s.gsel ? gV0 : gV1, sh_g);
-        return;
+    s.pending = done ? 0 : 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *st_out = s;
+    if (done) return;
+    K1_STAMP(1);
+
+    // ---- (2) the next trial: LL partials and the gradient at the trial point -------------------
+    const double lr = s.lr;
+    const double *cU = s.cur ? U1 : U0, *cV = s.cur ? V1 : V0;       // current point
+    double *tU = s.cur ? U0 : U1, *tV = s.cur ? V0 : V1;             // trial point
+    const double *gU = s.gsel ? gU1 : gU0, *gV = s.gsel ? gV1 : gV0; // gradient at the current point
+    double *nU = s.gsel ? gU0 : gU1, *nV = s.gsel ? gV0 : gV1;       // gradient at the trial point
+    double xc = s.cur ? x1 : x0, gxc = s.gsel ? gx1 : gx0;
+#pragma unroll
+    for (int u = 0; u < UNT; u++) {
+        if (s.cur) y[u] = y1[u];
+        if (s.gsel) gy[u] = gy1[u];
     }
-    if (done) {
-        if (threadIdx.x == 0) *st_out = s;
-        return;
+    double sq = 0., un = 0., vn = 0.;
+    for (int base = blockIdx.x * RPB;;) {   // block-uniform trip count
+        double xk = 0., acc = 0., sq_row = 0.;
+        if (valid) {
+            const size_t o = (size_t)row * d + k;
+            if (kok) xk = trial_value(xc, lr, gxc);
+            if (sub == 0 && g == 0 && kok) {
+                (is_user ? tU : tV)[o] = xk;
+                if (is_user) un += xk * xk;
+                else vn += xk * xk;
+            }
+            K1_STAMP(2);
+            if (has)
+                row_pass_trial<DP, WPR, UNT>(p, lane, sub, beg, end, is_user ? idx_u : idx_v,
+                                             is_user ? val_u : val_v, xk, is_user ? cV : cU,
+                                             is_user ? gV : gU, lr, c, r, ok, y, gy, acc, sq_row);
+            K1_STAMP(3);
+            acc = cross_group_sum<DP>(acc);
+            if (is_user) sq += sq_row;
+        }
+        if (WPR > 1) {
+            sh_g[wave][lane] = acc;
+            __syncthreads();
+            if (valid && sub == 0)
+#pragma unroll
+                for (int w = 1; w < WPR; w++) acc += sh_g[wave + w][lane];
+        }
+        if (valid && sub == 0 && g == 0 && kok)
+            (is_user ? nU : nV)[(size_t)row * d + k] = -xk / (is_user ? p.sig_u : p.sig_v) + acc;
+        base += gridDim.x * RPB;
+        if (base >= nrows) break;
+        if (WPR > 1) __syncthreads();      // this trip's reads of sh_g are over
+        // the block's next row, the decision being known
+        slot = base + wave / WPR;
+        valid = slot < nrows;
+        rd = desc[valid ? slot : 0];
+        row_all = __builtin_amdgcn_readfirstlane(rd.row_all);
+        is_user = row_all < p.n;
+        row = is_user ? row_all : row_all - p.n;
+        beg = ((int64_t)__builtin_amdgcn_readfirstlane((int)(rd.beg >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)rd.beg);
+        end = beg + __builtin_amdgcn_readfirstlane(rd.len);
+        has = valid && end - (beg + sub * G) > 0;
+        if (valid) {
+            const size_t o = (size_t)row * d + kc;
+            xc = (is_user ? cU : cV)[o];
+            gxc = (is_user ? gU : gV)[o];
+        }
+        if (has) {
+            load_entries<STRIDE, UNT>(beg + sub * G + g, end, is_user ? idx_u : idx_v, is_user ? val_u : val_v, c,
+                                      r, ok);
+#pragma unroll
+            for (int u = 0; u < UNT; u++) {
+                const size_t oy = (size_t)c[u] * d + kc;
+                y[u] = (is_user ? cV : cU)[oy];
+                gy[u] = (is_user ? gV : gU)[oy];
+            }
+        }
     }
-    double sums[3];
-    combine_parts(nparts, part, sh_d, sums);
-    if (threadIdx.x != 0) return;
-    const double ll = -sums[0] / (2. * sig) - sums[1] / (2. * p.sig_u) - sums[2] / (2. * p.sig_v);
-    FitState o = s;
-    if (ll > s.old_ll) {
-        o.cur = s.cur ^ 1;
-        o.gsel = s.gsel ^ 1;
-        o.lr = s.lr * 1.25;
-        if (ll - s.old_ll < s.stop_thresh) o.converged = 1;
-        if (s.steps < s.max_trace) trace[s.steps] = ll;
-        o.steps = s.steps + 1;
-        o.old_ll = ll;
-    } else {
-        o.lr = s.lr * .5;
-        if (o.lr < s.min_lr) o.converged = 1;
+    sq = wave_sum(sq);
+    un = wave_sum(un);
+    vn = wave_sum(vn);
+    if (lane == 0) {
+        sh_p[wave][0] = sq;
+        sh_p[wave][1] = un;
+        sh_p[wave][2] = vn;
     }
-    *st_out = o;
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int q = threadIdx.x;
+        double tot = sh_p[0][q];
+#pragma unroll
+        for (int w = 1; w < NW; w++) tot += sh_p[w][q];
+        part_out[(size_t)q * FIT_GRID_MAX + blockIdx.x] = tot;
+    }
+    K1_STAMP(4);
 }
 
 // minibatch momentum update, pmf_cy.pyx:338-344:
@@ -459,6 +727,10 @@ PmfParams make_params(const apmf_ratings *r, int d, double sigma_sq, double sigm
     p.sig = sigma_sq;
     p.sig_u = sigma_u_sq; p.sig_v = sigma_v_sq;
     p.mean_add = subtract_mean ? mean_rating : 0.;
+    int ex = 0;
+    const double mant = frexp(sigma_sq, &ex);
+    p.sig_pow2 = (mant == 0.5 && ex > -500 && ex < 500) ? 1 : 0;
+    p.inv_sig = 1. / sigma_sq;
     return p;
 }
 
@@ -517,12 +789,8 @@ int launch_ll(apmf_ctx *ctx, const apmf_ratings *r, const PmfParams &p, double s
     const int blocks = (nslots + (4 / wpr) - 1) / (4 / wpr);
     APMF_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)nslots * wpr * 24, ctx->stream));
     DISPATCH_DP_WPR(dp_for(p.d), wpr,
-                    hipLaunchKernelGGL((k_sqerr<DP, WPR, false>), dim3(blocks), dim3(256), 0, ctx->stream, p,
-                                       (const FitState *)nullptr, u_lo, u_hi, v_lo, v_hi, r->ptr[0],
-                                       r->idx[0], r->val[0], const_cast<double *>(U),
-                                       const_cast<double *>(V), (double *)nullptr, (double *)nullptr,
-                                       (const double *)nullptr, (const double *)nullptr,
-                                       (const double *)nullptr, (const double *)nullptr, d_part));
+                    hipLaunchKernelGGL((k_sqerr<DP, WPR>), dim3(blocks), dim3(256), 0, ctx->stream, p, u_lo,
+                                       u_hi, v_lo, v_hi, r->ptr[0], r->idx[0], r->val[0], U, V, d_part));
     APMF_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ll_finish, dim3(1), dim3(256), 0, ctx->stream, nslots * wpr, d_part, sigma_sq,
                        p.sig_u, p.sig_v, d_out4);
@@ -582,6 +850,24 @@ __global__ __launch_bounds__(64) void k_dense_fill(int n, int m, const double *_
     }
 }
 
+// the row slots of the whole-model launches (k_fit_iter): descending-nnz order, one record each
+int upload_desc(apmf_ctx *ctx, apmf_ratings *r, const std::vector<int32_t> &order,
+                const std::vector<int64_t> &ptr0, const std::vector<int64_t> &ptr1)
+{
+    std::vector<RowDesc> desc(order.size());
+    for (size_t t = 0; t < order.size(); t++) {
+        const int ra = order[t];
+        const std::vector<int64_t> &ptr = ra < r->n ? ptr0 : ptr1;
+        const int row = ra < r->n ? ra : ra - r->n;
+        desc[t].row_all = ra;
+        desc[t].beg = ptr[row];
+        desc[t].len = (int32_t)(ptr[row + 1] - ptr[row]);
+        r->max_len = std::max(r->max_len, desc[t].len);
+    }
+    if (desc.empty()) return APMF_OK;
+    return apmf_h2d(ctx, r->desc, desc.data(), desc.size() * sizeof(RowDesc));
+}
+
 } // namespace
 
 extern "C" {
@@ -637,7 +923,8 @@ int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_ptr0 = al((size_t)(n + 1) * 8), b_ptr1 = al((size_t)(m + 1) * 8);
     const size_t b_idx = al((size_t)N * 4 + 4), b_val = al((size_t)N * 8 + 8), b_ord = al((size_t)(n + m) * 4);
-    const size_t total = b_ptr0 + b_ptr1 + 2 * b_idx + 2 * b_val + b_ord;
+    const size_t b_desc = al((size_t)(n + m) * sizeof(RowDesc));
+    const size_t total = b_ptr0 + b_ptr1 + 2 * b_idx + 2 * b_val + b_ord + b_desc;
     APMF_CHECK_HIP(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(&r->block, total);
     if (e != hipSuccess) {
@@ -652,7 +939,8 @@ int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n
     r->idx[1] = (int32_t *)base; base += b_idx;
     r->val[0] = (double *)base; base += b_val;
     r->val[1] = (double *)base; base += b_val;
-    r->order = (int32_t *)base;
+    r->order = (int32_t *)base; base += b_ord;
+    r->desc = base;
     int rc = APMF_OK;
     for (int s = 0; s < 2 && rc == APMF_OK; s++) {
         rc = apmf_h2d(ctx, r->ptr[s], ptr[s].data(), ptr[s].size() * 8);
@@ -660,6 +948,7 @@ int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n
         if (rc == APMF_OK && N) rc = apmf_h2d(ctx, r->val[s], val[s].data(), (size_t)N * 8);
     }
     if (rc == APMF_OK) rc = apmf_h2d(ctx, r->order, order.data(), order.size() * 4);
+    if (rc == APMF_OK) rc = upload_desc(ctx, r, order, ptr[0], ptr[1]);
     if (rc != APMF_OK) { (void)hipFree(r->block); delete r; return rc; }
     *out = r;
     return APMF_OK;
@@ -698,7 +987,8 @@ int apmf_ratings_create_dense(apmf_ctx *ctx, const double *d_real, int ld_real, 
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_ptr0 = al((size_t)(n + 1) * 8), b_ptr1 = al((size_t)(m + 1) * 8);
     const size_t b_idx = al((size_t)N * 4 + 4), b_val = al((size_t)N * 8 + 8), b_ord = al((size_t)(n + m) * 4);
-    const size_t total = b_ptr0 + b_ptr1 + 2 * b_idx + 2 * b_val + b_ord;
+    const size_t b_desc = al((size_t)(n + m) * sizeof(RowDesc));
+    const size_t total = b_ptr0 + b_ptr1 + 2 * b_idx + 2 * b_val + b_ord + b_desc;
     APMF_CHECK_HIP(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(&r->block, total);
     if (e != hipSuccess) {
@@ -713,10 +1003,12 @@ int apmf_ratings_create_dense(apmf_ctx *ctx, const double *d_real, int ld_real, 
     r->idx[1] = (int32_t *)base; base += b_idx;
     r->val[0] = (double *)base; base += b_val;
     r->val[1] = (double *)base; base += b_val;
-    r->order = (int32_t *)base;
+    r->order = (int32_t *)base; base += b_ord;
+    r->desc = base;
     rc = apmf_h2d(ctx, r->ptr[0], ptr0.data(), ptr0.size() * 8);
     if (rc == APMF_OK) rc = apmf_h2d(ctx, r->ptr[1], ptr1.data(), ptr1.size() * 8);
     if (rc == APMF_OK) rc = apmf_h2d(ctx, r->order, order.data(), order.size() * 4);
+    if (rc == APMF_OK) rc = upload_desc(ctx, r, order, ptr0, ptr1);
     if (rc == APMF_OK && N > 0) {
         hipLaunchKernelGGL((k_dense_fill<0>), dim3(n), dim3(64), 0, ctx->stream, n, m, d_real, ld_real, d_known,
                            ld_known, r->ptr[0], r->idx[0], r->val[0]);
@@ -819,6 +1111,13 @@ int apmf_pmf_ll_terms(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, c
     return APMF_OK;
 }
 
+#ifdef APMF_K1_TIMING
+int apmf_k1_stamps(unsigned long long *h_out)
+{
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_k1_stamps), sizeof(unsigned long long) * 8 * 16384) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *d_V, int d,
                      double sigma_sq, double sigma_u_sq, double sigma_v_sq, int subtract_mean,
                      double mean_rating, double *h_lr, double *h_old_ll,
@@ -838,10 +1137,11 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     // outputs, the two states
     void *w0, *w1;
     APMF_TRY(apmf_ws(ctx, 0, (3 * (nu + nv) + (size_t)trace_cap) * 8 + 64, &w0));
-    APMF_TRY(apmf_ws(ctx, 1, (size_t)nparts * 24 + 128 + 2 * sizeof(FitState) + 64, &w1));
+    const size_t npart_alloc = std::max<size_t>(nparts, 2 * (size_t)FIT_GRID_MAX);
+    APMF_TRY(apmf_ws(ctx, 1, npart_alloc * 24 + 128 + 2 * sizeof(FitState) + 64, &w1));
     double *gU0 = (double *)w0, *gV0 = gU0 + nu, *gU1 = gV0 + nv, *gV1 = gU1 + nu, *tU = gV1 + nv,
            *tV = tU + nu, *d_trace = tV + nv;
-    double *d_part = (double *)w1, *d_out2 = d_part + (size_t)nparts * 3;
+    double *d_part = (double *)w1, *d_out2 = d_part + npart_alloc * 3;
     FitState *d_state = (FitState *)(d_out2 + 8);   // d_state[0], d_state[1]
     void *pin;
     APMF_TRY(apmf_pinned(ctx, 256, &pin));
@@ -864,12 +1164,21 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     h_state->max_steps = max_steps;
     h_state->max_trace = trace_cap;
     APMF_CHECK_HIP(hipMemcpyAsync(d_state, h_state, sizeof(FitState), hipMemcpyHostToDevice, ctx->stream));
+    APMF_CHECK_HIP(hipMemsetAsync(d_part, 0, 2 * (size_t)FIT_GRID_MAX * 24, ctx->stream));
     APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // the pinned block is reused for read-backs
 
     if (max_steps != 0) APMF_TRY(launch_grad(ctx, r, p, d_U, d_V, gU0, gV0));   // gradient at the start
-    const int t_blocks = (nslots + (4 / wpr) - 1) / (4 / wpr);
-    const int g_blocks = (r->n + r->m + (4 / wpr) - 1) / (4 / wpr);
+    // a fixed grid (the partial sums, hence the LL bits, must not depend on the device): two
+    // blocks per CU of a 256-CU part, each striding over the row slots
+    // Block shape: a wave per row (4 rows per block) unless some row is long - the launch lasts as
+    // long as its heaviest row, about 0.4 us per 8 ratings of one wave - then 4 waves per row.
+    const int fit_wpr = getenv("APMF_K1_WPR") ? atoi(getenv("APMF_K1_WPR")) : 0;
+    const int fwpr = (fit_wpr == 1 || fit_wpr == 4) ? fit_wpr : (r->max_len > 192 ? 4 : 1);
+    const int frpb = 4 / fwpr;
+    // a fixed grid cap (the partial sums, hence the LL bits, must not depend on the device)
+    const int g_blocks = std::min((r->n + r->m + frpb - 1) / frpb, FIT_GRID_MAX);
     const int dp = dp_for(d);
+    const RowDesc *desc = (const RowDesc *)r->desc;
     long long it = 0;
     for (;;) {
         if (max_steps == 0) break;
@@ -877,17 +1186,15 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
         const int chunk = (int)std::min<long long>(std::max<long long>(remaining + 1, 2), 16);
         for (int c = 0; c < chunk; c++, it++) {
             FitState *s_in = d_state + (it & 1), *s_out = d_state + ((it + 1) & 1);
-            DISPATCH_DP_WPR(dp, wpr,
-                            hipLaunchKernelGGL((k_sqerr<DP, WPR, true>), dim3(t_blocks), dim3(256), 0,
-                                               ctx->stream, p, s_in, 0, r->n, 0, r->m, r->ptr[0], r->idx[0],
-                                               r->val[0], d_U, d_V, tU, tV, gU0, gV0, gU1, gV1, d_part));
+            double *p_in = d_part + (size_t)(it & 1) * FIT_GRID_MAX * 3, *p_out = d_part + (size_t)((it + 1) & 1) * FIT_GRID_MAX * 3;
             ProfScope prof(ctx);
-            DISPATCH_DP_WPR(dp, wpr,
-                            hipLaunchKernelGGL((k_fit_step<DP, WPR>), dim3(g_blocks + 1), dim3(256), 0,
-                                               ctx->stream, p, s_in, s_out, g_blocks, r->order, r->ptr[0],
-                                               r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1], d_U,
-                                               d_V, tU, tV, gU0, gV0, gU1, gV1, nparts, d_part, sigma_sq,
-                                               d_trace));
+#define FIT_ITER(WPR_, RPB_)                                                                             \
+    DISPATCH_DP(dp, hipLaunchKernelGGL((k_fit_iter<DP, WPR_, RPB_, 2>), dim3(g_blocks), dim3(256), 0,    \
+                                       ctx->stream, p, s_in, s_out, g_blocks, p_in, p_out, desc, r->idx[0], \
+                                       r->val[0], r->idx[1], r->val[1], d_U, d_V, tU, tV, gU0, gV0, gU1, gV1, \
+                                       sigma_sq, d_trace))
+            if (fwpr == 4) { FIT_ITER(4, 1); } else { FIT_ITER(1, 4); }
+#undef FIT_ITER
         }
         APMF_CHECK_LAUNCH();
         APMF_CHECK_HIP(hipMemcpyAsync(h_state, d_state + (it & 1), sizeof(FitState), hipMemcpyDeviceToHost,

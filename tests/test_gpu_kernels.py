@@ -114,6 +114,44 @@ def test_pmf_fit_lls_golden(ctx, name):
     np.testing.assert_allclose(dV.to_host(), g['V_fit'], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize('shape', ['skewed', 'many_rows', 'uniform_wpr4'])
+def test_pmf_fit_lls_block_shapes(ctx, shape, monkeypatch):
+    """The one-launch search iteration against the oracle on the layouts its two block shapes meet:
+    a few very long rows next to empty ones (4 waves per row), more rows than the grid cap covers
+    in one trip (the blocks stride), and the 4-waves-per-row shape forced on short rows."""
+    rs = np.random.RandomState(11)
+    if shape == 'skewed':
+        n, m, d = 40, 700, 5
+        pairs = {(0, j) for j in range(650)} | {(1, j) for j in range(0, 700, 2)}
+        pairs |= {(int(i), int(j)) for i, j in zip(rs.randint(2, n - 3, 300), rs.randint(0, m - 10, 300))}
+    elif shape == 'many_rows':
+        n, m, d = 3000, 2500, 3
+        pairs = {(int(i), int(j)) for i, j in zip(rs.randint(0, n, 9000), rs.randint(0, m, 9000))}
+    else:
+        n, m, d = 60, 45, 10
+        pairs = {(int(i), int(j)) for i, j in zip(rs.randint(0, n, 900), rs.randint(0, m, 900))}
+        monkeypatch.setenv('APMF_K1_WPR', '4')
+    pairs = np.array(sorted(pairs))
+    ratings = np.column_stack([pairs, rs.randint(1, 6, len(pairs))]).astype(float)
+    U0, V0 = rs.normal(size=(n, d)), rs.normal(size=(m, d))
+    kw = dict(sig=.7, sig_u=10., sig_v=5., subtract_mean=True, mean_rating=float(ratings[:, 2].mean()))
+    steps = 25
+    Uo, Vo, tro = orc.pmf_fit_lls(ratings, U0, V0, lr=1e-4, max_steps=steps, **kw)
+    rt = ctx.ratings(ratings, n, m)
+    dU, dV = ctx.array(U0), ctx.array(V0)
+    trace, nst, lr, conv = ctx.pmf_fit_lls(rt, dU, dV, d, kw['sig'], kw['sig_u'], kw['sig_v'], True,
+                                           kw['mean_rating'], 1e-4, 1e-10, 1e-2, max_steps=steps)
+    assert nst == len(tro)
+    np.testing.assert_allclose(trace, tro, rtol=1e-11)
+    np.testing.assert_allclose(dU.to_host(), Uo, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(dV.to_host(), Vo, rtol=1e-9, atol=1e-11)
+    # bit-reproducible run to run
+    dU2, dV2 = ctx.array(U0), ctx.array(V0)
+    trace2, *_ = ctx.pmf_fit_lls(rt, dU2, dV2, d, kw['sig'], kw['sig_u'], kw['sig_v'], True,
+                                 kw['mean_rating'], 1e-4, 1e-10, 1e-2, max_steps=steps)
+    assert np.array_equal(trace, trace2) and np.array_equal(dU.to_host(), dU2.to_host())
+
+
 def test_pmf_fit_lls_resume(ctx):
     """max_steps + returned lr let a caller drive the generator step by step (fit_lls yields)."""
     g = load_golden('pmf_50x40_d3')
