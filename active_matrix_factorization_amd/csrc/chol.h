@@ -95,53 +95,167 @@ __device__ __forceinline__ int tile_col(int v) { return 32 * ((int)(threadIdx.x 
     _Pragma("unroll") for (int v = 0; v < 2; v++)                \
     _Pragma("unroll") for (int r = 0; r < 4; r++)
 
-// Diagonal block k..k+nb, one wave, everything in registers: lane t holds row t of the block
-// (64 doubles) and other lanes' entries arrive by v_readlane: 55 us per block.  The LDS
-// formulations were slower: one wave walking its rows serially 113 us (dependent LDS round
-// trips; rocSOLVER's potf2_kernel_small is of this kind, 135 us), four waves sharing the
-// trailing update 87 us (320 block barriers).  Writes L_kk in place and L_kk^-1 (64 x 64,
-// row-major, zero above the diagonal) to the job's linv slot for the panel solve.  A short
-// last block is padded with the identity.  *info = k + j + 1 at the first non-positive pivot.
-__global__ __launch_bounds__(64) void k_chol_diag(const ChJobs J, int N, int k)
+// The thread's share of an R x C tile (elements e = tid + 256 q, row-major) of a row-major matrix,
+// ALL requested before any is used: rows / columns past row_end / col_end are read at the last
+// valid one (the caller masks them).  Written as `T[i][j] = ok ? src[..] : fill` in a loop, every
+// element is a branch around its load and a wait before its LDS store - a chain of R * C / 256
+// round trips, which was most of the run time of the kernels below at one matrix per launch.
+template <int R, int C>
+struct TileRegs {
+    static constexpr int PER = R * C / 256;
+    double v[PER];
+    __device__ __forceinline__ void load(const double *src, size_t ld, int row0, int col0, int row_end, int col_end)
+    {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int e = (int)threadIdx.x + 256 * q;
+            const int i = min(row0 + e / C, row_end - 1), j = min(col0 + e % C, col_end - 1);
+            v[q] = src[(size_t)i * ld + j];
+        }
+    }
+    static __device__ __forceinline__ int row(int q) { return ((int)threadIdx.x + 256 * q) / C; }
+    static __device__ __forceinline__ int col(int q) { return ((int)threadIdx.x + 256 * q) % C; }
+};
+
+// 16 x 16 x 16 sub-block products on one wave, operands in LDS tiles of pitch TP, result in the
+// instruction's C layout (column = lane & 15, row = (lane >> 4) + 4 * register).
+//   NT: C[i][j] += A[ra + i][ka + k] B[rb + j][kb + k]      NN: C[i][j] += A[ra + i][ka + k] B[rb + k][cb + j]
+__device__ __forceinline__ f64x4 sub_nt(const double (*A)[TP], int ra, int ka, const double (*B)[TP], int rb, int kb,
+                                        f64x4 acc)
+{
+    const int li = threadIdx.x & 15, g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ra + li][ka + k0 + g], B[rb + li][kb + k0 + g], acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ f64x4 sub_nn(const double (*A)[TP], int ra, int ka, const double (*B)[TP], int rb, int cb,
+                                        f64x4 acc)
+{
+    const int li = threadIdx.x & 15, g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ra + li][ka + k0 + g], B[rb + k0 + g][cb + li], acc, 0, 0, 0);
+    return acc;
+}
+
+// Diagonal block k..k+nb: one workgroup of 4 waves, the block in LDS.  Four panels of 16 columns:
+// wave 0 holds the panel with one ROW per lane (16 registers) and runs the right-looking
+// elimination on it - the pivots and multipliers of other lanes arrive by v_readlane, and the rows
+// below the 16 x 16 diagonal sub-block are scaled along, so the panel comes out factored AND solved
+// (120 readlane-fma steps instead of the 2016 of a 64-column sweep) - then the four waves update
+// the trailing sub-blocks on the matrix cores.  L_kk^-1 for the panel solve of the big matrix: the
+// four 16 x 16 diagonal inverses one per wave (column per lane), then wave b builds block column b
+// below its diagonal block from products.  13 us per block; the formulations before it: one
+// wave with the whole 64 x 64 block in registers 61 us, one wave walking its rows serially
+// through LDS 113 us (rocSOLVER's potf2_kernel_small is of this kind, 135 us), four waves sharing
+// a 64-column trailing update 87 us (320 block barriers).  Writes L_kk in place and L_kk^-1
+// (64 x 64, row-major, zero above the diagonal) to the job's linv slot.  A short last block is
+// padded with the identity.  *info = k + j + 1 at the first non-positive pivot.
+__global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
 {
     const ChJob job = ch_job(J, blockIdx.y);
     double *__restrict__ A = job.A;
     int *__restrict__ info = job.info;
     double *__restrict__ linv = ch_linv(job, k);
-    const int t = threadIdx.x;
+    __shared__ double T[CH_NB][TP], X[CH_NB][TP];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
     const int nb = min(CH_NB, N - k);
-    if (*info != 0) return;          // an earlier panel already failed
-    double r[CH_NB];
+    if (*info != 0) return;          // an earlier panel already failed (block-uniform)
+    {
+        TileRegs<CH_NB, CH_NB> t;
+        t.load(A, N, k, k, N, N);
 #pragma unroll
-    for (int c = 0; c < CH_NB; c++)
-        r[c] = (t < nb && c <= t) ? A[(size_t)(k + t) * N + k + c] : (c == t ? 1. : 0.);
-    // right-looking factorisation; entries above the diagonal hold don't-care values
-#pragma unroll
-    for (int j = 0; j < CH_NB; j++) {
-        const double pj = lane_value(r[j], j);
-        if (!(pj > 0.)) {            // wave-uniform
-            if (t == 0) *info = k + j + 1;
-            return;
+        for (int q = 0; q < t.PER; q++) {
+            const int i = t.row(q), j = t.col(q);
+            T[i][j] = (i < nb && j <= i) ? t.v[q] : (i == j ? 1. : 0.);
+            X[i][j] = 0.;
         }
-        const double rj = sqrt(pj);
-        r[j] = t == j ? rj : r[j] / rj;
-#pragma unroll
-        for (int c = j + 1; c < CH_NB; c++) r[c] -= r[j] * lane_value(r[j], c);
     }
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
 #pragma unroll
-    for (int c = 0; c < CH_NB; c++)
-        if (t < nb && c <= t) A[(size_t)(k + t) * N + k + c] = r[c];
-    // X = L^-1: lane c owns column c, X[i][c] = (delta_ic - sum_{m=c}^{i-1} L[i][m] X[m][c]) / L[i][i]
-    double x[CH_NB];
+    for (int kb = 0; kb < 4; kb++) {
+        constexpr int SB = 16;
+        const int c0 = SB * kb;
+        if (w == 0) {
+            double r[SB];
 #pragma unroll
-    for (int i = 0; i < CH_NB; i++) {
-        double v = i == t ? 1. : 0.;
+            for (int c = 0; c < SB; c++) r[c] = T[lane][c0 + c];
+            int fail = 0;
 #pragma unroll
-        for (int m = 0; m < i; m++) v -= lane_value(r[m], i) * x[m];   // x[m] = 0 for m < c
-        x[i] = i < t ? 0. : v / lane_value(r[i], i);
+            for (int j = 0; j < SB; j++) {
+                const double pj = lane_value(r[j], c0 + j);
+                if (!fail && !(pj > 0.)) fail = c0 + j + 1;      // wave-uniform
+                const double rj = sqrt(pj);
+                r[j] = lane == c0 + j ? rj : r[j] / rj;
+#pragma unroll
+                for (int c = j + 1; c < SB; c++) r[c] -= r[j] * lane_value(r[j], c0 + c);
+            }
+            if (lane >= c0)
+#pragma unroll
+                for (int c = 0; c < SB; c++) T[lane][c0 + c] = r[c];
+            if (fail && lane == 0) s_fail = fail;
+        }
+        __syncthreads();
+        if (s_fail) break;               // block-uniform
+        // trailing sub-blocks (i, j), kb < j <= i < 4:  T_ij -= P_i P_j'
+        const int nrem = 3 - kb;
+        for (int bq = w; bq < nrem * (nrem + 1) / 2; bq += 4) {
+            int bi = 0, bj = bq;
+            while (bj > bi) { bj -= bi + 1; bi++; }     // bq -> (bi >= bj) within the remaining triangle
+            const int i0 = SB * (kb + 1 + bi), j0 = SB * (kb + 1 + bj);
+            f64x4 acc = {0., 0., 0., 0.};
+            acc = sub_nt(T, i0, c0, T, j0, c0, acc);
+#pragma unroll
+            for (int q = 0; q < 4; q++) T[i0 + g + 4 * q][j0 + li] -= acc[q];
+        }
+        __syncthreads();
     }
+    if (s_fail) {
+        if (tid == 0) *info = k + s_fail;
+        return;
+    }
+    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+        const int i = e / CH_NB, j = e % CH_NB;
+        if (i < nb && j <= i) A[(size_t)(k + i) * N + k + j] = T[i][j];
+    }
+    // X = L^-1.  Diagonal sub-block w: lane c < 16 owns column c,
+    // X[i][c] = (delta_ic - sum_{m=c}^{i-1} L[i][m] X[m][c]) / L[i][i]; lane i holds row i of L_ww
+    {
+        constexpr int SB = 16;
+        const int b0 = SB * w;
+        double r[SB], x[SB];
 #pragma unroll
-    for (int i = 0; i < CH_NB; i++) linv[i * CH_NB + t] = x[i];
+        for (int c = 0; c < SB; c++) r[c] = T[b0 + li][b0 + c];
+#pragma unroll
+        for (int i = 0; i < SB; i++) {
+            double v = i == lane ? 1. : 0.;
+#pragma unroll
+            for (int m = 0; m < i; m++) v -= lane_value(r[m], i) * x[m];    // x[m] = 0 for m < c
+            x[i] = i < lane ? 0. : v / lane_value(r[i], i);
+        }
+        if (lane < SB)
+#pragma unroll
+            for (int i = 0; i < SB; i++) X[b0 + i][b0 + lane] = x[i];
+    }
+    __syncthreads();
+    // block column w below its diagonal block: X_iw = -X_ii (sum_{m=w}^{i-1} L_im X_mw), top down
+    for (int bi = w + 1; bi < 4; bi++) {
+        f64x4 sacc = {0., 0., 0., 0.};
+        for (int bm = w; bm < bi; bm++) sacc = sub_nn(T, 16 * bi, 16 * bm, X, 16 * bm, 16 * w, sacc);
+#pragma unroll
+        for (int q = 0; q < 4; q++) X[16 * bi + g + 4 * q][16 * w + li] = sacc[q];      // S, in place of X_iw
+        f64x4 xacc = {0., 0., 0., 0.};
+        xacc = sub_nn(X, 16 * bi, 16 * bi, X, 16 * bi, 16 * w, xacc);
+#pragma unroll
+        for (int q = 0; q < 4; q++) X[16 * bi + g + 4 * q][16 * w + li] = -xacc[q];
+    }
+    __syncthreads();
+    for (int e = tid; e < CH_NB * CH_NB; e += 256) linv[e] = X[e / CH_NB][e % CH_NB];
 }
 
 // rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T = (rows) x (L_kk^-1)': a 64 x 64 x 64 product
@@ -152,15 +266,20 @@ __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k
     double *__restrict__ A = job.A;
     const double *__restrict__ linv = ch_linv(job, k);
     __shared__ double P[CH_NB][TP], X[CH_NB][TP];
-    const int tid = threadIdx.x;
     const int nb = min(CH_NB, N - k);
     if (*job.info != 0) return;
     const int r0 = k + nb + blockIdx.x * 64;
     const int rows = min(64, N - r0);
-    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-        const int i = e / CH_NB, j = e % CH_NB;
-        X[i][j] = linv[e];
-        P[i][j] = (i < rows && j < nb) ? A[(size_t)(r0 + i) * N + k + j] : 0.;
+    {
+        TileRegs<CH_NB, CH_NB> x, t;
+        x.load(linv, CH_NB, 0, 0, CH_NB, CH_NB);
+        t.load(A, N, r0, k, N, N);
+#pragma unroll
+        for (int q = 0; q < t.PER; q++) {
+            const int i = t.row(q), j = t.col(q);
+            X[i][j] = x.v[q];
+            P[i][j] = (i < rows && j < nb) ? t.v[q] : 0.;
+        }
     }
     __syncthreads();
     f64x4 acc[2][2] = {};
@@ -196,21 +315,31 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
     int ti, tj;
     tri_tile((int)blockIdx.x, ti, tj);
     const int i0 = base + ti * 64, j0 = base + tj * 64;
+    // everything the block reads is requested up front: the tile being updated and the first
+    // half-panels; the second half-panels while the first are multiplied
     f64x4 old[2][2];
     TILE_FOR_EACH(u, v, r) {
-        const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
-        old[u][v][r] = (i < N && j <= i) ? A[(size_t)i * N + j] : 0.;
+        const int i = min(i0 + tile_row(u, r), N - 1), j = min(j0 + tile_col(v), N - 1);
+        old[u][v][r] = A[(size_t)i * N + j];
     }
+    TileRegs<64, KS> pi, pj;
+    pi.load(A, N, i0, k, N, N);
+    pj.load(A, N, j0, k, N, N);
     f64x4 acc[2][2] = {};
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
     const int r0 = 32 * (w >> 1) + li, c0 = 32 * (w & 1) + li;
     for (int ks = 0; ks < nb; ks += KS) {
         __syncthreads();
-        for (int e = threadIdx.x; e < 64 * KS; e += 256) {
-            const int r = e / KS, c = e % KS;
-            Pi[r][c] = (i0 + r < N && ks + c < nb) ? A[(size_t)(i0 + r) * N + k + ks + c] : 0.;
-            Pj[r][c] = (j0 + r < N && ks + c < nb) ? A[(size_t)(j0 + r) * N + k + ks + c] : 0.;
+#pragma unroll
+        for (int q = 0; q < pi.PER; q++) {
+            const int r = pi.row(q), c = pi.col(q);
+            Pi[r][c] = (i0 + r < N && ks + c < nb) ? pi.v[q] : 0.;
+            Pj[r][c] = (j0 + r < N && ks + c < nb) ? pj.v[q] : 0.;
+        }
+        if (ks + KS < nb) {
+            pi.load(A, N, i0, k + ks + KS, N, N);
+            pj.load(A, N, j0, k + ks + KS, N, N);
         }
         __syncthreads();
 #pragma unroll
@@ -241,7 +370,7 @@ static inline int chol_lower_jobs(apmf_ctx *ctx, const ChJobs &J, int njobs, int
     if (njobs <= 0) return APMF_OK;
     for (int k = 0; k < N; k += CH_NB) {
         const int nb = N - k < CH_NB ? N - k : CH_NB;
-        hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(64), 0, ctx->stream, J, N, k);
+        hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, ctx->stream, J, N, k);
         const int rest = N - k - nb;
         if (rest > 0) {
             hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, ctx->stream, J, N, k);

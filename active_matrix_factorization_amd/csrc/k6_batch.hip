@@ -744,17 +744,25 @@ __global__ void kb_decide(const Refs R, const int *__restrict__ sel, int nsel, i
 // j <= k):   W_ij <- W_ij - L_ik W_kj   (W_ij = 0 when j = k, W_kk = Linv_kk),
 // and the tiles of row k + 1 are multiplied by Linv_{k+1,k+1} on the way out, so that row k + 1
 // is final when launch k + 1 reads it.  Diagonal tiles of W are never stored: they are Linv_kk.
-__device__ __forceinline__ void tile_load(double (*T)[TP], const double *__restrict__ A, int N, int r0, int c0)
+// a 64 x 64 operand tile: a window of a row-major matrix (zero beyond its edge), or a dense Linv
+struct TileSrc {
+    const double *p;
+    int ld, r0, c0, re, ce;
+};
+__device__ __forceinline__ TileSrc src_mat(const double *A, int N, int r0, int c0) { return {A, N, r0, c0, N, N}; }
+__device__ __forceinline__ TileSrc src_dense(const double *B) { return {B, CH_NB, 0, 0, CH_NB, CH_NB}; }
+// requested (all 16 elements of the thread in flight) ... and, later, placed in LDS
+__device__ __forceinline__ void tile_request(TileRegs<64, 64> &t, const TileSrc &s)
 {
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-        const int r = e >> 6, c = e & 63;
-        T[r][c] = (r0 + r < N && c0 + c < N) ? A[(size_t)(r0 + r) * N + c0 + c] : 0.;
-    }
+    t.load(s.p, s.ld, s.r0, s.c0, s.re, s.ce);
 }
-
-__device__ __forceinline__ void tile_load_dense(double (*T)[TP], const double *__restrict__ B)
+__device__ __forceinline__ void tile_place(const TileRegs<64, 64> &t, const TileSrc &s, double (*T)[TP])
 {
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) T[e >> 6][e & 63] = B[e];
+#pragma unroll
+    for (int q = 0; q < t.PER; q++) {
+        const int r = t.row(q), c = t.col(q);
+        T[r][c] = (s.r0 + r < s.re && s.c0 + c < s.ce) ? t.v[q] : 0.;
+    }
 }
 
 __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__restrict__ sel, int k)
@@ -766,25 +774,35 @@ __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__
     const double *__restrict__ L = tabp(R, T_S_F, h);
     double *__restrict__ W = tabp(R, T_S_W, h);
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
-    // the tile being updated first: its loads fly while the operands are staged and multiplied
+    // everything the block reads is requested before any of it is used
+    const TileSrc sa = src_mat(L, N, i * 64, k * 64);                                     // L_ik
+    const TileSrc sb = j == k ? src_dense(linv + (size_t)k * CH_NB * CH_NB)               // W_kk = Linv_kk
+                              : src_mat(W, N, k * 64, j * 64);                            // W_kj (final)
+    const TileSrc sc = src_dense(linv + (size_t)(k + 1) * CH_NB * CH_NB);
+    TileRegs<64, 64> ta, tb, tc;
+    tile_request(ta, sa);
+    tile_request(tb, sb);
     f64x4 old[2][2];
     TILE_FOR_EACH(u, v, r) {
-        const int rr = i * 64 + tile_row(u, r), cc = j * 64 + tile_col(v);
-        old[u][v][r] = (j < k && rr < N && cc < N) ? W[(size_t)rr * N + cc] : 0.;
+        const int rr = min(i * 64 + tile_row(u, r), N - 1), cc = min(j * 64 + tile_col(v), N - 1);
+        old[u][v][r] = W[(size_t)rr * N + cc];
     }
-    tile_load(A, L, N, i * 64, k * 64);                                    // L_ik
-    if (j == k) tile_load_dense(B, linv + (size_t)k * CH_NB * CH_NB);      // W_kk = Linv_kk
-    else tile_load(B, W, N, k * 64, j * 64);                               // W_kj (final)
+    if (i == k + 1) tile_request(tc, sc);
+    tile_place(ta, sa, A);
+    tile_place(tb, sb, B);
     __syncthreads();
     f64x4 acc[2][2] = {};
     tile_mfma<MM_NN>(acc, A, B, 64);
     __syncthreads();
     // out = (j < k ? W_ij : 0) - acc
-    TILE_FOR_EACH(u, v, r) acc[u][v][r] = old[u][v][r] - acc[u][v][r];
+    TILE_FOR_EACH(u, v, r) {
+        const int rr = i * 64 + tile_row(u, r), cc = j * 64 + tile_col(v);
+        acc[u][v][r] = ((j < k && rr < N && cc < N) ? old[u][v][r] : 0.) - acc[u][v][r];
+    }
     if (i == k + 1) {
         // row k + 1 becomes final: multiply by Linv_{k+1,k+1} from the left
         TILE_FOR_EACH(u, v, r) B[tile_row(u, r)][tile_col(v)] = acc[u][v][r];
-        tile_load_dense(A, linv + (size_t)(k + 1) * CH_NB * CH_NB);
+        tile_place(tc, sc, A);
         __syncthreads();
         TILE_FOR_EACH(u, v, r) acc[u][v][r] = 0.;
         tile_mfma<MM_NN>(acc, A, B, 64);
@@ -808,12 +826,20 @@ __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restr
     double *__restrict__ G = tabp(R, T_S_GRAD, h);
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
     f64x4 acc[2][2] = {};
+    auto src_a = [&](int k) { return k == ti ? src_dense(linv + (size_t)k * CH_NB * CH_NB) : src_mat(W, N, k * 64, ti * 64); };
+    auto src_b = [&](int k) { return k == tj ? src_dense(linv + (size_t)k * CH_NB * CH_NB) : src_mat(W, N, k * 64, tj * 64); };
+    // the operands of step k + 1 are requested while step k is multiplied
+    TileRegs<64, 64> ta, tb;
+    tile_request(ta, src_a(ti));
+    tile_request(tb, src_b(ti));
     for (int k = ti; k < nb; k++) {
         __syncthreads();
-        if (k == ti) tile_load_dense(A, linv + (size_t)k * CH_NB * CH_NB);
-        else tile_load(A, W, N, k * 64, ti * 64);
-        if (k == tj) tile_load_dense(B, linv + (size_t)k * CH_NB * CH_NB);
-        else tile_load(B, W, N, k * 64, tj * 64);
+        tile_place(ta, src_a(k), A);
+        tile_place(tb, src_b(k), B);
+        if (k + 1 < nb) {
+            tile_request(ta, src_a(k + 1));
+            tile_request(tb, src_b(k + 1));
+        }
         __syncthreads();
         tile_mfma<MM_TN>(acc, A, B, 64);
     }
