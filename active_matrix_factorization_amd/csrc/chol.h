@@ -18,6 +18,7 @@
 #include "common.h"
 
 constexpr int CH_NB = 64;
+constexpr int CH_FUSE_JOBS = 32;   // up to this many matrices per launch: update + next diagonal block in one launch
 
 namespace {   // one private copy of the kernels per translation unit that includes this header
 
@@ -153,30 +154,12 @@ __device__ __forceinline__ f64x4 sub_nn(const double (*A)[TP], int ra, int ka, c
 // a 64-column trailing update 87 us (320 block barriers).  Writes L_kk in place and L_kk^-1
 // (64 x 64, row-major, zero above the diagonal) to the job's linv slot.  A short last block is
 // padded with the identity.  *info = k + j + 1 at the first non-positive pivot.
-__global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
+// the block (identity-padded, in T) -> L in T and L^-1 in X (zeroed by the caller); returns 0 or
+// 1 + the index of the first non-positive pivot (block-uniform).  256 threads.
+__device__ __forceinline__ int diag_factor_invert(double (*T)[TP], double (*X)[TP], int *s_fail)
 {
-    const ChJob job = ch_job(J, blockIdx.y);
-    double *__restrict__ A = job.A;
-    int *__restrict__ info = job.info;
-    double *__restrict__ linv = ch_linv(job, k);
-    __shared__ double T[CH_NB][TP], X[CH_NB][TP];
-    __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, g = lane >> 4;
-    const int nb = min(CH_NB, N - k);
-    if (*info != 0) return;          // an earlier panel already failed (block-uniform)
-    {
-        TileRegs<CH_NB, CH_NB> t;
-        t.load(A, N, k, k, N, N);
-#pragma unroll
-        for (int q = 0; q < t.PER; q++) {
-            const int i = t.row(q), j = t.col(q);
-            T[i][j] = (i < nb && j <= i) ? t.v[q] : (i == j ? 1. : 0.);
-            X[i][j] = 0.;
-        }
-    }
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
 #pragma unroll
     for (int kb = 0; kb < 4; kb++) {
         constexpr int SB = 16;
@@ -198,10 +181,10 @@ __global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
             if (lane >= c0)
 #pragma unroll
                 for (int c = 0; c < SB; c++) T[lane][c0 + c] = r[c];
-            if (fail && lane == 0) s_fail = fail;
+            if (fail && lane == 0) *s_fail = fail;
         }
         __syncthreads();
-        if (s_fail) break;               // block-uniform
+        if (*s_fail) break;               // block-uniform
         // trailing sub-blocks (i, j), kb < j <= i < 4:  T_ij -= P_i P_j'
         const int nrem = 3 - kb;
         for (int bq = w; bq < nrem * (nrem + 1) / 2; bq += 4) {
@@ -215,14 +198,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
         }
         __syncthreads();
     }
-    if (s_fail) {
-        if (tid == 0) *info = k + s_fail;
-        return;
-    }
-    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
-        const int i = e / CH_NB, j = e % CH_NB;
-        if (i < nb && j <= i) A[(size_t)(k + i) * N + k + j] = T[i][j];
-    }
+    if (*s_fail) return *s_fail;
     // X = L^-1.  Diagonal sub-block w: lane c < 16 owns column c,
     // X[i][c] = (delta_ic - sum_{m=c}^{i-1} L[i][m] X[m][c]) / L[i][i]; lane i holds row i of L_ww
     {
@@ -255,7 +231,40 @@ __global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
         for (int q = 0; q < 4; q++) X[16 * bi + g + 4 * q][16 * w + li] = -xacc[q];
     }
     __syncthreads();
-    for (int e = tid; e < CH_NB * CH_NB; e += 256) linv[e] = X[e / CH_NB][e % CH_NB];
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
+{
+    const ChJob job = ch_job(J, blockIdx.y);
+    double *__restrict__ A = job.A;
+    int *__restrict__ info = job.info;
+    double *__restrict__ linv = ch_linv(job, k);
+    __shared__ double T[CH_NB][TP], X[CH_NB][TP];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int nb = min(CH_NB, N - k);
+    TileRegs<CH_NB, CH_NB> t;
+    t.load(A, N, k, k, N, N);
+    if (*info != 0) return;          // an earlier panel already failed (block-uniform)
+#pragma unroll
+    for (int q = 0; q < t.PER; q++) {
+        const int i = t.row(q), j = t.col(q);
+        T[i][j] = (i < nb && j <= i) ? t.v[q] : (i == j ? 1. : 0.);
+        X[i][j] = 0.;
+    }
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    const int fail = diag_factor_invert(T, X, &s_fail);
+    if (fail) {
+        if (tid == 0) *info = k + fail;
+        return;
+    }
+    for (int e = tid; e < CH_NB * CH_NB; e += 256) {
+        const int i = e / CH_NB, j = e % CH_NB;
+        if (i < nb && j <= i) A[(size_t)(k + i) * N + k + j] = T[i][j];
+        linv[e] = X[i][j];
+    }
 }
 
 // rows r >= k + nb: A[r][k..k+nb) <- A[r][k..k+nb) L_kk^-T = (rows) x (L_kk^-1)': a 64 x 64 x 64 product
@@ -300,7 +309,11 @@ __device__ __forceinline__ void tri_tile(int b, int &ti, int &tj)
 }
 
 // trailing update: for i >= j >= k + nb:  A[i][j] -= sum_t P[i][t] P[j][t],  P = A[:, k..k+nb)
-// one 64 x 64 tile per block (tiles on or below the diagonal), on the matrix cores
+// one 64 x 64 tile per block (tiles on or below the diagonal), on the matrix cores.
+// NEXT (few matrices per launch, where the chain of launches is what costs): the block of tile (0, 0)
+// - the next diagonal block, which nobody else touches - goes straight on to factor and invert it, so
+// the next panel solve can follow without a launch of k_chol_diag in between.
+template <bool NEXT>
 __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int k)
 {
     const ChJob job = ch_job(J, blockIdx.y);
@@ -308,8 +321,11 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
     // the panel is staged 32 columns at a time: 35 KB of LDS per block -> 4 blocks (16 waves) per CU
     // instead of 2; this kernel is latency-bound (PMC: ~1.7 TB/s of HBM traffic), occupancy is what helps
     constexpr int KS = 32, KP = KS + 2;
-    __shared__ double Pi[64][KP], Pj[64][KP];
-    if (*job.info != 0) return;
+    extern __shared__ double dyn_lds[];          // NEXT: T and X of the diagonal block (the staging tiles alias them)
+    __shared__ double stat_lds[NEXT ? 1 : 2 * 64 * KP];
+    double (*Pi)[KP] = (double (*)[KP])(NEXT ? dyn_lds : stat_lds);
+    double (*Pj)[KP] = Pi + 64;
+    __shared__ int s_fail;
     const int nb = min(CH_NB, N - k);
     const int base = k + nb;
     int ti, tj;
@@ -325,6 +341,7 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
     TileRegs<64, KS> pi, pj;
     pi.load(A, N, i0, k, N, N);
     pj.load(A, N, j0, k, N, N);
+    if (*job.info != 0) return;
     f64x4 acc[2][2] = {};
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int li = lane & 15, g = lane >> 4;
@@ -355,9 +372,35 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
                     acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
         }
     }
+    if (!NEXT || blockIdx.x != 0) {
+        TILE_FOR_EACH(u, v, r) {
+            const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
+            if (i < N && j <= i) A[(size_t)i * N + j] = old[u][v][r] - acc[u][v][r];
+        }
+        return;
+    }
+    // tile (0, 0): the next diagonal block, factored and inverted here
+    double (*T)[TP] = (double (*)[TP])dyn_lds;
+    double (*X)[TP] = T + CH_NB;
+    const int nbn = min(CH_NB, N - base);
+    __syncthreads();                 // the staging tiles (aliases of T / X) have been read
+    for (int e = threadIdx.x; e < CH_NB * CH_NB; e += 256) X[e / CH_NB][e % CH_NB] = 0.;
     TILE_FOR_EACH(u, v, r) {
-        const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
-        if (i < N && j <= i) A[(size_t)i * N + j] = old[u][v][r] - acc[u][v][r];
+        const int i = tile_row(u, r), j = tile_col(v);
+        T[i][j] = (i < nbn && j <= i) ? old[u][v][r] - acc[u][v][r] : (i == j ? 1. : 0.);
+    }
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    const int fail = diag_factor_invert(T, X, &s_fail);
+    if (fail) {
+        if (threadIdx.x == 0) *job.info = base + fail;
+        return;
+    }
+    double *__restrict__ linv = ch_linv(job, base);
+    for (int e = threadIdx.x; e < CH_NB * CH_NB; e += 256) {
+        const int i = e / CH_NB, j = e % CH_NB;
+        if (i < nbn && j <= i) A[(size_t)(base + i) * N + base + j] = T[i][j];
+        linv[e] = X[i][j];
     }
 }
 
@@ -368,15 +411,31 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
 static inline int chol_lower_jobs(apmf_ctx *ctx, const ChJobs &J, int njobs, int N)
 {
     if (njobs <= 0) return APMF_OK;
+    // few matrices: the chain of launches is what costs, so each update launch also factors the next
+    // diagonal block; many: the block in a launch of its own (and 4 update blocks per CU)
+    const bool next = njobs <= CH_FUSE_JOBS;
+    constexpr size_t next_lds = 2 * (size_t)CH_NB * TP * sizeof(double);
+    if (next) {
+        static bool attr_set = false;       // per translation unit; setting it again is harmless
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)k_chol_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)next_lds);
+            attr_set = true;
+        }
+    }
     for (int k = 0; k < N; k += CH_NB) {
         const int nb = N - k < CH_NB ? N - k : CH_NB;
-        hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, ctx->stream, J, N, k);
+        if (k == 0 || !next) hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, ctx->stream, J, N, k);
         const int rest = N - k - nb;
         if (rest > 0) {
             hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, ctx->stream, J, N, k);
             const int tiles = (rest + 63) / 64;
-            hipLaunchKernelGGL(k_chol_update, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), 0, ctx->stream, J,
-                               N, k);
+            if (next)
+                hipLaunchKernelGGL(k_chol_update<true>, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), next_lds,
+                                   ctx->stream, J, N, k);
+            else
+                hipLaunchKernelGGL(k_chol_update<false>, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), 0,
+                                   ctx->stream, J, N, k);
         }
     }
     APMF_CHECK_LAUNCH();

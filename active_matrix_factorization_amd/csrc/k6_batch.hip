@@ -227,10 +227,15 @@ __global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__res
     }
 }
 
-// mean and cov_latents parts of the trial point (cov_latents symmetrised like project_psd does)
-__global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *__restrict__ sel)
+__device__ __forceinline__ void make_jobs_one(const Refs &R, int y, int h, int mode, ChJob *__restrict__ jobs);
+
+// mean and cov_latents parts of the trial point (cov_latents symmetrised like project_psd does);
+// jobs != nullptr: also the hypothesis' pair of factorisation jobs (certificate + factor)
+__global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *__restrict__ sel,
+                                                      ChJob *__restrict__ jobs)
 {
     const int h = sel[blockIdx.y];
+    if (jobs && blockIdx.x == 0 && threadIdx.x == 0) make_jobs_one(R, (int)blockIdx.y, h, 2, jobs);
     const double lr = R.hs[h].lr;
     const size_t nm = (size_t)R.N * R.d, dd = (size_t)R.d * R.d;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -247,11 +252,8 @@ __global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *_
 
 // ---- factorisation jobs --------------------------------------------------------------------------
 // mode 2: certificate (W) + factor (F) per selected hypothesis; mode 1: factor only
-__global__ void kb_make_jobs(const Refs R, const int *__restrict__ sel, int nsel, int mode, ChJob *__restrict__ jobs)
+__device__ __forceinline__ void make_jobs_one(const Refs &R, int y, int h, int mode, ChJob *__restrict__ jobs)
 {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= nsel) return;
-    const int h = sel[y];
     const size_t blk = (size_t)CH_NB * CH_NB;
     ChJob f;
     f.A = tabp(R, T_S_F, h);
@@ -274,32 +276,43 @@ __global__ void kb_make_jobs(const Refs R, const int *__restrict__ sel, int nsel
     }
 }
 
-// hs[h].ld_s = 2 sum log F[i][i]
-__global__ __launch_bounds__(256) void kb_logdet(const Refs R, const int *__restrict__ sel)
+__global__ void kb_make_jobs(const Refs R, const int *__restrict__ sel, int nsel, int mode, ChJob *__restrict__ jobs)
 {
-    const int h = sel[blockIdx.x];
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y < nsel) make_jobs_one(R, y, sel[y], mode, jobs);
+}
+
+// hs[h].ld_s = 2 sum log F[i][i]   (one wave; the diagonal requested 8 entries per lane at a time)
+__device__ __forceinline__ void logdet_body(const Refs &R, int h)
+{
     const double *__restrict__ L = tabp(R, T_S_F, h);
-    const int N = R.N;
-    __shared__ double sh[256];
+    const int N = R.N, lane = threadIdx.x & 63;
     double s = 0;
-    for (int i = threadIdx.x; i < N; i += 256) s += log(L[(size_t)i * N + i]);
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
+    for (int base = 0; base < N; base += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = min(base + q * 64 + lane, N - 1);
+            v[q] = L[(size_t)i * N + i];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += base + q * 64 + lane < N ? log(v[q]) : 0.;
     }
-    if (threadIdx.x == 0) R.hs[h].ld_s = 2. * sh[0];
+    s = wave_sum(s);
+    if (lane == 0) R.hs[h].ld_s = 2. * s;
+}
+
+__global__ __launch_bounds__(64) void kb_logdet(const Refs R, const int *__restrict__ sel)
+{
+    logdet_body(R, sel[blockIdx.x]);
 }
 
 // d x d covariance (d <= 64), one wave per hypothesis, in LDS: optionally the projection
 // certificate (Cholesky of O - (min_eig + delta) I), then Cholesky of O itself -> log det and
 // O^-1.  ores[h] = {certificate failed, factorisation failed, log det}.
-__global__ __launch_bounds__(64) void kb_small_spd(const Refs R, const int *__restrict__ sel, int src, int dst,
-                                                   int do_cert, double min_eig)
+__device__ __forceinline__ void small_spd_body(const Refs &R, int h, int src, int dst, int do_cert, double min_eig)
 {
     extern __shared__ double sm[];
-    const int h = sel[blockIdx.x];
     const int N = R.d, P = N + 1;
     double *L = sm, *X = sm + (size_t)N * P;
     __shared__ int bad;
@@ -373,16 +386,20 @@ __global__ __launch_bounds__(64) void kb_small_spd(const Refs R, const int *__re
     }
 }
 
+__global__ __launch_bounds__(64) void kb_small_spd(const Refs R, const int *__restrict__ sel, int src, int dst,
+                                                   int do_cert, double min_eig)
+{
+    small_spd_body(R, sel[blockIdx.x], src, dst, do_cert, min_eig);
+}
+
 // ---- K5 kernels with a hypothesis dimension (see k5_klgrad.hip for the algebra) -------------------
 // per-row constants of the point in tables (tm, ts, to): xoff, c, q, diag(S); Omega's scalars
-__global__ __launch_bounds__(256) void kb_rowconst(const Refs R, const int *__restrict__ sel, int tm, int ts, int to)
+__device__ __forceinline__ void rowconst_body(const Refs &R, int h, int tm, int ts, int to, int t)
 {
-    const int h = sel[blockIdx.y];
     const int N = R.N, d = R.d;
     const double *__restrict__ M = tabp(R, tm, h);
     const double *__restrict__ S = tabp(R, ts, h);
     const double *__restrict__ O = tabp(R, to, h);
-    const int t = blockIdx.x * 256 + threadIdx.x;
     if (t == 0) {
         double T = 0, D2 = 0, off2 = 0;
         for (int k = 0; k < d; k++) {
@@ -410,20 +427,37 @@ __global__ __launch_bounds__(256) void kb_rowconst(const Refs R, const int *__re
     R.sdiag[(size_t)h * N + t] = S[(size_t)t * N + t];
 }
 
+__global__ __launch_bounds__(256) void kb_rowconst(const Refs R, const int *__restrict__ sel, int tm, int ts, int to)
+{
+    rowconst_body(R, sel[blockIdx.y], tm, ts, to, blockIdx.x * 256 + threadIdx.x);
+}
+
+// After the factorisations of a trial, in ONE launch of 64-thread blocks (blockIdx.y = hypothesis):
+// block 0 the d x d part (certificate, factor, inverse of cov_latents), block 1 log det of the
+// factor, blocks 2.. the per-row constants of the trial point.
+__global__ __launch_bounds__(64) void kb_post(const Refs R, const int *__restrict__ sel, int tm, int ts, int to,
+                                              int src_o, int dst_oi, int do_cert, double min_eig)
+{
+    const int h = sel[blockIdx.y];
+    if (blockIdx.x == 0) small_spd_body(R, h, src_o, dst_oi, do_cert, min_eig);
+    else if (blockIdx.x == 1) logdet_body(R, h);
+    else rowconst_body(R, h, tm, ts, to, ((int)blockIdx.x - 2) * 64 + (int)threadIdx.x);
+}
+
 constexpr int UN6 = 2;
 
 // One wave per row of the CURRENT point.  SIDE 0: user rows (also writes the per-rating cross
 // entries of g_S and the sums cov_latents' gradient needs); SIDE 1: item rows.  The hypothesis'
 // extra rating is entry `end` of its row.
 template <int DP, int SIDE>
-__global__ __launch_bounds__(256) void kb_kl_rows(const Refs R, const int *__restrict__ sel,
-                                                  const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
-                                                  const double *__restrict__ val, double inv_sig)
+__device__ __forceinline__ void kl_rows_body(const Refs &R, const int *__restrict__ sel, int bx,
+                                             const int64_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                             const double *__restrict__ val, double inv_sig)
 {
     constexpr int G = 64 / DP;
     const int h = sel[blockIdx.y];
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave_id_uniform();
+    const int row = bx * 4 + wave_id_uniform();
     const int rows = SIDE == 0 ? R.n : R.m;
     if (row >= rows) return;
     const int d = R.d, N = R.N, n = R.n;
@@ -501,6 +535,18 @@ __global__ __launch_bounds__(256) void kb_kl_rows(const Refs R, const int *__res
             out[d] = gs_d; out[d + 1] = cv;
         }
     }
+}
+
+// user rows (blocks [0, nbu)) and item rows in one launch: neither reads what the other writes
+template <int DP>
+__global__ __launch_bounds__(256) void kb_kl_rows(const Refs R, const int *__restrict__ sel, int nbu,
+                                                  const int64_t *__restrict__ ptr_u, const int32_t *__restrict__ idx_u,
+                                                  const double *__restrict__ val_u, const int64_t *__restrict__ ptr_v,
+                                                  const int32_t *__restrict__ idx_v, const double *__restrict__ val_v,
+                                                  double inv_sig)
+{
+    if ((int)blockIdx.x < nbu) kl_rows_body<DP, 0>(R, sel, (int)blockIdx.x, ptr_u, idx_u, val_u, inv_sig);
+    else kl_rows_body<DP, 1>(R, sel, (int)blockIdx.x - nbu, ptr_v, idx_v, val_v, inv_sig);
 }
 
 // g_mean rows and the diagonal of g_S from the per-row sums
@@ -646,42 +692,13 @@ __global__ __launch_bounds__(256) void kb_value_rows(const Refs R, const int *__
     }
 }
 
-// out4[h] = {sum bit, ||M_users||^2, tr(S_users), ||M_items||^2}
-__global__ __launch_bounds__(256) void kb_value_finish(const Refs R, const int *__restrict__ sel, int tm)
-{
-    const int h = sel[blockIdx.x];
-    const double *__restrict__ part = R.part + (size_t)h * R.n * 3;
-    const double *__restrict__ M = tabp(R, tm, h);
-    __shared__ double sh[4][256];
-    double a = 0, b = 0, c = 0, e = 0;
-    for (int t = threadIdx.x; t < R.n; t += 256) {
-        a += part[(size_t)t * 3]; b += part[(size_t)t * 3 + 1]; c += part[(size_t)t * 3 + 2];
-    }
-    for (size_t t = threadIdx.x; t < (size_t)R.m * R.d; t += 256) {
-        const double v = M[(size_t)R.n * R.d + t];
-        e += v * v;
-    }
-    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c; sh[3][threadIdx.x] = e;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o)
-            for (int z = 0; z < 4; z++) sh[z][threadIdx.x] += sh[z][threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        for (int z = 0; z < 4; z++) R.out4[(size_t)h * 4 + z] = sh[z][0];
-}
-
 // ---- the decision of the learning-rate search, per hypothesis (mn_active_pmf.py:262-288) -----------
 // mode 0: a trial point was evaluated - accept (swap the pointer tables) or reject;
 // mode 1: the KL of the current point was evaluated at entry (old_kl unknown).
 // forced: the flags were dealt with by the host (slow path), ld_s / ld_o are final.
-__global__ void kb_decide(const Refs R, const int *__restrict__ sel, int nsel, int mode, int forced,
-                          double sigma_sq, double sigma_u_sq)
+__device__ __forceinline__ void decide_one(const Refs &R, int h, int mode, int forced, double sigma_sq,
+                                           double sigma_u_sq)
 {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= nsel) return;
-    const int h = sel[y];
     HypState &s = R.hs[h];
     if (!forced) {
         int slow = 0;
@@ -734,6 +751,41 @@ __global__ void kb_decide(const Refs R, const int *__restrict__ sel, int nsel, i
         if (s.lr < 1e-10) s.status = ST_CONVERGED;
         s.need_grad = 0;
         s.accepted = 0;
+    }
+}
+
+// the four totals of a point's KL pieces, then the decision on it (one block per hypothesis):
+// out4[h] = {sum bit, ||M_users||^2, tr(S_users), ||M_items||^2}
+__global__ __launch_bounds__(256) void kb_value_finish(const Refs R, const int *__restrict__ sel, int tm, int mode,
+                                                       int forced, double sigma_sq, double sigma_u_sq)
+{
+    const int h = sel[blockIdx.x];
+    const double *__restrict__ part = R.part + (size_t)h * R.n * 3;
+    const double *__restrict__ M = tabp(R, tm, h) + (size_t)R.n * R.d;
+    __shared__ double sh[4][256];
+    double a = 0, b = 0, c = 0, e = 0;
+    for (int t = threadIdx.x; t < R.n; t += 256) {
+        a += part[(size_t)t * 3]; b += part[(size_t)t * 3 + 1]; c += part[(size_t)t * 3 + 2];
+    }
+    const int md = R.m * R.d;
+    for (int base = 0; base < md; base += 256 * 8) {       // 8 loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = M[min(base + q * 256 + (int)threadIdx.x, md - 1)];
+#pragma unroll
+        for (int q = 0; q < 8; q++) e += base + q * 256 + (int)threadIdx.x < md ? v[q] * v[q] : 0.;
+    }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c; sh[3][threadIdx.x] = e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+            for (int z = 0; z < 4; z++) sh[z][threadIdx.x] += sh[z][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        for (int z = 0; z < 4; z++) R.out4[(size_t)h * 4 + z] = sh[z][0];
+        __threadfence_block();
+        decide_one(R, h, mode, forced, sigma_sq, sigma_u_sq);
     }
 }
 
@@ -1077,23 +1129,16 @@ inline dim3 g2(size_t count, int ny, int cap = 1024)
 
 // KL pieces of the point in (tm, ts, to) for the selected hypotheses: row constants, per-user
 // sums, the four totals
-int launch_value(apmf_mn_batch *b, const int *sel, int nsel, int tm, int ts, int to)
+int launch_value(apmf_mn_batch *b, const int *sel, int nsel, int tm, int ts, int to, int mode, int forced,
+                 double sigma_sq, double sigma_u_sq, bool with_rowconst = true)
 {
     const Refs &R = b->R;
     hipStream_t st = b->ctx->stream;
-    hipLaunchKernelGGL(kb_rowconst, dim3((R.N + 255) / 256, nsel), dim3(256), 0, st, R, sel, tm, ts, to);
+    if (with_rowconst)
+        hipLaunchKernelGGL(kb_rowconst, dim3((R.N + 255) / 256, nsel), dim3(256), 0, st, R, sel, tm, ts, to);
     DISPATCH_DP6(dp6_for(R.d), hipLaunchKernelGGL((kb_value_rows<DP>), dim3((R.n + 3) / 4, nsel), dim3(256), 0, st,
                                                  R, sel, tm, ts, b->r->ptr[0], b->r->idx[0], b->r->val[0]));
-    hipLaunchKernelGGL(kb_value_finish, dim3(nsel), dim3(256), 0, st, R, sel, tm);
-    APMF_CHECK_LAUNCH();
-    return APMF_OK;
-}
-
-int launch_decide(apmf_mn_batch *b, const int *sel, int nsel, int mode, int forced, double sigma_sq,
-                  double sigma_u_sq)
-{
-    hipLaunchKernelGGL(kb_decide, dim3((nsel + 63) / 64), dim3(64), 0, b->ctx->stream, b->R, sel, nsel, mode, forced,
-                       sigma_sq, sigma_u_sq);
+    hipLaunchKernelGGL(kb_value_finish, dim3(nsel), dim3(256), 0, st, R, sel, tm, mode, forced, sigma_sq, sigma_u_sq);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -1111,7 +1156,7 @@ int launch_factor(apmf_mn_batch *b, const int *sel, int nsel, int mode, ChJob *j
     memset(&J, 0, sizeof(J));
     J.list = jobs;
     APMF_TRY(chol_lower_jobs(b->ctx, J, mode == 2 ? 2 * nsel : nsel, R.N));
-    hipLaunchKernelGGL(kb_logdet, dim3(nsel), dim3(256), 0, b->ctx->stream, R, sel);
+    hipLaunchKernelGGL(kb_logdet, dim3(nsel), dim3(64), 0, b->ctx->stream, R, sel);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -1256,8 +1301,7 @@ int handle_slow(apmf_mn_batch *b, const std::vector<int> &evaluated, bool trial,
     const int *dsel;
     APMF_TRY(upload_sel(b, 2, slow, &dsel));
     const int tm = trial ? T_M_CAND : T_M_CUR, ts = trial ? T_S_CAND : T_S_CUR, to = trial ? T_O_CAND : T_O_CUR;
-    APMF_TRY(launch_value(b, dsel, (int)slow.size(), tm, ts, to));
-    APMF_TRY(launch_decide(b, dsel, (int)slow.size(), trial ? 0 : 1, 1, sigma_sq, sigma_u_sq));
+    APMF_TRY(launch_value(b, dsel, (int)slow.size(), tm, ts, to, trial ? 0 : 1, 1, sigma_sq, sigma_u_sq));
     const int rc = read_status(b);
     b->st_slow_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rc;
@@ -1299,10 +1343,10 @@ int launch_gradient(apmf_mn_batch *b, const std::vector<int> &grad, double sigma
                        (int)T_S_CUR, (int)T_O_CUR);
     const double inv_sig = 1. / sigma_sq;
     const int dp = dp6_for(R.d);
-    DISPATCH_DP6(dp, hipLaunchKernelGGL((kb_kl_rows<DP, 0>), dim3((R.n + 3) / 4, ng), dim3(256), 0, st, R, dgrad,
-                                        b->r->ptr[0], b->r->idx[0], b->r->val[0], inv_sig));
-    DISPATCH_DP6(dp, hipLaunchKernelGGL((kb_kl_rows<DP, 1>), dim3((R.m + 3) / 4, ng), dim3(256), 0, st, R, dgrad,
-                                        b->r->ptr[1], b->r->idx[1], b->r->val[1], inv_sig));
+    const int nbu = (R.n + 3) / 4, nbv = (R.m + 3) / 4;
+    DISPATCH_DP6(dp, hipLaunchKernelGGL((kb_kl_rows<DP>), dim3(nbu + nbv, ng), dim3(256), 0, st, R, dgrad, nbu,
+                                        b->r->ptr[0], b->r->idx[0], b->r->val[0], b->r->ptr[1], b->r->idx[1],
+                                        b->r->val[1], inv_sig));
     hipLaunchKernelGGL(kb_finish_rows, dim3((R.N + 255) / 256, ng), dim3(256), 0, st, R, dgrad, inv_sig, sigma_u_sq,
                        sigma_v_sq);
     hipLaunchKernelGGL(kb_omega, dim3(R.d * R.d, ng), dim3(256), 0, st, R, dgrad, inv_sig, sigma_u_sq, sigma_v_sq);
@@ -1424,9 +1468,12 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
         return rc;
     }
     memset(b->hs_host, 0, (size_t)H * sizeof(HypState));
-    if (small_smem(d) > 48 * 1024)
+    if (small_smem(d) > 48 * 1024) {
         (void)hipFuncSetAttribute((const void *)kb_small_spd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)small_smem(d));
+        (void)hipFuncSetAttribute((const void *)kb_post, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)small_smem(d));
+    }
     b->fvalid.assign(H, 0);
     b->fvalid_cand.assign(H, 0);
     b->oivalid.assign(H, 0);
@@ -1546,8 +1593,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         APMF_TRY(launch_factor(b, dsel, ni, 1));
         hipLaunchKernelGGL(kb_small_spd, dim3(ni), dim3(64), small_smem(R.d), st, R, dsel, (int)T_O_CUR, (int)T_OI_CUR,
                            0, min_eig);
-        APMF_TRY(launch_value(b, dsel, ni, T_M_CUR, T_S_CUR, T_O_CUR));
-        APMF_TRY(launch_decide(b, dsel, ni, 1, 0, sigma_sq, sigma_u_sq));
+        APMF_TRY(launch_value(b, dsel, ni, T_M_CUR, T_S_CUR, T_O_CUR, 1, 0, sigma_sq, sigma_u_sq));
         APMF_TRY(read_status(b));
         for (int h : init) { b->fvalid[h] = 1; b->oivalid[h] = 1; }
         APMF_TRY(handle_slow(b, init, false, min_eig, sigma_sq, sigma_u_sq));
@@ -1595,8 +1641,8 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 APMF_TRY(slow_finish(b, lane, lane_masks, true, min_eig));
                 const int *dsel;
                 APMF_TRY(upload_sel(b, 2, lane, &dsel));
-                APMF_TRY(launch_value(b, dsel, (int)lane.size(), T_M_CAND, T_S_CAND, T_O_CAND));
-                APMF_TRY(launch_decide(b, dsel, (int)lane.size(), 0, 1, sigma_sq, sigma_u_sq));
+                APMF_TRY(launch_value(b, dsel, (int)lane.size(), T_M_CAND, T_S_CAND, T_O_CAND, 0, 1, sigma_sq,
+                                      sigma_u_sq));
                 APMF_TRY(read_status(b));
                 finish_decided(lane);
                 for (int h : lane) is_parked[h] = 0;
@@ -1625,13 +1671,17 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             const int nt32 = (R.N + 31) / 32;
             hipLaunchKernelGGL(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig);
             hipLaunchKernelGGL(kb_trial_small, dim3((unsigned)(((size_t)R.N * R.d + (size_t)R.d * R.d + 255) / 256), na),
-                               dim3(256), 0, st, R, dsel);
+                               dim3(256), 0, st, R, dsel, R.jobs);
             APMF_CHECK_LAUNCH();
-            APMF_TRY(launch_factor(b, dsel, na, 2));
-            hipLaunchKernelGGL(kb_small_spd, dim3(na), dim3(64), small_smem(R.d), st, R, dsel, (int)T_O_CAND,
-                               (int)T_OI_CAND, 1, min_eig);
-            APMF_TRY(launch_value(b, dsel, na, T_M_CAND, T_S_CAND, T_O_CAND));
-            APMF_TRY(launch_decide(b, dsel, na, 0, 0, sigma_sq, sigma_u_sq));
+            {
+                ChJobs J;
+                memset(&J, 0, sizeof(J));
+                J.list = R.jobs;
+                APMF_TRY(chol_lower_jobs(ctx, J, 2 * na, R.N));
+            }
+            hipLaunchKernelGGL(kb_post, dim3(2 + (R.N + 63) / 64, na), dim3(64), small_smem(R.d), st, R, dsel,
+                               (int)T_M_CAND, (int)T_S_CAND, (int)T_O_CAND, (int)T_O_CAND, (int)T_OI_CAND, 1, min_eig);
+            APMF_TRY(launch_value(b, dsel, na, T_M_CAND, T_S_CAND, T_O_CAND, 0, 0, sigma_sq, sigma_u_sq, false));
             APMF_TRY(read_status(b));
             for (int h : active) {
                 b->fvalid_cand[h] = 1;
