@@ -37,7 +37,9 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include <rocblas/rocblas.h>
@@ -1082,7 +1084,8 @@ struct apmf_mn_batch {
     std::vector<double *> tab_host;
     // APMF_BATCH_STATS=1: counters of the last fit, printed to stderr when it returns
     long st_iters, st_trials, st_grads, st_slow[4], st_slow_grad;
-    double st_slow_s;
+    double st_slow_s, st_lane_s;
+    long st_lane_passes, st_lane_hyps;
 };
 
 namespace {
@@ -1177,47 +1180,80 @@ int write_ld(apmf_mn_batch *b, int h, const double *ld_s, const double *ld_o)
 // no host synchronisation: eigen-projection of the hypotheses whose certificate failed, then the
 // factorisation of every listed hypothesis' (projected) matrix.  slot0 / slot0 + 1: selection-list
 // slots, jobs: job-list buffer - private to the caller's stream.
-int slow_S_enqueue(apmf_mn_batch *b, const std::vector<int> &list, const std::vector<int> &masks, bool trial,
-                   double min_eig, int slot0, ChJob *jobs)
+// Three parts, so that the middle one - the call into rocSOLVER, some 3000 small launches and 4 ms
+// of HOST time per pass - can run on a thread of its own while the search loop keeps feeding the main
+// stream:  pre (copies, pointer list, handle bound to the stream),  solve (the eigendecompositions),
+// post (rebuild of the projected matrices, factorisation of every listed hypothesis' matrix).
+struct SlowS {
+    std::vector<int> proj, refac;
+    void *handle = nullptr;
+};
+
+int slow_S_pre(apmf_mn_batch *b, const std::vector<int> &list, const std::vector<int> &masks, int slot0, SlowS &w)
 {
     const Refs &R = b->R;
-    const int N = R.N;
+    hipStream_t st = b->ctx->stream;
+    w.proj.clear();
+    w.refac.clear();
+    for (size_t q = 0; q < list.size(); q++) {
+        if (masks[q] & SLOW_CERT_S) w.proj.push_back(list[q]);
+        if (masks[q] & (SLOW_CERT_S | SLOW_FACT_S)) w.refac.push_back(list[q]);
+    }
+    if (w.proj.empty()) return APMF_OK;
+    const size_t nn = (size_t)R.N * R.N;
+    const int np = (int)w.proj.size();
+    const int *dsel;
+    APMF_TRY(upload_sel(b, slot0, w.proj, &dsel));
+    hipLaunchKernelGGL(kb_copy, g2(nn, np, 256), dim3(256), 0, st, R, dsel, (int)T_S_CAND, (int)T_S_W, nn);
+    hipLaunchKernelGGL(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
+    APMF_CHECK_LAUNCH();
+    APMF_TRY(apmf_dense_handle(b->ctx, &w.handle));      // binds the handle to the current stream
+    return APMF_OK;
+}
+
+// thread-safe with respect to everything but the handle
+rocblas_status slow_S_solve(const Refs &R, const SlowS &w)
+{
+    if (w.proj.empty()) return rocblas_status_success;
+    // (replaying the call from a captured hipGraph was tried: same 12.5 ms per pass - the ~3000 small
+    // kernels of a 519 x 519 syevd execute one after the other either way)
+    return rocsolver_dsyevd_batched((rocblas_handle)w.handle, rocblas_evect_original, rocblas_fill_lower, R.N, R.ptrs,
+                                    R.N, R.evals, R.N, R.evE, R.N, R.evinfo, (int)w.proj.size());
+}
+
+int slow_S_post(apmf_mn_batch *b, const SlowS &w, rocblas_status rs, bool trial, double min_eig, int slot0, ChJob *jobs)
+{
+    const Refs &R = b->R;
     hipStream_t st = b->ctx->stream;
     const int tS = trial ? T_S_CAND : T_S_CUR;
-    std::vector<int> proj, refac;
-    for (size_t q = 0; q < list.size(); q++) {
-        if (masks[q] & SLOW_CERT_S) proj.push_back(list[q]);
-        if (masks[q] & (SLOW_CERT_S | SLOW_FACT_S)) refac.push_back(list[q]);
+    const size_t nn = (size_t)R.N * R.N;
+    if (rs != rocblas_status_success) {
+        apmf_set_error("rocsolver_dsyevd_batched failed: rocblas_status %d", (int)rs);
+        return APMF_EHIP;
     }
-    const size_t nn = (size_t)N * N;
-    if (!proj.empty()) {
-        const int np = (int)proj.size();
-        const int *dsel;
-        APMF_TRY(upload_sel(b, slot0, proj, &dsel));
-        hipLaunchKernelGGL(kb_copy, g2(nn, np, 256), dim3(256), 0, st, R, dsel, (int)T_S_CAND, (int)T_S_W, nn);
-        hipLaunchKernelGGL(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
-        APMF_CHECK_LAUNCH();
-        void *hv = nullptr;
-        APMF_TRY(apmf_dense_handle(b->ctx, &hv));      // binds the handle to the current stream
-        const rocblas_status rs = rocsolver_dsyevd_batched((rocblas_handle)hv, rocblas_evect_original,
-                                                           rocblas_fill_lower, N, R.ptrs, N, R.evals, N, R.evE, N,
-                                                           R.evinfo, np);
-        if (rs != rocblas_status_success) {
-            apmf_set_error("rocsolver_dsyevd_batched failed: rocblas_status %d", (int)rs);
-            return APMF_EHIP;
-        }
-        hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, np), dim3(256), 0, st, R, dsel, min_eig);
+    if (!w.proj.empty()) {
+        const int *dsel = b->sel_dev + (size_t)slot0 * R.H;      // uploaded by slow_S_pre
+        hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, (int)w.proj.size()), dim3(256), 0, st, R, dsel,
+                           min_eig);
         APMF_CHECK_LAUNCH();
     }
-    if (!refac.empty()) {
-        const int nr = (int)refac.size();
+    if (!w.refac.empty()) {
+        const int nr = (int)w.refac.size();
         const int *dsel;
-        APMF_TRY(upload_sel(b, slot0 + 1, refac, &dsel));
+        APMF_TRY(upload_sel(b, slot0 + 1, w.refac, &dsel));
         hipLaunchKernelGGL(kb_copy, g2(nn, nr, 256), dim3(256), 0, st, R, dsel, tS, (int)T_S_F, nn);
         APMF_CHECK_LAUNCH();
         APMF_TRY(launch_factor(b, dsel, nr, 1, jobs));
     }
     return APMF_OK;
+}
+
+int slow_S_enqueue(apmf_mn_batch *b, const std::vector<int> &list, const std::vector<int> &masks, bool trial,
+                   double min_eig, int slot0, ChJob *jobs)
+{
+    SlowS w;
+    APMF_TRY(slow_S_pre(b, list, masks, slot0, w));
+    return slow_S_post(b, w, slow_S_solve(b->R, w), trial, min_eig, slot0, jobs);
 }
 
 // Host side of the same, once the enqueued work has completed: convergence of the eigensolver, LU
@@ -1577,7 +1613,9 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     }
     b->st_iters = b->st_trials = b->st_grads = b->st_slow_grad = 0;
     b->st_slow[0] = b->st_slow[1] = b->st_slow[2] = b->st_slow[3] = 0;
-    b->st_slow_s = 0.;
+    b->st_slow_s = b->st_lane_s = 0.;
+    b->st_lane_passes = b->st_lane_hyps = 0;
+    std::chrono::steady_clock::time_point t_lane;
     const auto t_fit = std::chrono::steady_clock::now();
     // a hypothesis whose KL is known AND whose factor / inverse are in place resumes directly
     std::vector<int> init;
@@ -1613,8 +1651,33 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     std::vector<int> active, grad, parked, decided, lane, lane_masks, osync;
     std::vector<char> is_parked(H, 0);
     bool lane_busy = false;
-    auto lane_wait = [&]() {
-        if (lane_busy) (void)hipEventSynchronize(b->ev_lane);
+    // lane_busy with lane_solving: the worker thread is still inside rocSOLVER; lane_post() joins it and
+    // enqueues the rest of the pass behind the solver's kernels
+    bool lane_solving = false;
+    std::thread lane_thr;
+    std::atomic<int> lane_enq(0);
+    rocblas_status lane_rs = rocblas_status_success;
+    SlowS lane_w;
+    struct Joiner {              // an early return must not leave a joinable thread behind
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{lane_thr};
+    auto lane_post = [&]() -> int {
+        if (!lane_solving) return APMF_OK;
+        if (lane_thr.joinable()) lane_thr.join();
+        lane_solving = false;
+        hipStream_t saved = ctx->stream;
+        ctx->stream = b->aux;
+        int rc = slow_S_post(b, lane_w, lane_rs, true, min_eig, 3, b->jobs2);
+        if (rc == APMF_OK && hipEventRecord(b->ev_lane, b->aux) != hipSuccess) rc = APMF_EHIP;
+        ctx->stream = saved;
+        return rc;
+    };
+    auto lane_wait = [&]() -> int {
+        if (!lane_busy) return APMF_OK;
+        APMF_TRY(lane_post());
+        (void)hipEventSynchronize(b->ev_lane);
+        return APMF_OK;
     };
     auto finish_decided = [&](const std::vector<int> &list) {
         // F holds the factor of the trial point: the current one's only if the trial was accepted
@@ -1629,7 +1692,8 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 if (b->hs_host[h].need_grad) grad.push_back(h);
             }
         if (lane_busy) {
-            bool done = hipEventQuery(b->ev_lane) == hipSuccess;
+            if (lane_solving && (lane_enq.load(std::memory_order_acquire) || active.empty())) APMF_TRY(lane_post());
+            bool done = !lane_solving && hipEventQuery(b->ev_lane) == hipSuccess;
             (void)hipGetLastError();             // hipErrorNotReady is not an error
             if (!done && active.empty()) {
                 APMF_CHECK_HIP(hipEventSynchronize(b->ev_lane));
@@ -1646,6 +1710,9 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 APMF_TRY(read_status(b));
                 finish_decided(lane);
                 for (int h : lane) is_parked[h] = 0;
+                b->st_lane_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_lane).count();
+                b->st_lane_passes++;
+                b->st_lane_hyps += (long)lane.size();
                 lane.clear();
                 lane_busy = false;
                 b->st_slow_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1662,7 +1729,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             if (!grad.empty()) {
                 bool need_sync = false;
                 for (int h : grad) need_sync |= !b->fvalid[h];
-                if (need_sync) lane_wait();      // the LU route of such a gradient uses rocSOLVER too
+                if (need_sync) APMF_TRY(lane_wait());      // the LU route of such a gradient uses rocSOLVER too
                 APMF_TRY(launch_gradient(b, grad, sigma_sq, sigma_u_sq, sigma_v_sq));
             }
             const int na = (int)active.size();
@@ -1700,7 +1767,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             }
         }
         if (!osync.empty()) {
-            lane_wait();
+            APMF_TRY(lane_wait());
             APMF_TRY(handle_slow(b, osync, true, min_eig, sigma_sq, sigma_u_sq));
             for (int h : osync) decided.push_back(h);
         }
@@ -1714,11 +1781,25 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 // the main stream is idle here (read_status synchronised it): the lane may start at once
                 hipStream_t saved = ctx->stream;
                 ctx->stream = b->aux;
-                int rc = slow_S_enqueue(b, lane, lane_masks, true, min_eig, 3, b->jobs2);
-                if (rc == APMF_OK && hipEventRecord(b->ev_lane, b->aux) != hipSuccess) rc = APMF_EHIP;
+                int rc = slow_S_pre(b, lane, lane_masks, 3, lane_w);
                 ctx->stream = saved;
                 if (rc != APMF_OK) return rc;
+                lane_enq.store(0, std::memory_order_relaxed);
+                lane_solving = true;
                 lane_busy = true;
+                t_lane = std::chrono::steady_clock::now();
+                if (lane_w.proj.empty()) {
+                    lane_rs = rocblas_status_success;
+                    lane_enq.store(1, std::memory_order_release);
+                    APMF_TRY(lane_post());
+                } else {
+                    const int device = ctx->device;
+                    lane_thr = std::thread([&, device]() {
+                        (void)hipSetDevice(device);
+                        lane_rs = slow_S_solve(b->R, lane_w);
+                        lane_enq.store(1, std::memory_order_release);
+                    });
+                }
             } else {
                 APMF_TRY(handle_slow(b, parked, true, min_eig, sigma_sq, sigma_u_sq));
                 for (int h : parked) {
@@ -1735,9 +1816,10 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         if (e[0] == '1')
             fprintf(stderr,
                     "[apmf batch] H=%d N=%d: %ld iterations, %ld trials, %ld gradients (%ld without factor); slow "
-                    "exits: projection S %ld, factor S %ld, projection O %ld, inverse O %ld, %.3f s; total %.3f s\n",
+                    "exits: projection S %ld, factor S %ld, projection O %ld, inverse O %ld, %.3f s; lane: %ld passes, %ld "
+                    "hypotheses, busy %.3f s; total %.3f s\n",
                     H, R.N, b->st_iters, b->st_trials, b->st_grads, b->st_slow_grad, b->st_slow[0], b->st_slow[1],
-                    b->st_slow[2], b->st_slow[3], b->st_slow_s,
+                    b->st_slow[2], b->st_slow[3], b->st_slow_s, b->st_lane_passes, b->st_lane_hyps, b->st_lane_s,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fit).count());
     for (int h = 0; h < H; h++) {
         const HypState &s = b->hs_host[h];
