@@ -132,11 +132,14 @@ def _fit_alone(ctx, ratings, n, m, d, mean, S, O, sig, su, sv, max_steps, cap):
     return dm.to_host(), ds.to_host(), do.to_host(), trace, steps, lr, conv, kl
 
 
-@pytest.mark.parametrize('shape,max_steps', [((24, 17, 5), 25), ((94, 425, 5), 6), ((60, 75, 3), -1)])
-def test_batched_equals_alone_bitwise(ctx, shape, max_steps):
+@pytest.mark.parametrize('shape,max_steps,H', [((24, 17, 5), 25, 5), ((94, 425, 5), 6, 5), ((60, 75, 3), -1, 5),
+                                                ((70, 90, 4), 12, 20)])
+def test_batched_equals_alone_bitwise(ctx, shape, max_steps, H):
     """H hypotheses fitted in one batch == each fitted alone on a container rebuilt with its extra
     rating appended (what deepcopy + add_rating + fit_normal does): states, KL traces, step counts
-    and learning rates bit-for-bit.  (94, 425, 5) is BASELINE.json configs[3]'s shape."""
+    and learning rates bit-for-bit.  (94, 425, 5) is BASELINE.json configs[3]'s shape.  H = 20 puts 40
+    matrices in a factorisation launch: the chain then factors diagonal blocks in launches of their own
+    (csrc/chol.h), while a fit run alone factors them inside the update launch - same bits."""
     n, m, d = shape
     N = n + m
     rs, ratings, mean, S, O = _problem(n, m, d, 77 + n, per_row=2)
@@ -144,9 +147,8 @@ def test_batched_equals_alone_bitwise(ctx, shape, max_steps):
     S = np.eye(N) + 0.01 * S
     O = np.eye(d)
     sig, su, sv = 1.0, 10.0, 10.0
-    H = 5
     ex = _unrated(rs, ratings, n, m, H - 1)
-    vals = [1., 5., 3., 2.]
+    vals = [[1., 5., 3., 2.][q % 4] for q in range(H - 1)]
     hi = [e[0] for e in ex] + [-1]
     hj = [e[1] for e in ex] + [-1]
     hv = vals + [0.]
