@@ -28,7 +28,6 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 constexpr int CT = 2;          // 16 x 16 tiles per wave, side by side
 constexpr int BR = 32;         // block tile rows  (2 waves)
 constexpr int BC = 32 * CT;    // block tile columns (2 waves x CT tiles)
-constexpr int MAXIT = 24;      // staging loads per thread: (BR + BC) * d / 256 <= 24 for d <= 64
 
 // workgroup barrier ordering LDS traffic only (see k2_score.hip: __syncthreads() would also
 // drain the global loads that are deliberately left in flight)
@@ -39,68 +38,69 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// NIT = ceil((BR + BC) d / 256) staging fragments per thread.  LDS image of one sample: the
-// U chunk (BR x d, row-major) then the V chunk (BC x d).  For a power-of-two d (row stride a
-// multiple of the bank count) row r is stored rotated by r, which spreads a column over banks.
-// (NIT <= 8 is held to 128 VGPRs = 4 blocks per CU: at 943 x 1682 the 810 blocks then run as one wave
+// NQ = ceil(d / 4) k-steps of the 16 x 16 x 4 instruction.  LDS image of one sample: BR rows of U_s
+// then BC rows of V_s, every row zero-padded to 4 NQ doubles at a pitch of 4 NQ + 2 (16 rows of an
+// operand read then fall on distinct banks).  With the row length a compile-time constant the
+// MFMA operands are read at immediate offsets from one per-lane base and the padding needs no masks:
+// the contraction loop has no VALU instruction left.  (The flat copy with run-time d it replaces
+// spent 242 VALU instructions per wave and sample - address arithmetic - against 8 MFMAs: the
+// kernel was VALU-bound at 16 TFLOP/s.)
+// (NQ <= 5 is held to 128 VGPRs = 4 blocks per CU: at 943 x 1682 the 810 blocks then run as one wave
 // of blocks instead of two)
-template <int NIT>
-__global__ __launch_bounds__(256, NIT <= 8 ? 4 : 2) void k_sample_stats(int S, int n, int m, int d, int ld,
+template <int NQ>
+__global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, int n, int m, int d, int ld,
                                                       const double *__restrict__ Us,
                                                       const double *__restrict__ Vs, double add,
                                                       double cutoff, double *__restrict__ o_mean,
                                                       double *__restrict__ o_var,
                                                       double *__restrict__ o_prob)
 {
-    extern __shared__ __attribute__((aligned(16))) double sm[];   // 2 x (BR + BC) x d
+    constexpr int DP = 4 * NQ;             // padded row length
+    constexpr int LS = DP + 2;             // LDS row pitch (doubles)
+    constexpr int RPP = 256 / DP;          // rows staged per pass of the block
+    constexpr int NIT = (BR + BC + RPP - 1) / RPP;
+    constexpr int TILE = (BR + BC) * LS;
+    extern __shared__ __attribute__((aligned(16))) double sm[];   // 2 x (BR + BC) x LS
     const int lane = threadIdx.x & 63;
     const int wave = wave_id_uniform();
     const int wr = wave >> 1, wc = wave & 1;
     const int ri = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.y * BR, col0 = blockIdx.x * BC;
-    const int tile_el = (BR + BC) * d;
-    const bool pow2 = (d & (d - 1)) == 0;
-    const int dmask = d - 1;
 
-    // staging: flat element e = it * 256 + thread of the image; the plan (source chunk, range
-    // check, LDS slot) is a handful of integer operations, recomputed per sample rather than
-    // kept in registers (the running statistics need them)
-    const int u_valid = min(BR, n - row0) * d;              // elements of the U chunk in range
-    const int v_valid = max(0, min(BC, m - col0)) * d;
-    const int log2d = 31 - __builtin_clz(d);
+    // staging: thread (rp, k) = (tid / DP, tid % DP) takes element k of rows rp, rp + RPP, ...
+    const int sk = (int)threadIdx.x % DP, rp = (int)threadIdx.x / DP;
+    const bool s_act = rp < RPP;
+    const int u_rows = min(BR, n - row0), v_rows = max(0, min(BC, m - col0));
+    const bool k_in = sk < d;
     double stg[NIT];
     auto fetch = [&](int s) {
         const double *ub = Us + ((size_t)s * n + row0) * d;
         const double *vb = Vs + ((size_t)s * m + col0) * d;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int e = it * 256 + (int)threadIdx.x;
-            const bool isv = e >= BR * d;
-            const int ce = isv ? e - BR * d : e;
-            const bool ok = ce < (isv ? v_valid : u_valid);
-            const double x = (isv ? vb : ub)[ok ? ce : 0];
+            const int row = it * RPP + rp;
+            const bool isv = row >= BR;
+            const int cr = isv ? row - BR : row;
+            const bool ok = s_act && k_in && cr < (isv ? v_rows : u_rows);
+            const double x = (isv ? vb : ub)[ok ? cr * d + sk : 0];      // always a valid address
             stg[it] = ok ? x : 0.;
         }
     };
     auto commit = [&](int buf) {
-        double *dst = sm + (size_t)buf * tile_el;
+        double *dst = sm + (size_t)buf * TILE + sk;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int e = it * 256 + (int)threadIdx.x;
-            int slot = e;
-            if (pow2) {
-                const int r = e >> log2d, k = e & dmask;
-                slot = (r << log2d) + ((k + r) & dmask);
-            }
-            if (e < tile_el) dst[slot] = stg[it];
+            const int row = it * RPP + rp;
+            if (s_act && row < BR + BC) dst[row * LS] = stg[it];
         }
     };
 
-    // operand slots of this lane within an LDS image: U row (16 wr + ri), V rows (32 wc + 16 t + ri)
-    const int arow = 16 * wr + ri;
-    int brow[CT];
+    // operand slots of this lane within an LDS image: U row (16 wr + ri), V rows (32 wc + 16 t + ri),
+    // element kq of every group of four
+    const int aoff = (16 * wr + ri) * LS + kq;
+    int boff[CT];
 #pragma unroll
-    for (int t = 0; t < CT; t++) brow[t] = BR + 32 * wc + 16 * t + ri;
+    for (int t = 0; t < CT; t++) boff[t] = (BR + 32 * wc + 16 * t + ri) * LS + kq;
 
     double c[CT][4], s1[CT][4], s2[CT][4];
     int cnt[CT][4];
@@ -112,28 +112,19 @@ __global__ __launch_bounds__(256, NIT <= 8 ? 4 : 2) void k_sample_stats(int S, i
     fetch(0);
     commit(0);
     __syncthreads();
-    const int nq = (d + 3) >> 2;
     for (int s = 0; s < S; s++) {
         const int buf = s & 1;
         fetch(min(s + 1, S - 1));            // the last sample re-reads itself: no branch
-        const double *img = sm + (size_t)buf * tile_el;
+        const double *img = sm + (size_t)buf * TILE;
         f64x4 acc[CT];
 #pragma unroll
         for (int t = 0; t < CT; t++) acc[t] = (f64x4){add, add, add, add};   // x_s = u.v + add
-        for (int q = 0; q < nq; q++) {
-            const int k = 4 * q + kq;
-            const bool kok = k < d;
-            const int kc = kok ? k : 0;
-            const int ka = pow2 ? ((kc + arow) & dmask) : kc;
-            double av = img[arow * d + ka];
-            av = kok ? av : 0.;
 #pragma unroll
-            for (int t = 0; t < CT; t++) {
-                const int kb = pow2 ? ((kc + brow[t]) & dmask) : kc;
-                double bv = img[brow[t] * d + kb];
-                bv = kok ? bv : 0.;
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
-            }
+        for (int q = 0; q < NQ; q++) {
+            const double av = img[aoff + 4 * q];
+#pragma unroll
+            for (int t = 0; t < CT; t++)
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, img[boff[t] + 4 * q], acc[t], 0, 0, 0);
         }
         commit(buf ^ 1);
         if (s == 0) {            // the shift of the running sums is the first sample
@@ -188,24 +179,24 @@ extern "C" int apmf_sample_stats_f64(apmf_ctx *ctx, int S, int n, int m, int d, 
     if (!d_mean && !d_var && !d_prob) return APMF_OK;
     APMF_REQUIRE(d <= APMF_MAX_D, "latent_d=%d unsupported (1..%d)", d, APMF_MAX_D);
     dim3 grid((ld + BC - 1) / BC, (n + BR - 1) / BR);
-    const size_t smem = 2 * (size_t)(BR + BC) * d * sizeof(double);
-    const int nit = ((BR + BC) * d + 255) / 256;
-#define APMF_K4(NIT)                                                                              \
-    {                                                                                              \
+    const int nq = (d + 3) / 4;
+    const size_t smem = 2 * (size_t)(BR + BC) * (4 * nq + 2) * sizeof(double);
+#define APMF_K4(NQ)                                                                                \
+    case NQ: {                                                                                     \
         if (smem > 64 * 1024)                                                                      \
-            APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_sample_stats<NIT>,                  \
+            APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_sample_stats<NQ>,                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         ProfScope prof(ctx);                                                                       \
-        hipLaunchKernelGGL((k_sample_stats<NIT>), grid, dim3(256), smem, ctx->stream, S, n, m, d, ld, d_Us, \
+        hipLaunchKernelGGL((k_sample_stats<NQ>), grid, dim3(256), smem, ctx->stream, S, n, m, d, ld, d_Us, \
                            d_Vs, add, cutoff, d_mean, d_var, d_prob);                              \
+    } break;
+    switch (nq) {
+        APMF_K4(1) APMF_K4(2) APMF_K4(3) APMF_K4(4) APMF_K4(5) APMF_K4(6) APMF_K4(7) APMF_K4(8)
+        APMF_K4(9) APMF_K4(10) APMF_K4(11) APMF_K4(12) APMF_K4(13) APMF_K4(14) APMF_K4(15) APMF_K4(16)
+    default:
+        apmf_set_error("latent_d=%d unsupported", d);
+        return APMF_EINVAL;
     }
-    if (nit <= 2) APMF_K4(2)
-    else if (nit <= 4) APMF_K4(4)
-    else if (nit <= 6) APMF_K4(6)
-    else if (nit <= 8) APMF_K4(8)
-    else if (nit <= 12) APMF_K4(12)
-    else if (nit <= 16) APMF_K4(16)
-    else APMF_K4(MAXIT)
 #undef APMF_K4
     APMF_CHECK_LAUNCH();
     return APMF_OK;
