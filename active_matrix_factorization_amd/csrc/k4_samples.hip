@@ -11,13 +11,12 @@
 // A block is 2 x 2 waves = a 32-row x 64-column tile of the grid; a wave owns 16 x 32 of it
 // (two 16 x 16 accumulators, 8 candidates per lane: the 7 registers of running statistics per
 // candidate are what bounds the tile).  Per sample the block's operands are two CONTIGUOUS
-// chunks of the row-major sample arrays (32 rows of U_s, 64 rows of V_s): they are copied
-// flat into LDS (double-buffered, the next sample's chunk in flight during this sample's
+// chunks of the row-major sample arrays (32 rows of U_s, 64 rows of V_s): they are staged
+// into LDS (double-buffered, the next sample's chunk in flight during this sample's
 // MFMAs) and the 4 waves read their MFMA operands from there (lane l: row / column l & 15,
-// k = 4 q + (l >> 4)).  Measured 943 x 1682, d = 15, S = 128: 0.40 ms (the 8 x 2 VALU micro-tile
-// kernel it replaces: 0.80 ms; per-wave operand gathers from global memory: 0.49 ms).  What is
-// left is the per-sample fold (about 7 f64 VALU operations per candidate), which does not overlap
-// with the 64-cycle f64 MFMAs of the same SIMD.
+// k = 4 q + (l >> 4)).  Measured 943 x 1682, d = 15, S = 128: 0.25 ms = 26 TFLOP/s (the 8 x 2 VALU
+// micro-tile kernel: 0.80 ms; per-wave operand gathers from global memory: 0.49 ms; a flat LDS copy
+// with run-time row length: 0.40 ms, VALU-bound on address arithmetic).
 // Variance is accumulated around the first sample (shifted sums), which matches numpy's
 // two-pass np.var to rounding.
 #include "common.h"
