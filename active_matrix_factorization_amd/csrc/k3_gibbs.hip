@@ -41,6 +41,35 @@ __device__ __forceinline__ bool chol_lds(double *A, int d, int lda, int lane)
     return ok;
 }
 
+// lane `src` 's value of a wave-resident double, as a wave-uniform value
+__device__ __forceinline__ double lane_value(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// The same factorisation for d <= 16 with the matrix in REGISTERS: lane t holds row t (entries above
+// the diagonal are don't-care), other lanes' entries arrive by v_readlane.  Same operations on every
+// element in the same order as chol_lds - whose inner loop is a chain of dependent LDS round trips,
+// 22 us per 15 x 15 matrix and two thirds of a half-sweep - in about 1.5 us.  Rows >= d must hold the
+// identity.  Returns false (wave-uniform) if a pivot is not positive.
+__device__ __forceinline__ bool chol_regs16(double (&r)[16], int lane)
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double piv = lane_value(r[j], j);
+        ok = ok && piv > 0.;
+        const double s = sqrt(piv);
+        r[j] = lane == j ? s : r[j] / s;
+#pragma unroll
+        for (int c = j + 1; c < 16; c++) r[c] -= r[j] * lane_value(r[j], c);
+    }
+    return ok;
+}
+
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 // per-hypothesis layout of a batched half-sweep (all zero / NULL for the plain one)
@@ -107,24 +136,55 @@ __global__ __launch_bounds__(64) void k_gibbs_rows(int row_lo, int rows, int d, 
 
     const int64_t beg = ptr[row], end0 = ptr[row + 1];
     const int64_t end = end0 + (xsrc >= 0 ? 1 : 0);
-    for (int64_t r0 = beg; r0 < end; r0 += 4) {
-        const int64_t r = r0 + q;
-        const bool ok = r < end;
-        const bool ex = ok && r == end0;          // only reachable with an extra rating
-        const int32_t src = ok ? (ex ? xsrc : idx[r]) : 0;
-        const double rv = ok ? (ex ? xval : val[r]) - mean_sub : 0.;
-        double f[TL];
+    // 4 MFMA steps (16 ratings) per trip; every load is unconditional (entries past the end are read at
+    // the row's first entry and masked) so that a trip's 4 index loads, then its 4 x TL gathers, are in
+    // flight together, and the next trip's indices are requested before this trip's gathers are used
+    constexpr int UR = 4;
+    int32_t src[UR];
+    double rv[UR];
+    bool ok[UR];
+    auto entries = [&](int64_t r0) {
 #pragma unroll
-        for (int t = 0; t < TL; t++) {
-            const int col = 16 * t + c;
-            f[t] = (ok && col < d) ? oth[(size_t)src * d + col] : 0.;
-            racc[t] += f[t] * rv;
+        for (int u = 0; u < UR; u++) {
+            const int64_t r = r0 + 4 * u + q;
+            ok[u] = r < end;
+            const bool ex = ok[u] && r == end0;          // only reachable with an extra rating
+            const int64_t rc = (ok[u] && !ex) ? r : beg;  // beg < end0: no row is empty (checked by the host)
+            const int32_t si = idx[rc];
+            const double vi = val[rc];
+            src[u] = ex ? xsrc : (ok[u] ? si : 0);
+            rv[u] = ok[u] ? (ex ? xval : vi) - mean_sub : 0.;
         }
+    };
+    entries(beg);
+    for (int64_t r0 = beg; r0 < end; r0 += 4 * UR) {
+        double f[UR][TL];
 #pragma unroll
-        for (int ti = 0; ti < TL; ti++)
+        for (int u = 0; u < UR; u++)
 #pragma unroll
-            for (int tj = ti; tj < TL; tj++)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[ti], f[tj], acc[ti][tj], 0, 0, 0);
+            for (int t = 0; t < TL; t++) {
+                const int col = 16 * t + c;
+                f[u][t] = oth[(size_t)src[u] * d + (col < d ? col : 0)];
+            }
+        double rvc[UR];
+        bool okc[UR];
+#pragma unroll
+        for (int u = 0; u < UR; u++) { rvc[u] = rv[u]; okc[u] = ok[u]; }
+        entries(r0 + 4 * UR);
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+#pragma unroll
+            for (int t = 0; t < TL; t++) {
+                const int col = 16 * t + c;
+                f[u][t] = (okc[u] && col < d) ? f[u][t] : 0.;
+                racc[t] += f[u][t] * rvc[u];
+            }
+#pragma unroll
+            for (int ti = 0; ti < TL; ti++)
+#pragma unroll
+                for (int tj = ti; tj < TL; tj++)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][ti], f[u][tj], acc[ti][tj], 0, 0, 0);
+        }
     }
     // A = alpha + beta F'F : C/D layout of the f64 MFMA is col = lane & 15, row = (lane >> 4) + 4 reg
 #pragma unroll
@@ -155,6 +215,57 @@ __global__ __launch_bounds__(64) void k_gibbs_rows(int row_lo, int rows, int d, 
     }
     __syncthreads();
 
+    if (TL == 1) {
+        // d <= 16: everything below in registers, lane t = row t (or column t); rows >= d are identity
+        double r[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) r[k] = (lane < d && k < d) ? A[lane * lda + k] : (k == lane ? 1. : 0.);
+        // A = R R'
+        if (!chol_regs16(r, lane)) {
+            if (lane == 0) atomicExch(status, 1);
+            return;
+        }
+        // X = R^-1 (lower): lane c owns column c, x[i] = X[i][c]
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            double v = i == lane ? 1. : 0.;
+#pragma unroll
+            for (int m = 0; m < i; m++) v -= lane_value(r[m], i) * x[m];      // x[m] = 0 for m < c
+            x[i] = i < lane ? 0. : v / lane_value(r[i], i);
+        }
+        // cov = X' X: lane a holds row a, cov[a][b] = sum_r X[r][a] X[r][b] (terms below max(a, b) are zero)
+        double cv[16];
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            double sum = 0.;
+#pragma unroll
+            for (int k = 0; k < 16; k++) sum += x[k] * lane_value(x[k], b);
+            cv[b] = sum;
+        }
+        // mean = cov rhs
+        const double rl = lane < d ? rhs[lane] : 0.;
+        double mn = 0.;
+#pragma unroll
+        for (int l = 0; l < 16; l++) mn += cv[l] * lane_value(rl, l);
+        // lower Cholesky of the covariance (identity outside d), then the draw
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (lane >= d || k >= d) cv[k] = k == lane ? 1. : 0.;
+        if (!chol_regs16(cv, lane)) {
+            if (lane == 0) atomicExch(status, 1);
+            return;
+        }
+        const double zl = lane < d ? z[(size_t)row * d + lane] : 0.;
+        double sum = 0.;
+#pragma unroll
+        for (int l = 0; l < 16; l++) {
+            const double t = fma(cv[l], lane_value(zl, l), sum);
+            sum = l <= lane ? t : sum;
+        }
+        if (lane < d) out[(size_t)row * d + lane] = sum + mn;
+        return;
+    }
     // A = R R'
     if (!chol_lds(A, d, lda, lane)) {
         if (lane == 0) atomicExch(status, 1);

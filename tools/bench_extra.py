@@ -65,7 +65,7 @@ np.random.seed(1)
 a = mn_active_pmf.MNActivePMF(ratings, latent_d=10)
 t0 = time.perf_counter(); a.do_fit(); out['pmf_do_fit_s_class'] = time.perf_counter() - t0
 a.initialize_approx(random_cov=True)
-a.cov_useritems /= (n + m)
+a.cov_useritems = a.cov_useritems / (n + m)
 pool = list(a.unrated)
 t0 = time.perf_counter()
 vals = a._get_key_vals(pool, mn_active_pmf.MNActivePMF.pred_variance, None, None)
