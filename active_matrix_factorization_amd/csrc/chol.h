@@ -415,14 +415,9 @@ static inline int chol_lower_jobs(apmf_ctx *ctx, const ChJobs &J, int njobs, int
     // diagonal block; many: the block in a launch of its own (and 4 update blocks per CU)
     const bool next = njobs <= CH_FUSE_JOBS;
     constexpr size_t next_lds = 2 * (size_t)CH_NB * TP * sizeof(double);
-    if (next) {
-        static bool attr_set = false;       // per translation unit; setting it again is harmless
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)k_chol_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)next_lds);
-            attr_set = true;
-        }
-    }
+    if (next && next_lds > 64 * 1024)      // (67.6 KB; set per call: the attribute is per device)
+        (void)hipFuncSetAttribute((const void *)k_chol_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)next_lds);
     for (int k = 0; k < N; k += CH_NB) {
         const int nb = N - k < CH_NB ? N - k : CH_NB;
         if (k == 0 || !next) hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, ctx->stream, J, N, k);

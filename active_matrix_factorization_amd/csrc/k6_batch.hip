@@ -1794,11 +1794,16 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                     APMF_TRY(lane_post());
                 } else {
                     const int device = ctx->device;
-                    lane_thr = std::thread([&, device]() {
-                        (void)hipSetDevice(device);
+                    try {
+                        lane_thr = std::thread([&, device]() {
+                            (void)hipSetDevice(device);
+                            lane_rs = slow_S_solve(b->R, lane_w);
+                            lane_enq.store(1, std::memory_order_release);
+                        });
+                    } catch (...) {              // no thread to be had: issue the call from here
                         lane_rs = slow_S_solve(b->R, lane_w);
                         lane_enq.store(1, std::memory_order_release);
-                    });
+                    }
                 }
             } else {
                 APMF_TRY(handle_slow(b, parked, true, min_eig, sigma_sq, sigma_u_sq));
