@@ -557,7 +557,7 @@ def test_gibbs_half_sweep(ctx, name):
     np.testing.assert_allclose(out.to_host()[0], g['sf_out'], rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize('d', [1, 3, 10, 11, 22, 23, 32, 33, 46, 47, 64])
+@pytest.mark.parametrize('d', [1, 3, 10, 11, 15, 16, 17, 22, 23, 32, 33, 46, 47, 64])
 def test_gibbs_all_d(ctx, d):
     rs = np.random.RandomState(d)
     n, m, N = 9, 12, 150
@@ -614,7 +614,8 @@ def test_sample_stats_golden(ctx, name):
 
 
 @pytest.mark.parametrize('shape', [(1, 1, 1, 1), (3, 5, 70, 2), (8, 33, 65, 5), (16, 47, 130, 15), (5, 32, 64, 16),
-                                   (4, 70, 31, 17), (3, 20, 40, 33), (6, 95, 129, 64)])
+                                   (4, 70, 31, 17), (3, 20, 40, 33), (6, 95, 129, 64), (4, 40, 70, 12), (3, 50, 66, 24),
+                                   (2, 33, 65, 49)])
 def test_sample_stats_shapes_vs_oracle(ctx, shape):
     """K4 over every staging bucket (d = 1 .. 64, power-of-two d included: rotated LDS rows),
     ragged tiles and S = 1, against the oracle's sample-by-sample restatement."""
