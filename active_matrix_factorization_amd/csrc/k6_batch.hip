@@ -1062,22 +1062,36 @@ int dp6_for(int d)
 } // namespace
 
 // ---- the batch object -------------------------------------------------------------------------------------
-constexpr int SEL_SLOTS = 5;       // 0 active, 1 gradient, 2 scratch (synchronous paths), 3 / 4 slow lane
+constexpr int MAX_LANES = 4;
+constexpr int SEL_SLOTS = 3 + 2 * (MAX_LANES + 1);   // 0 active, 1 gradient, 2 scratch, then two per eigen set
+
+// What one eigen-projection pass works with: index 0 is the synchronous set (main stream, the
+// context's rocBLAS handle), 1 .. nlanes the slow lanes - a stream, an event, a handle and a worker
+// thread each, so that several passes can be in flight beside the fast path.
+struct EigSet {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    void *handle = nullptr;            // rocblas_handle, created at the first pass
+    double **ptrs = nullptr;           // [H]
+    double *evals = nullptr, *evE = nullptr;   // [H][N]
+    int *evinfo = nullptr;             // [H]
+    ChJob *jobs = nullptr;             // [H] job list of the re-factorisations
+    int slot0 = 0;                     // selection-list slots slot0, slot0 + 1
+};
 
 struct apmf_mn_batch {
     apmf_ctx *ctx;
     const apmf_ratings *r;
     Refs R;                       // device pointers
-    void *blocks[32];             // every device allocation, for destroy
+    void *blocks[64];             // every device allocation, for destroy
     int nblocks;
     HypState *hs_host;            // pinned mirror
     int *sel_host;                // pinned, SEL_SLOTS * H ints
     int *sel_dev;                 // SEL_SLOTS * H ints
-    // the slow lane: eigen-projections of parked hypotheses run on a second stream, beside the fast
-    // path of the others
-    hipStream_t aux;
-    hipEvent_t ev_lane;
-    ChJob *jobs2;                 // [H] job list of the lane's re-factorisations
+    // the slow lanes: eigen-projections of parked hypotheses run on streams of their own, beside the
+    // fast path of the others
+    EigSet eig[MAX_LANES + 1];
+    int nlanes;
     std::vector<char> fvalid;     // F holds the factor of the current cov_useritems
     std::vector<char> fvalid_cand;
     std::vector<char> oivalid;    // OI_CUR holds the inverse of the current cov_latents
@@ -1189,12 +1203,26 @@ struct SlowS {
     void *handle = nullptr;
 };
 
-int slow_S_pre(apmf_mn_batch *b, const std::vector<int> &list, const std::vector<int> &masks, int slot0, SlowS &w)
+// the batch's device references with the eigen buffers of one set
+Refs set_refs(const apmf_mn_batch *b, const EigSet &e)
 {
-    const Refs &R = b->R;
+    Refs R = b->R;
+    R.ptrs = e.ptrs;
+    R.evals = e.evals;
+    R.evE = e.evE;
+    R.evinfo = e.evinfo;
+    return R;
+}
+
+// handle: bound to the current stream by the caller
+int slow_S_pre(apmf_mn_batch *b, const EigSet &e, void *handle, const std::vector<int> &list,
+               const std::vector<int> &masks, SlowS &w)
+{
+    const Refs R = set_refs(b, e);
     hipStream_t st = b->ctx->stream;
     w.proj.clear();
     w.refac.clear();
+    w.handle = handle;
     for (size_t q = 0; q < list.size(); q++) {
         if (masks[q] & SLOW_CERT_S) w.proj.push_back(list[q]);
         if (masks[q] & (SLOW_CERT_S | SLOW_FACT_S)) w.refac.push_back(list[q]);
@@ -1203,11 +1231,10 @@ int slow_S_pre(apmf_mn_batch *b, const std::vector<int> &list, const std::vector
     const size_t nn = (size_t)R.N * R.N;
     const int np = (int)w.proj.size();
     const int *dsel;
-    APMF_TRY(upload_sel(b, slot0, w.proj, &dsel));
+    APMF_TRY(upload_sel(b, e.slot0, w.proj, &dsel));
     hipLaunchKernelGGL(kb_copy, g2(nn, np, 256), dim3(256), 0, st, R, dsel, (int)T_S_CAND, (int)T_S_W, nn);
     hipLaunchKernelGGL(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
     APMF_CHECK_LAUNCH();
-    APMF_TRY(apmf_dense_handle(b->ctx, &w.handle));      // binds the handle to the current stream
     return APMF_OK;
 }
 
@@ -1221,9 +1248,9 @@ rocblas_status slow_S_solve(const Refs &R, const SlowS &w)
                                     R.N, R.evals, R.N, R.evE, R.N, R.evinfo, (int)w.proj.size());
 }
 
-int slow_S_post(apmf_mn_batch *b, const SlowS &w, rocblas_status rs, bool trial, double min_eig, int slot0, ChJob *jobs)
+int slow_S_post(apmf_mn_batch *b, const EigSet &e, const SlowS &w, rocblas_status rs, bool trial, double min_eig)
 {
-    const Refs &R = b->R;
+    const Refs R = set_refs(b, e);
     hipStream_t st = b->ctx->stream;
     const int tS = trial ? T_S_CAND : T_S_CUR;
     const size_t nn = (size_t)R.N * R.N;
@@ -1232,7 +1259,7 @@ int slow_S_post(apmf_mn_batch *b, const SlowS &w, rocblas_status rs, bool trial,
         return APMF_EHIP;
     }
     if (!w.proj.empty()) {
-        const int *dsel = b->sel_dev + (size_t)slot0 * R.H;      // uploaded by slow_S_pre
+        const int *dsel = b->sel_dev + (size_t)e.slot0 * R.H;      // uploaded by slow_S_pre
         hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, (int)w.proj.size()), dim3(256), 0, st, R, dsel,
                            min_eig);
         APMF_CHECK_LAUNCH();
@@ -1240,28 +1267,31 @@ int slow_S_post(apmf_mn_batch *b, const SlowS &w, rocblas_status rs, bool trial,
     if (!w.refac.empty()) {
         const int nr = (int)w.refac.size();
         const int *dsel;
-        APMF_TRY(upload_sel(b, slot0 + 1, w.refac, &dsel));
+        APMF_TRY(upload_sel(b, e.slot0 + 1, w.refac, &dsel));
         hipLaunchKernelGGL(kb_copy, g2(nn, nr, 256), dim3(256), 0, st, R, dsel, tS, (int)T_S_F, nn);
         APMF_CHECK_LAUNCH();
-        APMF_TRY(launch_factor(b, dsel, nr, 1, jobs));
+        APMF_TRY(launch_factor(b, dsel, nr, 1, e.jobs));
     }
     return APMF_OK;
 }
 
+// the synchronous form: set 0, the context's handle, the current stream
 int slow_S_enqueue(apmf_mn_batch *b, const std::vector<int> &list, const std::vector<int> &masks, bool trial,
-                   double min_eig, int slot0, ChJob *jobs)
+                   double min_eig)
 {
     SlowS w;
-    APMF_TRY(slow_S_pre(b, list, masks, slot0, w));
-    return slow_S_post(b, w, slow_S_solve(b->R, w), trial, min_eig, slot0, jobs);
+    void *hv = nullptr;
+    APMF_TRY(apmf_dense_handle(b->ctx, &hv));      // binds the handle to the current stream
+    APMF_TRY(slow_S_pre(b, b->eig[0], hv, list, masks, w));
+    return slow_S_post(b, b->eig[0], w, slow_S_solve(set_refs(b, b->eig[0]), w), trial, min_eig);
 }
 
 // Host side of the same, once the enqueued work has completed: convergence of the eigensolver, LU
 // fallback for a factorisation that still fails, and the (rare) d x d parts through dense.hip.
-int slow_finish(apmf_mn_batch *b, const std::vector<int> &list, const std::vector<int> &masks, bool trial,
-                double min_eig)
+int slow_finish(apmf_mn_batch *b, const EigSet &e, const std::vector<int> &list, const std::vector<int> &masks,
+                bool trial, double min_eig)
 {
-    const Refs &R = b->R;
+    const Refs R = set_refs(b, e);
     const int H = R.H, N = R.N, d = R.d;
     const int tS = trial ? T_S_CAND : T_S_CUR, tO = trial ? T_O_CAND : T_O_CUR, tOI = trial ? T_OI_CAND : T_OI_CUR;
     int np = 0;
@@ -1316,8 +1346,8 @@ int slow_fix_all(apmf_mn_batch *b, const std::vector<int> &slow, bool trial, dou
 {
     std::vector<int> masks;
     for (int h : slow) masks.push_back(b->hs_host[h].slow);
-    APMF_TRY(slow_S_enqueue(b, slow, masks, trial, min_eig, 3, b->jobs2));
-    return slow_finish(b, slow, masks, trial, min_eig);
+    APMF_TRY(slow_S_enqueue(b, slow, masks, trial, min_eig));
+    return slow_finish(b, b->eig[0], slow, masks, trial, min_eig);
 }
 
 // after a batch of evaluations: deal with the hypotheses that left the fast path, then decide them
@@ -1400,8 +1430,13 @@ int apmf_mn_batch_destroy(apmf_ctx *ctx, apmf_mn_batch *b)
     (void)ctx;
     (void)hipStreamSynchronize(b->ctx->stream);
     for (int i = 0; i < b->nblocks; i++) (void)apmf_free(b->ctx, b->blocks[i]);
-    if (b->aux) { (void)hipStreamSynchronize(b->aux); (void)hipStreamDestroy(b->aux); }
-    if (b->ev_lane) (void)hipEventDestroy(b->ev_lane);
+    for (int l = 1; l <= MAX_LANES; l++) {
+        EigSet &e = b->eig[l];
+        if (e.stream) (void)hipStreamSynchronize(e.stream);
+        if (e.handle) (void)rocblas_destroy_handle((rocblas_handle)e.handle);
+        if (e.stream) (void)hipStreamDestroy(e.stream);
+        if (e.ev) (void)hipEventDestroy(e.ev);
+    }
     if (b->hs_host) (void)hipHostFree(b->hs_host);
     if (b->sel_host) (void)hipHostFree(b->sel_host);
     delete b;
@@ -1423,9 +1458,7 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     b->nblocks = 0;
     b->hs_host = nullptr;
     b->sel_host = nullptr;
-    b->aux = nullptr;
-    b->ev_lane = nullptr;
-    b->jobs2 = nullptr;
+    b->nlanes = 0;
     Refs &R = b->R;
     memset(&R, 0, sizeof(R));
     R.H = H; R.n = r->n; R.m = r->m; R.d = d; R.N = r->n + r->m;
@@ -1456,23 +1489,38 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     BA(R.part, (size_t)H * R.n * 3 * sizeof(double));
     BA(R.out4, (size_t)H * 4 * sizeof(double));
     BA(R.oc, (size_t)H * sizeof(OmegaConsts));
-    BA(R.ptrs, (size_t)H * sizeof(double *));
-    BA(R.evals, (size_t)H * N * sizeof(double));
-    BA(R.evE, (size_t)H * N * sizeof(double));
-    BA(R.evinfo, (size_t)H * sizeof(int));
+    // eigen sets: the synchronous one and one per slow lane: a lane per ~4 hypotheses, at most 3 (measured at
+    // H = 10, 94 x 425: 1 lane 2.15 s, 2: 2.00 s, 3: 1.84 s, 4: 2.52 s - concurrent passes of ~3000 small
+    // kernels each slow one another and the main stream down)
+    b->nlanes = std::max(1, std::min(3, (H + 3) / 4));
+    if (const char *e = getenv("APMF_BATCH_LANES")) b->nlanes = std::max(1, std::min(MAX_LANES, atoi(e)));
+    for (int l = 0; l <= b->nlanes; l++) {
+        EigSet &e = b->eig[l];
+        e.slot0 = 3 + 2 * l;
+        BA(e.ptrs, (size_t)H * sizeof(double *));
+        BA(e.evals, (size_t)H * N * sizeof(double));
+        BA(e.evE, (size_t)H * N * sizeof(double));
+        BA(e.evinfo, (size_t)H * sizeof(int));
+        BA(e.jobs, (size_t)H * sizeof(ChJob));
+    }
+    R.ptrs = b->eig[0].ptrs;
+    R.evals = b->eig[0].evals;
+    R.evE = b->eig[0].evE;
+    R.evinfo = b->eig[0].evinfo;
     BA(R.trace, (size_t)H * (trace_cap ? trace_cap : 1) * sizeof(double));
     BA(R.ei, (size_t)H * sizeof(int));
     BA(R.ej, (size_t)H * sizeof(int));
     BA(R.ev, (size_t)H * sizeof(double));
     BA(b->sel_dev, (size_t)SEL_SLOTS * H * sizeof(int));
-    BA(b->jobs2, (size_t)H * sizeof(ChJob));
 #undef BA
     if (rc == APMF_OK && hipHostMalloc((void **)&b->hs_host, (size_t)H * sizeof(HypState), hipHostMallocDefault) != hipSuccess)
         rc = APMF_ENOMEM;
     if (rc == APMF_OK && hipHostMalloc((void **)&b->sel_host, (size_t)SEL_SLOTS * H * sizeof(int), hipHostMallocDefault) != hipSuccess)
         rc = APMF_ENOMEM;
-    if (rc == APMF_OK && hipStreamCreateWithFlags(&b->aux, hipStreamNonBlocking) != hipSuccess) rc = APMF_EHIP;
-    if (rc == APMF_OK && hipEventCreateWithFlags(&b->ev_lane, hipEventDisableTiming) != hipSuccess) rc = APMF_EHIP;
+    for (int l = 1; l <= b->nlanes && rc == APMF_OK; l++) {
+        if (hipStreamCreateWithFlags(&b->eig[l].stream, hipStreamNonBlocking) != hipSuccess) rc = APMF_EHIP;
+        if (rc == APMF_OK && hipEventCreateWithFlags(&b->eig[l].ev, hipEventDisableTiming) != hipSuccess) rc = APMF_EHIP;
+    }
     if (rc != APMF_OK) {
         if (rc == APMF_ENOMEM) apmf_set_error("out of memory for a batch of %d hypotheses (N=%zu)", H, N);
         apmf_mn_batch_destroy(ctx, b);
@@ -1615,7 +1663,6 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     b->st_slow[0] = b->st_slow[1] = b->st_slow[2] = b->st_slow[3] = 0;
     b->st_slow_s = b->st_lane_s = 0.;
     b->st_lane_passes = b->st_lane_hyps = 0;
-    std::chrono::steady_clock::time_point t_lane;
     const auto t_fit = std::chrono::steady_clock::now();
     // a hypothesis whose KL is known AND whose factor / inverse are in place resumes directly
     std::vector<int> init;
@@ -1648,36 +1695,42 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     // independent, so the order in which they advance changes nothing.  APMF_BATCH_ASYNC=0: the
     // parked hypotheses are dealt with on the main stream instead (debugging).
     const bool use_lane = !(getenv("APMF_BATCH_ASYNC") && getenv("APMF_BATCH_ASYNC")[0] == '0');
-    std::vector<int> active, grad, parked, decided, lane, lane_masks, osync;
+    std::vector<int> active, grad, parked, decided, osync;
     std::vector<char> is_parked(H, 0);
-    bool lane_busy = false;
-    // lane_busy with lane_solving: the worker thread is still inside rocSOLVER; lane_post() joins it and
-    // enqueues the rest of the pass behind the solver's kernels
-    bool lane_solving = false;
-    std::thread lane_thr;
-    std::atomic<int> lane_enq(0);
-    rocblas_status lane_rs = rocblas_status_success;
-    SlowS lane_w;
+    // One pass of a lane: busy from the moment it takes the parked hypotheses; `solving` while its worker
+    // thread is inside rocSOLVER - lane_post() then joins the thread and enqueues the rest of the pass
+    // behind the solver's kernels, after which the lane's event tells when the pass is over.
+    struct LanePass {
+        std::vector<int> list, masks;
+        SlowS w;
+        std::thread thr;
+        std::atomic<int> enq{0};
+        rocblas_status rs = rocblas_status_success;
+        bool busy = false, solving = false;
+        std::chrono::steady_clock::time_point t0;
+    };
+    const int NL = b->nlanes;
+    LanePass pass[MAX_LANES];
     struct Joiner {              // an early return must not leave a joinable thread behind
-        std::thread &t;
-        ~Joiner() { if (t.joinable()) t.join(); }
-    } joiner{lane_thr};
-    auto lane_post = [&]() -> int {
-        if (!lane_solving) return APMF_OK;
-        if (lane_thr.joinable()) lane_thr.join();
-        lane_solving = false;
+        LanePass *p;
+        ~Joiner() { for (int l = 0; l < MAX_LANES; l++) if (p[l].thr.joinable()) p[l].thr.join(); }
+    } joiner{pass};
+    auto any_busy = [&]() {
+        for (int l = 0; l < NL; l++) if (pass[l].busy) return true;
+        return false;
+    };
+    auto lane_post = [&](int l) -> int {
+        LanePass &P = pass[l];
+        if (!P.solving) return APMF_OK;
+        if (P.thr.joinable()) P.thr.join();
+        P.solving = false;
+        const EigSet &e = b->eig[l + 1];
         hipStream_t saved = ctx->stream;
-        ctx->stream = b->aux;
-        int rc = slow_S_post(b, lane_w, lane_rs, true, min_eig, 3, b->jobs2);
-        if (rc == APMF_OK && hipEventRecord(b->ev_lane, b->aux) != hipSuccess) rc = APMF_EHIP;
+        ctx->stream = e.stream;
+        int rc = slow_S_post(b, e, P.w, P.rs, true, min_eig);
+        if (rc == APMF_OK && hipEventRecord(e.ev, e.stream) != hipSuccess) rc = APMF_EHIP;
         ctx->stream = saved;
         return rc;
-    };
-    auto lane_wait = [&]() -> int {
-        if (!lane_busy) return APMF_OK;
-        APMF_TRY(lane_post());
-        (void)hipEventSynchronize(b->ev_lane);
-        return APMF_OK;
     };
     auto finish_decided = [&](const std::vector<int> &list) {
         // F holds the factor of the trial point: the current one's only if the trial was accepted
@@ -1691,35 +1744,41 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 active.push_back(h);
                 if (b->hs_host[h].need_grad) grad.push_back(h);
             }
-        if (lane_busy) {
-            if (lane_solving && (lane_enq.load(std::memory_order_acquire) || active.empty())) APMF_TRY(lane_post());
-            bool done = !lane_solving && hipEventQuery(b->ev_lane) == hipSuccess;
+        bool returned = false;
+        for (int l = 0; l < NL; l++) {
+            LanePass &P = pass[l];
+            if (!P.busy) continue;
+            const EigSet &e = b->eig[l + 1];
+            // nothing else to do: wait for the first busy lane instead of spinning
+            const bool idle = active.empty() && !returned;
+            if (P.solving && (P.enq.load(std::memory_order_acquire) || idle)) APMF_TRY(lane_post(l));
+            bool done = !P.solving && hipEventQuery(e.ev) == hipSuccess;
             (void)hipGetLastError();             // hipErrorNotReady is not an error
-            if (!done && active.empty()) {
-                APMF_CHECK_HIP(hipEventSynchronize(b->ev_lane));
+            if (!done && idle) {
+                APMF_CHECK_HIP(hipEventSynchronize(e.ev));
                 done = true;
             }
-            if (done) {
-                const auto t0 = std::chrono::steady_clock::now();
-                APMF_CHECK_HIP(hipStreamWaitEvent(st, b->ev_lane, 0));
-                APMF_TRY(slow_finish(b, lane, lane_masks, true, min_eig));
-                const int *dsel;
-                APMF_TRY(upload_sel(b, 2, lane, &dsel));
-                APMF_TRY(launch_value(b, dsel, (int)lane.size(), T_M_CAND, T_S_CAND, T_O_CAND, 0, 1, sigma_sq,
-                                      sigma_u_sq));
-                APMF_TRY(read_status(b));
-                finish_decided(lane);
-                for (int h : lane) is_parked[h] = 0;
-                b->st_lane_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_lane).count();
-                b->st_lane_passes++;
-                b->st_lane_hyps += (long)lane.size();
-                lane.clear();
-                lane_busy = false;
-                b->st_slow_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                continue;                        // rebuild the active list with the returned hypotheses
-            }
+            if (!done) continue;
+            const auto t0 = std::chrono::steady_clock::now();
+            APMF_CHECK_HIP(hipStreamWaitEvent(st, e.ev, 0));
+            APMF_TRY(slow_finish(b, e, P.list, P.masks, true, min_eig));
+            const int *dsel;
+            APMF_TRY(upload_sel(b, 2, P.list, &dsel));
+            APMF_TRY(launch_value(b, dsel, (int)P.list.size(), T_M_CAND, T_S_CAND, T_O_CAND, 0, 1, sigma_sq,
+                                  sigma_u_sq));
+            APMF_TRY(read_status(b));
+            finish_decided(P.list);
+            for (int h : P.list) is_parked[h] = 0;
+            b->st_lane_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - P.t0).count();
+            b->st_lane_passes++;
+            b->st_lane_hyps += (long)P.list.size();
+            P.list.clear();
+            P.busy = false;
+            b->st_slow_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            returned = true;
         }
-        if (active.empty() && parked.empty() && !lane_busy) break;
+        if (returned) continue;              // rebuild the active list with the returned hypotheses
+        if (active.empty() && parked.empty() && !any_busy()) break;
         decided.clear();
         osync.clear();
         if (!active.empty()) {
@@ -1727,9 +1786,6 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             b->st_trials += (long)active.size();
             b->st_grads += (long)grad.size();
             if (!grad.empty()) {
-                bool need_sync = false;
-                for (int h : grad) need_sync |= !b->fvalid[h];
-                if (need_sync) APMF_TRY(lane_wait());      // the LU route of such a gradient uses rocSOLVER too
                 APMF_TRY(launch_gradient(b, grad, sigma_sq, sigma_u_sq, sigma_v_sq));
             }
             const int na = (int)active.size();
@@ -1767,42 +1823,56 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             }
         }
         if (!osync.empty()) {
-            APMF_TRY(lane_wait());
             APMF_TRY(handle_slow(b, osync, true, min_eig, sigma_sq, sigma_u_sq));
             for (int h : osync) decided.push_back(h);
         }
-        if (!parked.empty() && !lane_busy) {
+        int free_lane = -1;
+        for (int l = 0; l < NL && free_lane < 0; l++) if (!pass[l].busy) free_lane = l;
+        if (!parked.empty() && (free_lane >= 0 || !use_lane)) {
             const auto t0 = std::chrono::steady_clock::now();
             if (use_lane) {
-                lane.swap(parked);
+                LanePass &P = pass[free_lane];
+                EigSet &e = b->eig[free_lane + 1];
+                P.list.swap(parked);
                 parked.clear();
-                lane_masks.clear();
-                for (int h : lane) lane_masks.push_back(b->hs_host[h].slow);
+                P.masks.clear();
+                for (int h : P.list) P.masks.push_back(b->hs_host[h].slow);
+                if (!e.handle) {
+                    rocblas_handle hnd = nullptr;
+                    if (rocblas_create_handle(&hnd) != rocblas_status_success ||
+                        rocblas_set_stream(hnd, e.stream) != rocblas_status_success) {
+                        apmf_set_error("rocblas_create_handle failed for a slow lane");
+                        return APMF_EHIP;
+                    }
+                    e.handle = hnd;
+                }
                 // the main stream is idle here (read_status synchronised it): the lane may start at once
                 hipStream_t saved = ctx->stream;
-                ctx->stream = b->aux;
-                int rc = slow_S_pre(b, lane, lane_masks, 3, lane_w);
+                ctx->stream = e.stream;
+                int rc = slow_S_pre(b, e, e.handle, P.list, P.masks, P.w);
                 ctx->stream = saved;
                 if (rc != APMF_OK) return rc;
-                lane_enq.store(0, std::memory_order_relaxed);
-                lane_solving = true;
-                lane_busy = true;
-                t_lane = std::chrono::steady_clock::now();
-                if (lane_w.proj.empty()) {
-                    lane_rs = rocblas_status_success;
-                    lane_enq.store(1, std::memory_order_release);
-                    APMF_TRY(lane_post());
+                P.enq.store(0, std::memory_order_relaxed);
+                P.solving = true;
+                P.busy = true;
+                P.t0 = std::chrono::steady_clock::now();
+                if (P.w.proj.empty()) {
+                    P.rs = rocblas_status_success;
+                    P.enq.store(1, std::memory_order_release);
+                    APMF_TRY(lane_post(free_lane));
                 } else {
                     const int device = ctx->device;
+                    const Refs RL = set_refs(b, e);
+                    LanePass *pp = &P;
                     try {
-                        lane_thr = std::thread([&, device]() {
+                        P.thr = std::thread([pp, RL, device]() {
                             (void)hipSetDevice(device);
-                            lane_rs = slow_S_solve(b->R, lane_w);
-                            lane_enq.store(1, std::memory_order_release);
+                            pp->rs = slow_S_solve(RL, pp->w);
+                            pp->enq.store(1, std::memory_order_release);
                         });
                     } catch (...) {              // no thread to be had: issue the call from here
-                        lane_rs = slow_S_solve(b->R, lane_w);
-                        lane_enq.store(1, std::memory_order_release);
+                        P.rs = slow_S_solve(RL, P.w);
+                        P.enq.store(1, std::memory_order_release);
                     }
                 }
             } else {
