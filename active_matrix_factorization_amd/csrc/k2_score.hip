@@ -111,18 +111,43 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
     {
         const int nreal = max(0, min(R, n + m - t0));
         const T *src = mean + ((size_t)b * (n + m) + t0) * d;
-        for (int e = threadIdx.x; e < nreal * d; e += R) {
-            const int r = e / d, k = e - r * d;
-            sA[r * st + k] = src[e];
+        const int total = nreal * d;
+        if (DT > 0 && total > 0) {      // (a block of padding columns only has nothing to stage: src is past the array)
+            // all of the thread's elements requested before the first is stored (a plain loop is one
+            // round trip per element: d of them in a row)
+            T v[DT > 0 ? DT : 1];
+#pragma unroll
+            for (int it = 0; it < DT; it++) {
+                const int e = (int)threadIdx.x + it * R;
+                v[it] = src[e < total ? e : 0];
+            }
+#pragma unroll
+            for (int it = 0; it < DT; it++) {
+                const int e = (int)threadIdx.x + it * R;
+                if (it < d && e < total) {
+                    const int r = e / d, k = e - r * d;
+                    sA[r * st + k] = v[it];
+                }
+            }
+        } else if (DT == 0) {
+            for (int e = threadIdx.x; e < total; e += R) {
+                const int r = e / d, k = e - r * d;
+                sA[r * st + k] = src[e];
+            }
         }
     }
+    // block 0 of a state also reduces Omega to its two scalars: Omega staged in LDS first (read from
+    // global memory inside the loop, the d^2 dependent round trips made this block the kernel's tail)
+    T *sO = sA + (size_t)R * st;
+    if (blockIdx.x == 0)
+        for (int e = threadIdx.x; e < d * d; e += R) sO[e] = O[e];
     __syncthreads();
     if (t == 0) {
         T t2 = 0, tr = 0;
         for (int k = 0; k < d; k++) {
-            tr += O[k * d + k];
-            t2 += O[k * d + k] * O[k * d + k];
-            for (int l = k + 1; l < d; l++) t2 += 2 * O[k * d + l] * O[k * d + l];
+            tr += sO[k * d + k];
+            t2 += sO[k * d + k] * sO[k * d + k];
+            for (int l = k + 1; l < d; l++) t2 += 2 * sO[k * d + l] * sO[k * d + l];
         }
         state[2 * b] = t2;
         state[2 * b + 1] = tr;
@@ -1002,7 +1027,7 @@ int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_
     a.part_val = (T *)(a.part_idx + (size_t)B * nblk);
 
     const int prep_rows = d <= 16 ? 256 : 64;
-    const size_t prep_smem = (size_t)prep_rows * (size_t)(d | 1) * sizeof(T);
+    const size_t prep_smem = ((size_t)prep_rows * (size_t)(d | 1) + (size_t)d * d) * sizeof(T);   // rows + Omega
     const dim3 prep_grid((n + ld + prep_rows - 1) / prep_rows, B);
     if (d <= 4)
         hipLaunchKernelGGL((k_mn_prep<T, 4>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m, d,

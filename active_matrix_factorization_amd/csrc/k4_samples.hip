@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, in
             const bool isv = row >= BR;
             const int cr = isv ? row - BR : row;
             const bool ok = s_act && k_in && cr < (isv ? v_rows : u_rows);
-            const double x = (isv ? vb : ub)[ok ? cr * d + sk : 0];      // always a valid address
+            const double x = *(ok ? (isv ? vb : ub) + cr * d + sk : Us);   // always a valid address
             stg[it] = ok ? x : 0.;
         }
     };
