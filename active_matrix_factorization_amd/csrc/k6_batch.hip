@@ -622,17 +622,32 @@ __global__ __launch_bounds__(256) void kb_omega(const Refs R, const int *__restr
         }
         __syncthreads();
     }
-    if (threadIdx.x != 0) return;
     const double G = sh[0][0], SVV = sh[1][0], S2 = sh[2][0], RS = sh[3][0], AW = sh[4][0];
     const double TRU = sh[5][0], TRV = sh_trv[0];
+    // diagonal entries also need X = sum_i M[i][k] w_i[k], added in row order by one thread: its
+    // operands are fetched by the whole block, 256 rows at a time, and handed over through LDS (read
+    // from global memory inside the loop this was n dependent round trips: 10 us at n = 94)
+    double X = 0;
+    if (k == l) {                    // block-uniform
+        for (int base = 0; base < n; base += 256) {
+            __syncthreads();
+            const int i = base + (int)threadIdx.x;
+            sh[0][threadIdx.x] = i < n ? M[(size_t)i * d + k] : 0.;
+            sh[1][threadIdx.x] = i < n ? racc_u[(size_t)i * su + d + k] : 0.;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int cnt = min(256, n - base);
+                for (int q = 0; q < cnt; q++) X += sh[0][q] * sh[1][q];
+            }
+        }
+    }
+    if (threadIdx.x != 0) return;
     const double okl = O[k <= l ? k * d + l : l * d + k];
     double out;
     if (k != l) {
         out = inv_sig * (G + 2. * okl * (SVV + S2));
     } else {
         const double dgk = O[k * d + k];
-        double X = 0;
-        for (int i = 0; i < n; i++) X += M[(size_t)i * d + k] * racc_u[(size_t)i * su + d + k];
         const double Q = G - 2. * X;
         const double diag_q = AW - X + S2 * (oc.T - dgk);
         const double diag_s = .5 * (4. * X + 4. * S2 * dgk + Q + 2. * SVV * dgk);
