@@ -637,7 +637,7 @@ def test_sample_stats_shapes_vs_oracle(ctx, shape):
 
 
 # ---------------------------------------------------------------------------- dense (rocSOLVER)
-@pytest.mark.parametrize('N', [3, 17, 64, 200])
+@pytest.mark.parametrize('N', [3, 17, 63, 64, 65, 129, 200, 519])
 def test_dense_project_psd_and_inverse(ctx, N):
     rs = np.random.RandomState(N)
     a = rs.normal(size=(N, N))
