@@ -94,7 +94,7 @@ struct GridArgs {
 // wave-uniform operands (scalar loads); padding columns of colpack are zeroed.
 template <typename T, int DT>
 __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int D, int ld, int rs,
-                                                 int tiled, const T *__restrict__ mean,
+                                                 int tiled, int stage, const T *__restrict__ mean,
                                                  const T *__restrict__ diag,
                                                  const T *__restrict__ omega,
                                                  T *__restrict__ rowpack, T *__restrict__ colpack,
@@ -152,13 +152,18 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
         state[2 * b] = t2;
         state[2 * b + 1] = tr;
     }
-    if (t >= n + ld) return;
+    // stage (row-major user pack only): a thread's rs values go to LDS first and the block then writes
+    // its rows as one contiguous run - written directly, every store instruction of a wave scatters
+    // over 64 rows rs * sizeof(T) bytes apart
+    T *sP = sO + (size_t)d * d;
+    do {
+    if (t >= n + ld) break;
     const bool is_user = t < n;
     const int j = t - n;  // column when !is_user (may be padding >= m)
     T *cp = colpack + (size_t)b * (D + 2) * ld;
     if (!is_user && j >= m) {
         for (int k = 0; k < D + 2; k++) cp[(size_t)k * ld + j] = 0;
-        return;
+        break;
     }
     const T *a = sA + threadIdx.x * st;
     const T sd = diag[(size_t)b * (n + m) + t];
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
     // user pack: row-major [Oa | a | a'Oa | s_ii] with stride rs, or (tiled, for the matrix-core
     // sweep) tile-major transposed: tile t/32 holds (2D+2) x 32 floats [Oa | a'Oa | s_ii | a]
     T *rp = tiled ? rowpack + (((size_t)b * ((n + 31) >> 5) + (t >> 5)) * (2 * D + 2)) * 32 + (t & 31)
-                  : rowpack + ((size_t)b * n + t) * rs;
+                  : (stage ? sP + (size_t)threadIdx.x * (rs + 1) : rowpack + ((size_t)b * n + t) * rs);
     const size_t rstr = tiled ? 32 : 1;
     const int pos_a = tiled ? D + 2 : D, pos_q = tiled ? D : 2 * D;
     if (DT > 0) {
@@ -216,6 +221,13 @@ __global__ __launch_bounds__(256) void k_mn_prep(int B, int n, int m, int d, int
     } else {
         cp[(size_t)D * ld + j] = quad;
         cp[(size_t)(D + 1) * ld + j] = sd;
+    }
+    } while (0);
+    if (stage && !tiled) {           // block-uniform
+        __syncthreads();
+        const int nuser = max(0, min(R, n - t0));
+        T *dst = rowpack + ((size_t)b * n + t0) * rs;
+        for (int e = threadIdx.x; e < nuser * rs; e += R) dst[e] = sP[(size_t)(e / rs) * (rs + 1) + e % rs];
     }
 }
 
@@ -1027,20 +1039,24 @@ int mn_score_grid(apmf_ctx *ctx, int B, int n, int m, int d, int ld, const T *d_
     a.part_val = (T *)(a.part_idx + (size_t)B * nblk);
 
     const int prep_rows = d <= 16 ? 256 : 64;
-    const size_t prep_smem = ((size_t)prep_rows * (size_t)(d | 1) + (size_t)d * d) * sizeof(T);   // rows + Omega
+    size_t prep_smem = ((size_t)prep_rows * (size_t)(d | 1) + (size_t)d * d) * sizeof(T);   // rows + Omega
+    // + the staged row-major user pack, when it fits the default 64 KB
+    const size_t stage_bytes = (size_t)prep_rows * (rs + 1) * sizeof(T);
+    const int stage = (!mfma && prep_smem + stage_bytes <= 64 * 1024) ? 1 : 0;
+    if (stage) prep_smem += stage_bytes;
     const dim3 prep_grid((n + ld + prep_rows - 1) / prep_rows, B);
     if (d <= 4)
         hipLaunchKernelGGL((k_mn_prep<T, 4>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m, d,
-                           D, ld, rs, (int)mfma, d_mean, d_diag, d_omega, rowpack, colpack, state);
+                           D, ld, rs, (int)mfma, stage, d_mean, d_diag, d_omega, rowpack, colpack, state);
     else if (d <= 10)
         hipLaunchKernelGGL((k_mn_prep<T, 10>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m,
-                           d, D, ld, rs, (int)mfma, d_mean, d_diag, d_omega, rowpack, colpack, state);
+                           d, D, ld, rs, (int)mfma, stage, d_mean, d_diag, d_omega, rowpack, colpack, state);
     else if (d <= 16)
         hipLaunchKernelGGL((k_mn_prep<T, 16>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m,
-                           d, D, ld, rs, (int)mfma, d_mean, d_diag, d_omega, rowpack, colpack, state);
+                           d, D, ld, rs, (int)mfma, stage, d_mean, d_diag, d_omega, rowpack, colpack, state);
     else
         hipLaunchKernelGGL((k_mn_prep<T, 0>), prep_grid, dim3(prep_rows), prep_smem, ctx->stream, B, n, m, d,
-                           D, ld, rs, (int)mfma, d_mean, d_diag, d_omega, rowpack, colpack, state);
+                           D, ld, rs, (int)mfma, stage, d_mean, d_diag, d_omega, rowpack, colpack, state);
     APMF_CHECK_LAUNCH();
     const uint16_t *maskT = nullptr;
     if (d_mask && (want != 0 || d_sum)) {
