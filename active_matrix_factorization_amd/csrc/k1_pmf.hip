@@ -435,16 +435,17 @@ __global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, 
     K1_START();
 
     // ---- (0) requested before the decision is known ----------------------------------------
-    // partials of the previous launch (wave 0; zeros before the first trial)
+    // partials of the previous launch (zeros before the first trial): the block's waves take every
+    // NW-th group of 64 each, all loads of a chunk in flight together (a plain loop is one round trip
+    // per 64 partials)
     double a0 = 0., a1 = 0., a2 = 0.;
-    if (wave == 0) {
-        // all loads of a chunk in flight together (a plain loop is one round trip per 64 partials)
+    {
         constexpr int CH = 8;
-        for (int base = 0; base < nparts_in; base += 64 * CH) {
+        for (int base = wave * 64; base < nparts_in; base += NW * 64 * CH) {
             double v0[CH], v1[CH], v2[CH];
 #pragma unroll
             for (int q = 0; q < CH; q++) {
-                const int t = base + q * 64 + lane;
+                const int t = base + q * NW * 64 + lane;
                 const int tc = t < nparts_in ? t : 0;
                 v0[q] = part_in[tc];
                 v1[q] = part_in[FIT_GRID_MAX + tc];
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, 
             }
 #pragma unroll
             for (int q = 0; q < CH; q++) {
-                const bool in = base + q * 64 + lane < nparts_in;
+                const bool in = base + q * NW * 64 + lane < nparts_in;
                 a0 += in ? v0[q] : 0.;
                 a1 += in ? v1[q] : 0.;
                 a2 += in ? v2[q] : 0.;
@@ -500,14 +501,14 @@ __global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, 
     // ---- (1) the decision on the trial of the previous launch ---------------------------------
     FitState s = *st_in;
     if (s.pending) {          // block-uniform
-        if (wave == 0) {
-            a0 = wave_sum(a0);
-            a1 = wave_sum(a1);
-            a2 = wave_sum(a2);
-            if (lane == 0) { sh_p[0][0] = a0; sh_p[0][1] = a1; sh_p[0][2] = a2; }
-        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        if (lane == 0) { sh_p[wave][0] = a0; sh_p[wave][1] = a1; sh_p[wave][2] = a2; }
         __syncthreads();
-        const double b0 = sh_p[0][0], b1 = sh_p[0][1], b2 = sh_p[0][2];
+        double b0 = sh_p[0][0], b1 = sh_p[0][1], b2 = sh_p[0][2];
+#pragma unroll
+        for (int w = 1; w < NW; w++) { b0 += sh_p[w][0]; b1 += sh_p[w][1]; b2 += sh_p[w][2]; }
         __syncthreads();      // sh_p is reused for the partials of this launch
         const double ll = -b0 / (2. * sig) - b1 / (2. * p.sig_u) - b2 / (2. * p.sig_v);
         const bool first = blockIdx.x == 0 && threadIdx.x == 0;
