@@ -22,6 +22,7 @@
 namespace {
 
 constexpr int HY_MAXD = 32;
+constexpr int HY_STAGE = 4096;   // doubles of the feature matrix staged per pass (a multiple of 8 rows)
 
 __device__ __forceinline__ void philox7(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
 {
@@ -87,6 +88,72 @@ __device__ bool chol_block(double *A, int d, int P, int t)
     return ok;
 }
 
+// lane `src` 's value of a wave-resident double, as a wave-uniform value
+__device__ __forceinline__ double lane_value7(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// d <= 16: the same two helpers with the matrix in the REGISTERS of wave 0 (lane = row, other lanes'
+// entries by v_readlane; the same operations on every element in the same order).  The LDS loops
+// below are chains of dependent LDS round trips - 22 us per 15 x 15 factorisation, and this kernel
+// runs five of them and three inversions.
+__device__ bool chol_block16(double *A, int d, int P, int t)
+{
+    __shared__ int s_ok;
+    __syncthreads();
+    if (t < 64) {
+        double r[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) r[k] = (t < d && k < d) ? A[t * P + k] : (k == t ? 1. : 0.);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double piv = lane_value7(r[j], j);
+            ok = ok && piv > 0.;
+            const double sq = sqrt(piv);
+            r[j] = t == j ? sq : r[j] / sq;
+#pragma unroll
+            for (int c = j + 1; c < 16; c++) r[c] -= r[j] * lane_value7(r[j], c);
+        }
+        if (t < d)
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k <= t) A[t * P + k] = r[k];
+        if (t == 0) s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+__device__ void inv_from_chol16(const double *L, double *Ainv, int d, int P, int t)
+{
+    __syncthreads();
+    if (t < 64) {
+        double r[16], x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) r[k] = (t < d && k <= t) ? L[t * P + k] : (k == t ? 1. : 0.);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {       // lane c owns column c of X = L^-1
+            double v = i == t ? 1. : 0.;
+#pragma unroll
+            for (int m = 0; m < i; m++) v -= lane_value7(r[m], i) * x[m];
+            x[i] = i < t ? 0. : v / lane_value7(r[i], i);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {       // (X' X)[t][j]; terms below max(t, j) are zero
+            double v = 0.;
+#pragma unroll
+            for (int k = 0; k < 16; k++) v += x[k] * lane_value7(x[k], j);
+            if (t < d && j < d) Ainv[t * P + j] = v;
+        }
+    }
+    __syncthreads();
+}
+
 // Ainv <- (L L')^-1 from the lower factor in L; X is scratch
 __device__ void inv_from_chol(const double *L, double *X, double *Ainv, int d, int P, int t)
 {
@@ -107,6 +174,17 @@ __device__ void inv_from_chol(const double *L, double *X, double *Ainv, int d, i
     __syncthreads();
 }
 
+__device__ __forceinline__ bool chol_any(double *A, int d, int P, int t)
+{
+    return d <= 16 ? chol_block16(A, d, P, t) : chol_block(A, d, P, t);
+}
+
+__device__ __forceinline__ void inv_any(const double *L, double *X, double *Ainv, int d, int P, int t)
+{
+    if (d <= 16) inv_from_chol16(L, Ainv, d, P, t);
+    else inv_from_chol(L, X, Ainv, d, P, t);
+}
+
 __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int N, int d,
                                                const double *__restrict__ W0, double b0, double df,
                                                const double *__restrict__ mu0,
@@ -123,12 +201,45 @@ __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int
     double *vec = T + d * P;           // d: z, then misc
     __shared__ int bad;
     if (t == 0) bad = 0;
+    // The two passes over the feature matrix go through LDS, HY_ROWS rows at a time: the block fetches a
+    // chunk with all its loads in flight (the next chunk while this one is summed) and the sums then
+    // walk LDS in the same row order as before.  Read from global memory inside the summation loops
+    // these were N dependent round trips per thread: 300 us of a 312 us kernel at N = 1682.
+    double *stage = vec + HY_MAXD;     // HY_ROWS x d
+    const int HY_ROWS = HY_STAGE / d / 8 * 8;
+    constexpr int SQ = HY_STAGE / 256;
+    double sv[SQ];
+    auto chunk_load = [&](int r0) {
+        const int lim = min(HY_ROWS, N - r0) * d;
+#pragma unroll
+        for (int q = 0; q < SQ; q++) {
+            const int e = t + 256 * q;
+            const double x = F[(size_t)r0 * d + (e < lim ? e : 0)];
+            sv[q] = e < lim ? x : 0.;
+        }
+    };
+    auto chunk_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < SQ; q++) {
+            const int e = t + 256 * q;
+            if (e < HY_ROWS * d) stage[e] = sv[q];
+        }
+    };
     // ---- x_bar: thread (g, k) sums rows g, g + 8, ... of column k
     {
         const int k = t & 31, g = t >> 5;
         double s = 0.;
-        if (k < d)
-            for (int r = g; r < N; r += 8) s += F[(size_t)r * d + k];
+        chunk_load(0);
+        for (int r0 = 0; r0 < N; r0 += HY_ROWS) {
+            __syncthreads();
+            chunk_store();
+            if (r0 + HY_ROWS < N) chunk_load(r0 + HY_ROWS);
+            __syncthreads();
+            const int rows = min(HY_ROWS, N - r0);
+            if (k < d)
+#pragma unroll 8
+                for (int rr = g; rr < rows; rr += 8) s += stage[rr * d + k];
+        }
         part[g * HY_MAXD + k] = s;
         __syncthreads();
         if (t < d) {
@@ -139,18 +250,40 @@ __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int
         __syncthreads();
     }
     // ---- N * S_bar = N / (N - 1) * sum (x - x_bar)(x - x_bar)'   into B
-    for (int e = t; e < d * d; e += 256) {
-        const int k = e / d, l = e % d;
-        const double xk = xbar[k], xl = xbar[l];
-        double s = 0.;
-        for (int r = 0; r < N; r++) s += (F[(size_t)r * d + k] - xk) * (F[(size_t)r * d + l] - xl);
-        B[k * P + l] = s / (N - 1.) * N;
+    {
+        const int k = t / d, l = t % d;          // d * d <= 1024: up to four entries per thread
+        double s4[4] = {0., 0., 0., 0.};
+        chunk_load(0);
+        for (int r0 = 0; r0 < N; r0 += HY_ROWS) {
+            __syncthreads();
+            chunk_store();
+            if (r0 + HY_ROWS < N) chunk_load(r0 + HY_ROWS);
+            __syncthreads();
+            const int rows = min(HY_ROWS, N - r0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = t + 256 * u;
+                if (e < d * d) {
+                    const int kk = u == 0 ? k : e / d, ll = u == 0 ? l : e % d;
+                    const double xk = xbar[kk], xl = xbar[ll];
+                    double s = s4[u];
+#pragma unroll 8
+                    for (int rr = 0; rr < rows; rr++) s += (stage[rr * d + kk] - xk) * (stage[rr * d + ll] - xl);
+                    s4[u] = s;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = t + 256 * u;
+            if (e < d * d) B[(e / d) * P + e % d] = s4[u] / (N - 1.) * N;
+        }
     }
     // ---- inv(W0) into A (via C, T)
     for (int e = t; e < d * d; e += 256) C[(e / d) * P + e % d] = W0[e];
     __syncthreads();
-    if (!chol_block(C, d, P, t) && t == 0) bad = 1;
-    inv_from_chol(C, T, A, d, P, t);
+    if (!chol_any(C, d, P, t) && t == 0) bad = 1;
+    inv_any(C, T, A, d, P, t);
     // ---- A <- inv(W0) + N S_bar + b0 N / (b0 + N) * <mu0 - x_bar, mu0 - x_bar>  (scalar, every element)
     double sc = 0.;
     for (int k = 0; k < d; k++) sc += (mu0[k] - xbar[k]) * (mu0[k] - xbar[k]);
@@ -161,15 +294,15 @@ __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int
     }
     __syncthreads();
     // ---- WI = inv(A); WI = WI / 2 + (WI / 2)'   into B
-    if (!chol_block(A, d, P, t) && t == 0) bad = 1;
-    inv_from_chol(A, T, C, d, P, t);
+    if (!chol_any(A, d, P, t) && t == 0) bad = 1;
+    inv_any(A, T, C, d, P, t);
     for (int e = t; e < d * d; e += 256) {
         const int k = e / d, l = e % d;
         B[k * P + l] = C[k * P + l] / 2. + C[l * P + k] / 2.;
     }
     __syncthreads();
     // ---- chol(WI) in B
-    if (!chol_block(B, d, P, t) && t == 0) bad = 1;
+    if (!chol_any(B, d, P, t) && t == 0) bad = 1;
     // ---- Bartlett factor T: variates supplied [chi (d) | normals (d (d - 1) / 2) | z (d)] or generated
     const double dof = df + N;
     const int nlow = d * (d - 1) / 2;
@@ -186,11 +319,14 @@ __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int
         if (t < d) vec[t] = variates[d + nlow + t];
     } else {
         // counters: [0, 4 d) chi-squares (thread 0, sequential rejection), then one per normal pair
-        if (t == 0) {
-            uint64_t ctr = offset;
-            for (int i = 0; i < d; i++) T[i * P + i] = sqrt(chi_square(dof - i, seed, ctr));
+        // counters (< 1024 per call, see apmf.h): chi-square i starts at offset + 16 i, one thread each (its
+        // rejection loop takes two per round and accepts > 95 % of the rounds: running into the next
+        // one's range needs 8 rejections in a row); the normals start at offset + 512, one per pair
+        if (t < d) {
+            uint64_t ctr = offset + 16 * (uint64_t)t;
+            T[t * P + t] = sqrt(chi_square(dof - t, seed, ctr));
         }
-        const uint64_t base = offset + 256;       // far beyond what the rejection loops can consume
+        const uint64_t base = offset + 16 * (uint64_t)HY_MAXD;
         for (int e = t; e < (nlow + 1) / 2; e += 256) {
             double a, b, u;
             draw(seed, base + e, a, b, u);
@@ -231,9 +367,9 @@ __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int
     // ---- lam = chol(inv((b0 + N) alpha));  mu = lam z + (b0 mu0 + N x_bar) / (b0 + N)
     for (int e = t; e < d * d; e += 256) B[(e / d) * P + e % d] = (b0 + N) * A[(e / d) * P + e % d];
     __syncthreads();
-    if (!chol_block(B, d, P, t) && t == 0) bad = 1;
-    inv_from_chol(B, T, C, d, P, t);
-    if (!chol_block(C, d, P, t) && t == 0) bad = 1;
+    if (!chol_any(B, d, P, t) && t == 0) bad = 1;
+    inv_any(B, T, C, d, P, t);
+    if (!chol_any(C, d, P, t) && t == 0) bad = 1;
     if (t < d) {
         double v = (b0 * mu0[t] + N * xbar[t]) / (b0 + N);
         for (int k = 0; k <= t; k++) v += C[t * P + k] * vec[k];
@@ -262,7 +398,9 @@ extern "C" int apmf_gibbs_sample_hyperparam(apmf_ctx *ctx, const double *d_feats
         status_ptr = (int *)w;
         APMF_CHECK_HIP(hipMemsetAsync(status_ptr, 0, sizeof(int), ctx->stream));
     }
-    const size_t smem = (HY_MAXD + 8 * HY_MAXD + 4 * (size_t)d * (d + 1) + HY_MAXD) * sizeof(double);
+    const size_t smem = (HY_MAXD + 8 * HY_MAXD + 4 * (size_t)d * (d + 1) + HY_MAXD + (size_t)HY_STAGE) * sizeof(double);
+    if (smem > 64 * 1024)
+        APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_hyper, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(k_hyper, dim3(1), dim3(256), smem, ctx->stream, d_feats, N, d, d_wi, b0, df, d_mu0, d_variates,
                        seed, offset, d_mu, d_alpha, status_ptr);
     APMF_CHECK_LAUNCH();
