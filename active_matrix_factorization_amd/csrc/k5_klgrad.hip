@@ -274,9 +274,25 @@ __global__ __launch_bounds__(256) void k_kl_omega(const KlDims q, const double *
         }
         __syncthreads();
     }
-    if (threadIdx.x != 0) return;
     const double G = sh[0][0], SVV = sh[1][0], S2 = sh[2][0], RS = sh[3][0], AW = sh[4][0];
     const double TRU = sh[5][0], TRV = sh_trv[0];
+    // X = sum_i M[i][k] w_i[k] of the diagonal entries, added in row order by one thread: the operands
+    // are fetched by the whole block, 256 rows at a time, and handed over through LDS
+    double X = 0;
+    if (k == l) {                    // block-uniform
+        for (int base = 0; base < n; base += 256) {
+            __syncthreads();
+            const int i = base + (int)threadIdx.x;
+            sh[0][threadIdx.x] = i < n ? M[(size_t)i * d + k] : 0.;
+            sh[1][threadIdx.x] = i < n ? racc_u[(size_t)i * su + d + k] : 0.;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int cnt = min(256, n - base);
+                for (int q2 = 0; q2 < cnt; q2++) X += sh[0][q2] * sh[1][q2];
+            }
+        }
+    }
+    if (threadIdx.x != 0) return;
     const double okl = O[k <= l ? k * d + l : l * d + k];
     double out;
     if (k != l) {
@@ -287,9 +303,7 @@ __global__ __launch_bounds__(256) void k_kl_omega(const KlDims q, const double *
         const double sum_awk_x2_plus_sq = G;   // = 2 * sum a_k w_k + (cvj a_k^2 + cvi b_k^2 sums)
         // diag_q = AW - sum_i a_k w_k + S2 (T - dg);  diag_s = (4 sum a_k w_k + 4 S2 dg + sq + 2 SVV dg) / 2
         // with sum a_k w_k =: X and sq =: Q (G = 2X + Q) we need X and Q separately:
-        // recompute X here (thread 0 only; n is small next to the block's work above)
-        double X = 0;
-        for (int i = 0; i < n; i++) X += M[(size_t)i * d + k] * racc_u[(size_t)i * su + d + k];
+        // (X: see above)
         const double Q = sum_awk_x2_plus_sq - 2. * X;
         const double diag_q = AW - X + S2 * (oc.T - dgk);
         const double diag_s = .5 * (4. * X + 4. * S2 * dgk + Q + 2. * SVV * dgk);
