@@ -239,3 +239,42 @@ def test_batch_slow_path_projection(ctx):
         np.testing.assert_allclose(dS.to_host(), cand[1], rtol=1e-8, atol=1e-10)
     assert clipped, 'the test problem no longer exercises the projection branch'
     b.free()
+
+
+@pytest.mark.parametrize('lanes', ['1', '3'])
+def test_batch_slow_lanes_same_states(ctx, lanes, monkeypatch):
+    """Hypotheses that keep leaving the fast path (covariances with eigenvalues at the clipping
+    threshold) go through the slow lanes - streams, rocBLAS handles and worker threads of their own -
+    while the others iterate: however many lanes there are, every hypothesis ends in the same state,
+    bit for bit, as when it is fitted in a batch of one."""
+    monkeypatch.setenv('APMF_BATCH_LANES', lanes)
+    n, m, d, H = 30, 40, 3, 6
+    N = n + m
+    rs, ratings, mean, S, O = _problem(n, m, d, 991)
+    sig, su, sv = 1.0, 10.0, 10.0
+    w, v = np.linalg.eigh(S)
+    states = []
+    for h in range(H):
+        k = 3 + h                       # k eigenvalues sit just above min_eig = 1e-5
+        Sh = (v * np.concatenate([np.full(k, 1.2e-5 + 1e-6 * h), w[k:]])) @ v.T
+        states.append((Sh + Sh.T) / 2)
+    rt = ctx.ratings(ratings, n, m)
+
+    def run(idx):
+        b = ctx.mn_batch(rt, d, len(idx), trace_cap=32)
+        b.set_state(ctx.array(np.stack([mean] * len(idx))), ctx.array(np.stack([states[h] for h in idx])),
+                    ctx.array(np.stack([O] * len(idx))), per_hypothesis=7)
+        lr, kl, nsteps, conv, trace = b.fit(sig, su, sv, 1e-5, 1e-3, max_steps=12)
+        out = []
+        dm, ds, do = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+        for q in range(len(idx)):
+            b.get_state(q, dm, ds, do)
+            out.append((dm.to_host(), ds.to_host(), do.to_host(), float(kl[q]), int(nsteps[q]), float(lr[q])))
+        b.free()
+        return out
+
+    together = run(list(range(H)))
+    for h in range(H):
+        alone = run([h])[0]
+        for x, y in zip(together[h], alone):
+            assert np.array_equal(x, y)
