@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b': only section J")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -119,6 +119,9 @@ def main():
                                    num_ratings=per_user, latent_dimension=d)
 
     timings = {}
+    if args.only == 'r2b':
+        round2b(np, mn_active_pmf, save, seed, _print)
+        return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
         if not args.keep:
@@ -452,6 +455,7 @@ def main():
          exp_dotprod_sq=mnx.exp_dotprod_sq(2, M_, R_, C_, 1, 2))
 
     round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
+    round2b(np, mn_active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -461,6 +465,56 @@ def main():
 
     if not args.keep:
         shutil.rmtree(args.scratch)
+
+
+def headline_inputs(np, seed):
+    """The 943 x 1682, N = 100 000 synthetic ratings of section A (tests/conftest.py:c2_inputs draws the same)."""
+    seed(0)
+    n, m, d, N = 943, 1682, 10, 100000
+    Ut = np.random.normal(0, 2, (n, d))
+    Vt = np.random.normal(0, 2, (m, d))
+    mask = np.zeros((n, m), bool)
+    mask[np.arange(n), np.random.randint(0, m, n)] = True
+    mask[np.random.randint(0, n, m), np.arange(m)] = True
+    free = np.flatnonzero(~mask.ravel())
+    extra = np.random.choice(free, N - int(mask.sum()), replace=False)
+    mask.ravel()[extra] = True
+    ii, jj = mask.nonzero()
+    perm = np.random.permutation(ii.size)
+    ii, jj = ii[perm], jj[perm]
+    vals = (Ut[ii] * Vt[jj]).sum(1) + np.random.normal(0, .25, ii.size)
+    return np.column_stack([ii, jj, vals]).astype(float)
+
+
+def round2b(np, mn_active_pmf, save, seed, _print):
+    """J. The matrix-normal scoring sweep at the HEADLINE shape (BASELINE.json metric: 943 x 1682, rank 10),
+    from the real reference: approx_pred_means_vars() over all 1 586 126 entries and pick_query_point over
+    the 1 486 126 unrated ones, for a posterior state generated from a few small factors (the
+    (n+m) x (n+m) covariance itself is 55 MB and is not stored):
+        mean = Mf,   cov_useritems = A A' + 0.1 I  (A: (n+m) x 8),   cov_latents = B B' / d + 0.1 I."""
+    MN = mn_active_pmf.MNActivePMF
+    t0 = time.perf_counter()
+    ratings = headline_inputs(np, seed)
+    n, m, d = 943, 1682, 10
+    seed(80)
+    Mf = np.random.normal(0, 1, (n + m, d))
+    A = np.random.normal(0, 1, (n + m, 8)) / 3.
+    B = np.random.normal(0, 1, (d, d))
+    a = MN(ratings.copy(), latent_d=d)
+    a.mean = Mf.copy()
+    a.cov_useritems = A @ A.T + .1 * np.eye(n + m)
+    a.cov_latents = B @ B.T / d + .1 * np.eye(d)
+    pm, pv = a.approx_pred_means_vars()
+    _print('headline MN grids: %.0f s' % (time.perf_counter() - t0))
+    pick = a.pick_query_point(key=MN.pred_variance)
+    _print('headline MN pick: %.0f s' % (time.perf_counter() - t0))
+    rows = np.array([0, 1, 470, 471, 941, 942])
+    rs = np.random.RandomState(81)
+    si, sj = rs.randint(0, n, 20000), rs.randint(0, m, 20000)
+    save('mn_c2_943x1682_d10', N=ratings.shape[0], ratings_sum=ratings.sum(0), Mf=Mf, A=A, B=B,
+         rows=rows, p_mean_rows=pm[rows], p_var_rows=pv[rows], si=si, sj=sj, p_mean_s=pm[si, sj],
+         p_var_s=pv[si, sj], total_variance=a._total_variance(), var_sum=pv.sum(), mean_sum=pm.sum(),
+         pick=np.array(pick), pick_var=pv[pick])
 
 
 def round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print):

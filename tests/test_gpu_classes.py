@@ -906,6 +906,56 @@ def test_configs3_golden_lookahead(pkg):
     assert vals[0] == got
 
 
+def test_headline_shape_golden_scoring_and_selection(pkg):
+    """BASELINE.json's metric shape - 943 x 1682, rank 10 - recorded from the real reference
+    (make_golden.py section J: approx_pred_means_vars over all 1 586 126 entries, pick_query_point over
+    the 1 486 126 unrated ones, 49 s there): the class-level float64 path (device-resident state,
+    masked sweep, fused arg-max) and the float32 B-state sweep the benchmark times, on the same state."""
+    from conftest import c2_inputs
+    from active_matrix_factorization_amd import _lib
+    g = load_golden('mn_c2_943x1682_d10')
+    n, m, d = 943, 1682, 10
+    ratings, _, _ = c2_inputs()
+    MN = pkg.mn.MNActivePMF
+    a = MN(ratings.copy(), latent_d=d)
+    a.mean = g['Mf'].copy()
+    a.cov_useritems = g['A'] @ g['A'].T + .1 * np.eye(n + m)
+    a.cov_latents = g['B'] @ g['B'].T / d + .1 * np.eye(d)
+    pm, pv = a.approx_pred_means_vars()
+    scale = np.abs(g['p_var_rows']).max()
+    np.testing.assert_allclose(pv[g['rows']], g['p_var_rows'], rtol=1e-10, atol=1e-13 * scale)
+    np.testing.assert_allclose(pm[g['rows']], g['p_mean_rows'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(pv[g['si'], g['sj']], g['p_var_s'], rtol=1e-10, atol=1e-13 * scale)
+    np.testing.assert_allclose(pm[g['si'], g['sj']], g['p_mean_s'], rtol=1e-10, atol=1e-12)
+    assert abs(a._total_variance() - g['total_variance']) <= 1e-11 * abs(g['total_variance'])
+    pick = tuple(int(x) for x in g['pick'])
+    assert tuple(a.pick_query_point(key=MN.pred_variance)) == pick
+    assert tuple(a.pick_query_point()) == pick
+    # the float32 sweep the benchmark times, on the same state: values within the float32 tolerance of the
+    # reference's, and an entry selected among the unrated whose float64 variance is within float32
+    # rounding of the reference's maximum
+    ctx = _lib.default_context()
+    ld = _lib.grid_ld(m)
+    R = np.asarray(a.cov_useritems)
+    dm, dc = ctx.array(np.asarray(a.mean), np.float32), ctx.upload_grid(R[:n, n:], np.float32)
+    dd, do = ctx.array(np.diag(R).copy(), np.float32), ctx.array(np.asarray(a.cov_latents), np.float32)
+    rated = np.zeros((n, m), bool)
+    rated[ratings[:, 0].astype(int), ratings[:, 1].astype(int)] = True
+    dmask = ctx.upload_grid((~rated).astype(np.uint8), np.uint8, ld=ld)
+    var = ctx.empty((n, ld), np.float32)
+    dsum, bv, bi = ctx.empty(1), ctx.empty(1, np.float32), ctx.empty(1, np.int64)
+    ctx.mn_score_grid(np.float32, 1, n, m, d, ld, dm, dc, dd, do, mask=dmask, var=var, dsum=dsum, want=1,
+                      best_val=bv, best_idx=bi)
+    v32 = ctx.download_grid(var, m)
+    np.testing.assert_allclose(v32[g['rows']], g['p_var_rows'], rtol=3e-5, atol=3e-5 * scale)
+    np.testing.assert_allclose(v32[g['si'], g['sj']], g['p_var_s'], rtol=3e-5, atol=3e-5 * scale)
+    i32, j32 = divmod(int(bi.to_host()[0]), m)
+    assert not rated[i32, j32]
+    assert abs(pv[i32, j32] - float(g['pick_var'])) <= 3e-5 * abs(float(g['pick_var']))
+    tot = pv[~rated].sum()
+    assert abs(dsum.to_host()[0] - tot) <= 1e-5 * abs(tot)
+
+
 def test_minibatch_golden(pkg):
     """fit_minibatches / _validation / _until_validation (pmf_cy.pyx:308-381) against traces recorded
     from the reference under the same seeds (np.random.shuffle and random.sample stay on the host)."""

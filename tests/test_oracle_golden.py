@@ -261,6 +261,41 @@ def test_configs3_fixture_oracle():
         assert cand[tuple(pick)] == cand.max()
 
 
+def headline_state(g):
+    """The posterior state of the headline-shape fixture from its small factors (make_golden.py, section J)."""
+    n, m, d = 943, 1682, 10
+    mean = g['Mf']
+    R = g['A'] @ g['A'].T + .1 * np.eye(n + m)
+    Cl = g['B'] @ g['B'].T / d + .1 * np.eye(d)
+    return n, m, d, mean, R, Cl
+
+
+def test_headline_shape_fixture_oracle():
+    """BASELINE.json's metric shape (943 x 1682, rank 10), recorded from the reference: the oracle's
+    per-candidate path reproduces the reference's mean / variance grid on six whole rows and 20 000
+    sampled candidates, its totals over all 1 586 126 entries, and the entry the reference picked
+    over the 1 486 126 unrated ones."""
+    from conftest import c2_inputs
+    g = load_golden('mn_c2_943x1682_d10')
+    n, m, d, mean, R, Cl = headline_state(g)
+    pm, pv = orc.mn_pred_means_vars(n, m, mean, R, Cl)
+    scale = np.abs(g['p_var_rows']).max()
+    np.testing.assert_allclose(pv[g['rows']], g['p_var_rows'], rtol=1e-10, atol=1e-13 * scale)
+    np.testing.assert_allclose(pm[g['rows']], g['p_mean_rows'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(pv[g['si'], g['sj']], g['p_var_s'], rtol=1e-10, atol=1e-13 * scale)
+    np.testing.assert_allclose(pm[g['si'], g['sj']], g['p_mean_s'], rtol=1e-10, atol=1e-12)
+    assert abs(pv.sum() - g['var_sum']) <= 1e-11 * abs(g['var_sum'])
+    assert abs(pv.sum() - g['total_variance']) <= 1e-11 * abs(g['total_variance'])
+    ratings, _, _ = c2_inputs()
+    assert ratings.shape[0] == int(g['N']) and np.allclose(ratings.sum(0), g['ratings_sum'])
+    rated = np.zeros((n, m), bool)
+    rated[ratings[:, 0].astype(int), ratings[:, 1].astype(int)] = True
+    cand = np.where(rated, -np.inf, pv)
+    pick = tuple(int(x) for x in g['pick'])
+    assert cand[pick] == cand.max() and np.argmax(cand) == pick[0] * m + pick[1]
+    assert abs(pv[pick] - float(g['pick_var'])) <= 1e-10 * abs(float(g['pick_var']))
+
+
 def test_minibatch_fixture_oracle():
     """fit_minibatches (pmf_cy.pyx:308-351) recorded from the reference: two epochs of the momentum
     recipe composed from the oracle's gradient on the same shuffles give the reference's factors."""
