@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b': only section J")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' / 'r2c': only section J / K")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -121,6 +121,9 @@ def main():
     timings = {}
     if args.only == 'r2b':
         round2b(np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r2c':
+        round2c(np, pmf_cy, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -456,6 +459,7 @@ def main():
 
     round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
     round2b(np, mn_active_pmf, save, seed, _print)
+    round2c(np, pmf_cy, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -484,6 +488,25 @@ def headline_inputs(np, seed):
     ii, jj = ii[perm], jj[perm]
     vals = (Ut[ii] * Vt[jj]).sum(1) + np.random.normal(0, .25, ii.size)
     return np.column_stack([ii, jj, vals]).astype(float)
+
+
+def round2c(np, pmf_cy, save, seed, _print):
+    """K. fit_lls at the headline shape (BASELINE.json configs[1]: 943 x 1682, rank 10, N = 100 000), from the
+    real reference: the log-likelihood after each of the first 20 accepted steps of the learning-rate search
+    from section A's starting point, and the factors there (sampled rows + sums)."""
+    from itertools import islice
+    t0 = time.perf_counter()
+    ratings = headline_inputs(np, seed)
+    U0 = np.random.random((943, 10))        # the draws that follow the ratings in section A / conftest.c2_inputs
+    V0 = np.random.random((1682, 10))
+    p = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    p.users, p.items = U0.copy(), V0.copy()
+    lls = list(islice(p.fit_lls(), 20))
+    _print('headline fit_lls, 20 accepted steps: %.0f s' % (time.perf_counter() - t0))
+    rows_u, rows_v = np.array([0, 1, 500, 942]), np.array([0, 7, 1000, 1681])
+    save('pmf_c2_fit_943x1682_d10', N=ratings.shape[0], U0_sum=U0.sum(), V0_sum=V0.sum(), ll_trace=np.array(lls),
+         rows_u=rows_u, rows_v=rows_v, U_rows=p.users[rows_u], V_rows=p.items[rows_v], U_sum=p.users.sum(),
+         V_sum=p.items.sum(), learning_rate=float(p.learning_rate) if hasattr(p, 'learning_rate') else np.nan)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

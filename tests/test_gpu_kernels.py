@@ -182,6 +182,25 @@ def test_pmf_headline_shape(ctx):
     assert np.array_equal(gU, gU2) and np.array_equal(gV, gV2) and ll == ll2
 
 
+def test_pmf_headline_fit_trace(ctx):
+    """The one-launch search iteration at BASELINE.json configs[1]'s shape against the REAL reference:
+    20 accepted steps of fit_lls from the recorded starting point - same accept / reject sequence
+    (the trace has exactly the reference's values), same factors."""
+    g = load_golden('pmf_c2_fit_943x1682_d10')
+    ratings, U0, V0 = c2_inputs()
+    n, m, d = 943, 1682, 10
+    rt = ctx.ratings(ratings, n, m)
+    dU, dV = ctx.array(U0), ctx.array(V0)
+    trace, steps, lr, conv = ctx.pmf_fit_lls(rt, dU, dV, d, 1., 10., 10., False, 0., float(g['learning_rate']),
+                                             1e-10, 1e-2, max_steps=20)
+    assert steps == 20
+    np.testing.assert_allclose(trace, g['ll_trace'], rtol=1e-11)
+    U, V = dU.to_host(), dV.to_host()
+    np.testing.assert_allclose(U[g['rows_u']], g['U_rows'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(V[g['rows_v']], g['V_rows'], rtol=1e-9, atol=1e-11)
+    assert abs(U.sum() - g['U_sum']) <= 1e-9 * abs(g['U_sum']) and abs(V.sum() - g['V_sum']) <= 1e-9 * abs(g['V_sum'])
+
+
 def test_pmf_minibatch_epoch(ctx):
     rs = np.random.RandomState(5)
     n, m, d, N, bs = 23, 31, 6, 500, 64

@@ -58,6 +58,20 @@ def test_pmf_headline_shape():
     assert abs(ll - g['ll']) <= 1e-13 * abs(g['ll'])
 
 
+def test_pmf_headline_fit_trace():
+    """fit_lls at BASELINE.json configs[1]'s shape (943 x 1682, rank 10, N = 100 000): the reference's
+    log-likelihood after each of its first 20 accepted steps, and its factors there."""
+    g = load_golden('pmf_c2_fit_943x1682_d10')
+    ratings, U0, V0 = c2_inputs()
+    assert abs(U0.sum() - g['U0_sum']) <= 1e-9 and abs(V0.sum() - g['V0_sum']) <= 1e-9
+    U, V, trace = orc.pmf_fit_lls(ratings, U0, V0, lr=float(g['learning_rate']), max_steps=20)
+    assert len(trace) == 20
+    np.testing.assert_allclose(trace, g['ll_trace'], rtol=1e-11)
+    np.testing.assert_allclose(U[g['rows_u']], g['U_rows'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(V[g['rows_v']], g['V_rows'], rtol=1e-9, atol=1e-11)
+    assert abs(U.sum() - g['U_sum']) <= 1e-9 * abs(g['U_sum']) and abs(V.sum() - g['V_sum']) <= 1e-9 * abs(g['V_sum'])
+
+
 MN_CASES = ['mn_c1_10x10_d2_eye', 'mn_c1_10x10_d2_rand', 'mn_24x17_d5_rand', 'mn_12x20_d10_rand']
 
 
