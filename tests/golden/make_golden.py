@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' / 'r2c': only section J / K")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' / 'r2c' / 'r2d': only section J / K / L")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -124,6 +124,9 @@ def main():
         return
     if args.only == 'r2c':
         round2c(np, pmf_cy, save, seed, _print)
+        return
+    if args.only == 'r2d':
+        round2d(np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -460,6 +463,7 @@ def main():
     round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
     round2b(np, mn_active_pmf, save, seed, _print)
     round2c(np, pmf_cy, save, seed, _print)
+    round2d(np, mn_active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -507,6 +511,34 @@ def round2c(np, pmf_cy, save, seed, _print):
     save('pmf_c2_fit_943x1682_d10', N=ratings.shape[0], U0_sum=U0.sum(), V0_sum=V0.sum(), ll_trace=np.array(lls),
          rows_u=rows_u, rows_v=rows_v, U_rows=p.users[rows_u], V_rows=p.items[rows_v], U_sum=p.users.sum(),
          V_sum=p.items.sum(), learning_rate=float(p.learning_rate) if hasattr(p, 'learning_rate') else np.nan)
+
+
+def round2d(np, mn_active_pmf, save, seed, _print):
+    """L. The variational fit at the headline shape (943 x 1682, rank 10, N = 100 000; (n+m) = 2625), from the
+    real reference: KL at initialize_approx() (mean = the section-A starting factors, identity covariances)
+    and after each of the first 3 fit_normal_kls steps, and the state there (mean, cov_latents, the diagonal
+    and 5000 sampled entries of the 2625 x 2625 cov_useritems)."""
+    from itertools import islice
+    MN = mn_active_pmf.MNActivePMF
+    t0 = time.perf_counter()
+    ratings = headline_inputs(np, seed)
+    U0 = np.random.random((943, 10))
+    V0 = np.random.random((1682, 10))
+    a = MN(ratings.copy(), latent_d=10)
+    a.users, a.items = U0.copy(), V0.copy()
+    a.initialize_approx()
+    kl0 = a.kl_divergence()
+    _print('headline MN: KL at start %.6g, %.0f s' % (kl0, time.perf_counter() - t0))
+    kls = []
+    for kl in islice(a.fit_normal_kls(), 3):
+        kls.append(kl)
+        _print('headline MN: step %d KL %.6g, %.0f s' % (len(kls), kl, time.perf_counter() - t0))
+    rs = np.random.RandomState(82)
+    si, sj = rs.randint(0, 2625, 5000), rs.randint(0, 2625, 5000)
+    save('mn_c2_fit_943x1682_d10', N=ratings.shape[0], U0_sum=U0.sum(), V0_sum=V0.sum(), kl0=kl0,
+         kl_trace3=np.array(kls), mean3=a.mean.copy(), cov_latents3=a.cov_latents.copy(),
+         cov_diag3=np.diag(a.cov_useritems).copy(), si=si, sj=sj, cov_s3=a.cov_useritems[si, sj].copy(),
+         sigma=np.array([a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq]))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

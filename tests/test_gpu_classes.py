@@ -956,6 +956,29 @@ def test_headline_shape_golden_scoring_and_selection(pkg):
     assert abs(dsum.to_host()[0] - tot) <= 1e-5 * abs(tot)
 
 
+def test_headline_shape_golden_variational_fit(pkg):
+    """The variational fit at the metric's shape (943 x 1682, rank 10, N = 100 000: (n+m) = 2625, 42
+    block columns of the factorisations) against the real reference (make_golden.py section L): the KL
+    at initialize_approx() and after each of the first three fit_normal_kls steps - the reference took
+    rejected trials on the way, so this is its accept / reject sequence too - and the state there."""
+    from conftest import c2_inputs
+    g = load_golden('mn_c2_fit_943x1682_d10')
+    ratings, U0, V0 = c2_inputs()
+    assert abs(U0.sum() - g['U0_sum']) <= 1e-9 and abs(V0.sum() - g['V0_sum']) <= 1e-9
+    a = pkg.mn.MNActivePMF(ratings.copy(), latent_d=10)
+    a.users, a.items = U0.copy(), V0.copy()
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    a.initialize_approx()
+    assert abs(a.kl_divergence() - g['kl0']) <= 1e-10 * abs(g['kl0'])
+    kls = list(islice(a.fit_normal_kls(), 3))
+    np.testing.assert_allclose(kls, g['kl_trace3'], rtol=1e-9)
+    np.testing.assert_allclose(a.mean, g['mean3'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a.cov_latents, g['cov_latents3'], rtol=1e-8, atol=1e-10)
+    S = np.asarray(a.cov_useritems)
+    np.testing.assert_allclose(np.diag(S), g['cov_diag3'], rtol=1e-8)
+    np.testing.assert_allclose(S[g['si'], g['sj']], g['cov_s3'], rtol=1e-7, atol=1e-10)
+
+
 def test_minibatch_golden(pkg):
     """fit_minibatches / _validation / _until_validation (pmf_cy.pyx:308-381) against traces recorded
     from the reference under the same seeds (np.random.shuffle and random.sample stay on the host)."""
