@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' / 'r2c' / 'r2d': only section J / K / L")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' / 'r2c' / 'r2d' / 'r2e': only section J / K / L / M")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -127,6 +127,9 @@ def main():
         return
     if args.only == 'r2d':
         round2d(np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r2e':
+        round2e(np, bayes_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -464,6 +467,7 @@ def main():
     round2b(np, mn_active_pmf, save, seed, _print)
     round2c(np, pmf_cy, save, seed, _print)
     round2d(np, mn_active_pmf, save, seed, _print)
+    round2e(np, bayes_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -539,6 +543,29 @@ def round2d(np, mn_active_pmf, save, seed, _print):
          kl_trace3=np.array(kls), mean3=a.mean.copy(), cov_latents3=a.cov_latents.copy(),
          cov_diag3=np.diag(a.cov_useritems).copy(), si=si, sj=sj, cov_s3=a.cov_useritems[si, sj].copy(),
          sigma=np.array([a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq]))
+
+
+def round2e(np, bayes_pmf, save, seed, _print):
+    """M. BayesianPMF.exp_variance (bayes_pmf.py:457-525, 560-598) from the real reference, sequential
+    (pool=None) under fixed seeds, on the 10 x 10 rank-2 discrete case of section D: five chain samples from
+    seed 5, then the expected total variance of the first four unrated entries from seed 6, with and without
+    fit_first, three lookahead samples per hypothesis."""
+    from itertools import islice
+    g = np.load(os.path.join(HERE, 'bayes_c1_10x10_d2.npz'))
+    b = bayes_pmf.BayesianPMF(g['ratings'].copy(), latent_d=2, subtract_mean=False, rating_values=(1, 2, 3, 4, 5))
+    b.users, b.items = g['users'].copy(), g['items'].copy()
+    seed(5)
+    samps = list(islice(b.samples(), 5))
+    unr = np.array(sorted(b.unrated)[:4]).T
+    which = tuple(unr)
+    out = dict(which=unr, chain_U=np.array([u for u, v in samps]), chain_V=np.array([v for u, v in samps]))
+    for fit_first in (True, False):
+        seed(6)
+        ev = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
+        out['exp_variance_fit%d' % int(fit_first)] = np.asarray(ev, float)
+        out['rng_after_fit%d' % int(fit_first)] = np.random.get_state()[1][:8].copy()
+        _print('exp_variance fit_first=%s: %s' % (fit_first, ev))
+    save('bayes_c1_exp_variance', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

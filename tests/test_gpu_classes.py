@@ -1116,6 +1116,30 @@ def test_from_dense_defers_the_sets(pkg):
     assert [s[1] for s in res_a['pred-variance']] == [s[1] for s in res_b['pred-variance']]
 
 
+def test_bayes_exp_variance_reference_fixture(pkg, monkeypatch):
+    """BayesianPMF.exp_variance against values recorded from the REAL reference (make_golden.py section M:
+    sequential, pool=None, seeds 5 / 6): the chain samples, then the expected total variance of four
+    candidates with and without fit_first - from the batched evaluation and from the one-at-a-time one -
+    and the same NumPy random stream consumed."""
+    g0 = load_golden('bayes_c1_10x10_d2')
+    g = load_golden('bayes_c1_exp_variance')
+    b = pkg.bayes.BayesianPMF(g0['ratings'].copy(), latent_d=2, subtract_mean=False, rating_values=(1, 2, 3, 4, 5))
+    b.users, b.items = g0['users'].copy(), g0['items'].copy()
+    seed(5)
+    samps = list(islice(b.samples(), 5))
+    np.testing.assert_allclose(np.array([u for u, v in samps]), g['chain_U'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.array([v for u, v in samps]), g['chain_V'], rtol=1e-6, atol=1e-9)
+    which = tuple(g['which'])
+    assert np.array_equal(np.array(sorted(b.unrated)[:4]).T, g['which'])
+    for batch in ('1', '0'):
+        monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', batch)
+        for fit_first in (True, False):
+            seed(6)
+            ev = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
+            np.testing.assert_allclose(ev, g['exp_variance_fit%d' % int(fit_first)], rtol=1e-6)
+            assert np.array_equal(np.random.get_state()[1][:8], g['rng_after_fit%d' % int(fit_first)])
+
+
 def test_bayes_exp_variance_batched_equals_sequential(pkg, monkeypatch):
     """BayesianPMF.exp_variance (bayes_pmf.py:457-525, 560-598): all hypotheses (candidate x rating
     value) sampled together - batched K3 half-sweeps with the hypothesis' extra rating, K4 on the
