@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' / 'r2c' / 'r2d' / 'r2e': only section J / K / L / M")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2f': only section J .. N")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -130,6 +130,9 @@ def main():
         return
     if args.only == 'r2e':
         round2e(np, bayes_pmf, save, seed, _print)
+        return
+    if args.only == 'r2f':
+        round2f(np, active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -468,6 +471,7 @@ def main():
     round2c(np, pmf_cy, save, seed, _print)
     round2d(np, mn_active_pmf, save, seed, _print)
     round2e(np, bayes_pmf, save, seed, _print)
+    round2f(np, active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -566,6 +570,29 @@ def round2e(np, bayes_pmf, save, seed, _print):
         out['rng_after_fit%d' % int(fit_first)] = np.random.get_state()[1][:8].copy()
         _print('exp_variance fit_first=%s: %s' % (fit_first, ev))
     save('bayes_c1_exp_variance', **out)
+
+
+def round2f(np, active_pmf, save, seed, _print):
+    """N. One-step lookahead criteria of the FULL-covariance class (active_pmf.py:477-700) on config 1's
+    10 x 10 rank-2 ratings: do_fit, initialize_approx (seeded: it draws a random covariance), fit_normal,
+    then the criteria for one candidate - each a deepcopy + add_rating + fit_normal per rating value."""
+    g = np.load(os.path.join(HERE, 'lookahead_c1_mn.npz'))
+    t0 = time.perf_counter()
+    seed(43)
+    a = active_pmf.ActivePMF(g['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5),
+                             discrete_expectations=True)
+    a.do_fit()
+    a.initialize_approx()
+    a.fit_normal()
+    _print('full-cov config 1: fitted, %.0f s' % (time.perf_counter() - t0))
+    cand = sorted(a.unrated)[7]
+    out = dict(ratings=g['ratings'], users=a.users, items=a.items, mean=a.mean, cov=a.cov, cand=np.array(cand),
+               pred=a.pred(cand), pred_variance=a.pred_variance(cand), total_variance=a._total_variance(),
+               approx_entropy=a._approx_entropy())
+    for key in ('exp_total_variance', 'exp_approx_entropy', 'onestep_ge_3_5'):
+        out[key] = getattr(a, key)(cand)
+        _print('full-cov config 1: %s = %r, %.0f s' % (key, out[key], time.perf_counter() - t0))
+    save('lookahead_c1_full', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

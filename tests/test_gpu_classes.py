@@ -472,6 +472,24 @@ def test_mn_lookahead_golden(pkg):
         assert abs(got - g[key]) <= 2e-4 * abs(g[key]), (key, got, float(g[key]))
 
 
+def test_full_lookahead_golden(pkg):
+    """One-step lookahead criteria of the FULL-covariance class (active_pmf.py:477-700) against values
+    recorded from the real reference on config 1 (make_golden.py section N): each is a deepcopy +
+    add_rating + fit_normal (to convergence, on the device: apmf_full_fit_normal) per rating value."""
+    g = load_golden('lookahead_c1_full')
+    a = pkg.full.ActivePMF(g['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5),
+                           discrete_expectations=True)
+    a.users, a.items, a.mean, a.cov = g['users'].copy(), g['items'].copy(), g['mean'].copy(), g['cov'].copy()
+    cand = tuple(int(x) for x in g['cand'])
+    assert abs(a.pred(cand) - g['pred']) <= 1e-12 * abs(g['pred'])
+    assert abs(a.pred_variance(cand) - g['pred_variance']) <= 1e-10 * abs(g['pred_variance'])
+    assert abs(a._total_variance() - g['total_variance']) <= 1e-10 * abs(g['total_variance'])
+    assert abs(a._approx_entropy() - g['approx_entropy']) <= 1e-10 * abs(g['approx_entropy'])
+    for key in ('exp_total_variance', 'exp_approx_entropy', 'onestep_ge_3_5'):
+        got = getattr(a, key)(cand)
+        assert abs(got - g[key]) <= 5e-4 * abs(g[key]), (key, got, float(g[key]))
+
+
 # ------------------------------------------------------------------ the reference's own checks
 @pytest.mark.parametrize('subtract_mean', [False, True])
 def test_pmf_check_grad_like_reference_notebook(pkg, subtract_mean):
