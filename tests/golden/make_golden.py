@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2f': only section J .. N")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2g': only section J .. O")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -133,6 +133,9 @@ def main():
         return
     if args.only == 'r2f':
         round2f(np, active_pmf, save, seed, _print)
+        return
+    if args.only == 'r2g':
+        round2g(np, bayes_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -472,6 +475,7 @@ def main():
     round2d(np, mn_active_pmf, save, seed, _print)
     round2e(np, bayes_pmf, save, seed, _print)
     round2f(np, active_pmf, save, seed, _print)
+    round2g(np, bayes_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -593,6 +597,28 @@ def round2f(np, active_pmf, save, seed, _print):
         out[key] = getattr(a, key)(cand)
         _print('full-cov config 1: %s = %r, %.0f s' % (key, out[key], time.perf_counter() - t0))
     save('lookahead_c1_full', **out)
+
+
+def round2g(np, bayes_pmf, save, seed, _print):
+    """O. The Bayesian selection loop end to end (bayes_pmf.py:682-826: compare_active -> full_test):
+    config 1's 10 x 10 rank-2 discrete matrix, keys random / pred-variance / prob-ge-3.5, 8 chain samples,
+    4 steps each, sequential (procs=0) under seed 44: picks, RMSEs and the evaluation grids."""
+    g = np.load(os.path.join(HERE, 'trace_c1_mn.npz'))
+    real, ratings = g['real'], g['ratings']
+    keys = ['random', 'pred-variance', 'prob-ge-3.5']
+    seed(44)
+    res = bayes_pmf.compare_active(keys, 2, real, ratings.copy(), rating_vals=(1, 2, 3, 4, 5), num_steps=5,
+                                   procs=0, num_samps=8, subtract_mean=False)
+    out = dict(real=real, ratings=ratings, seed=44, keys=np.array(keys))
+    for key in keys:
+        steps = res[key]
+        out[key + '_n_rated'] = np.array([s[0] for s in steps])
+        out[key + '_rmse'] = np.array([s[1] for s in steps], dtype=np.float64)
+        out[key + '_picks'] = np.array([s[2] for s in steps[1:]])
+        for k, s in enumerate(steps[1:]):
+            out['%s_vals_%d' % (key, k)] = np.array(s[3], dtype=np.float64)
+        _print('bayes compare %s: picks %s' % (key, out[key + '_picks'].tolist()))
+    save('trace_c1_bayes', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -280,6 +280,29 @@ def test_config1_selection_trace(pkg):
     assert set(res) == {'_real', '_ratings', '_rating_vals', '_initial_apmf', 'random', 'pred-variance'}
 
 
+def test_config1_bayes_selection_trace(pkg):
+    """The Bayesian selection loop end to end (bayes_pmf.py:682-826: compare_active -> full_test -> Gibbs
+    chains -> statistics -> pick -> add_rating -> re-fit) on config 1's 10 x 10 rank-2 discrete matrix:
+    the picks the REAL reference made under seed 44 for random / pred-variance / prob-ge-3.5 (exact), its
+    RMSE after every step and its evaluation grids."""
+    g = load_golden('trace_c1_bayes')
+    keys = [str(k) for k in g['keys']]
+    seed(int(g['seed']))
+    res = pkg.bayes.compare_active(keys, 2, g['real'], g['ratings'].copy(), rating_vals=(1, 2, 3, 4, 5),
+                                   num_steps=5, procs=0, num_samps=8, subtract_mean=False)
+    for key in keys:
+        steps = res[key]
+        assert [s[0] for s in steps] == list(g[key + '_n_rated'])
+        picks = np.array([s[2] for s in steps[1:]])
+        np.testing.assert_array_equal(picks, g[key + '_picks'])       # selected indices: exact
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-5)
+        for k, s in enumerate(steps[1:]):
+            ref = g['%s_vals_%d' % (key, k)]
+            got = np.asarray(s[3], float)
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-5, atol=1e-9)
+
+
 def test_mn_lookahead_total_variance(pkg):
     """exp_total_variance: deepcopy + add_rating + fit_normal + grid sum per rating value
     (mn_active_pmf.py:600-696); evaluated here against a by-hand composition."""
