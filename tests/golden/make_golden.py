@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2g': only section J .. O")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2h': only section J .. P")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -136,6 +136,9 @@ def main():
         return
     if args.only == 'r2g':
         round2g(np, bayes_pmf, save, seed, _print)
+        return
+    if args.only == 'r2h':
+        round2h(np, active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -476,6 +479,7 @@ def main():
     round2e(np, bayes_pmf, save, seed, _print)
     round2f(np, active_pmf, save, seed, _print)
     round2g(np, bayes_pmf, save, seed, _print)
+    round2h(np, active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -619,6 +623,31 @@ def round2g(np, bayes_pmf, save, seed, _print):
             out['%s_vals_%d' % (key, k)] = np.array(s[3], dtype=np.float64)
         _print('bayes compare %s: picks %s' % (key, out[key + '_picks'].tolist()))
     save('trace_c1_bayes', **out)
+
+
+def round2h(np, active_pmf, save, seed, _print):
+    """P. The full-covariance selection loop end to end (active_pmf.py:933-1090: compare -> full_test) on
+    config 1's 10 x 10 rank-2 discrete matrix: keys random / pred-variance / pred, 4 steps each, unthreaded,
+    under seed 45 (initialize_approx draws its random covariance from it): picks, RMSEs, evaluation grids
+    and the initial approximation."""
+    g = np.load(os.path.join(HERE, 'trace_c1_mn.npz'))
+    real, ratings = g['real'], g['ratings']
+    keys = ['random', 'pred-variance', 'pred']
+    seed(45)
+    res = active_pmf.compare(keys, latent_d=2, do_threading=False, steps=5,
+                             real_ratings_vals=(real, ratings.copy(), (1, 2, 3, 4, 5)))
+    out = dict(real=real, ratings=ratings, seed=45, keys=np.array(keys))
+    for key in keys:
+        steps = res[key]
+        out[key + '_n_rated'] = np.array([s[0] for s in steps])
+        out[key + '_rmse'] = np.array([s[1] for s in steps], dtype=np.float64)
+        out[key + '_picks'] = np.array([s[2] for s in steps[1:]])
+        for k, s in enumerate(steps[1:]):
+            out['%s_vals_%d' % (key, k)] = np.array(s[3], dtype=np.float64)
+        _print('full-cov compare %s: picks %s' % (key, out[key + '_picks'].tolist()))
+    init = res['_initial_apmf']
+    out.update(init_users=init.users, init_items=init.items, init_mean=init.mean, init_cov=init.cov)
+    save('trace_c1_full', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -303,6 +303,33 @@ def test_config1_bayes_selection_trace(pkg):
             np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-5, atol=1e-9)
 
 
+def test_config1_full_selection_trace(pkg):
+    """The full-covariance selection loop end to end (active_pmf.py:933-1090: compare -> full_test -> fit ->
+    initialize_approx (a random covariance from the seeded NumPy stream) -> fit_normal -> score -> pick ->
+    add_rating -> re-fit) on config 1: the picks the REAL reference made under seed 45 for random /
+    pred-variance / pred (exact), its RMSEs, evaluation grids and initial approximation."""
+    g = load_golden('trace_c1_full')
+    keys = [str(k) for k in g['keys']]
+    seed(int(g['seed']))
+    res = pkg.full.compare(keys, latent_d=2, do_threading=False, steps=5,
+                           real_ratings_vals=(g['real'], g['ratings'].copy(), (1, 2, 3, 4, 5)))
+    init = res['_initial_apmf']
+    np.testing.assert_allclose(init.users, g['init_users'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(init.mean, g['init_mean'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(init.cov, g['init_cov'], rtol=1e-4, atol=1e-6)
+    for key in keys:
+        steps = res[key]
+        assert [s[0] for s in steps] == list(g[key + '_n_rated'])
+        picks = np.array([s[2] for s in steps[1:]])
+        np.testing.assert_array_equal(picks, g[key + '_picks'])       # selected indices: exact
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-5)
+        for k, s in enumerate(steps[1:]):
+            ref = g['%s_vals_%d' % (key, k)]
+            got = np.asarray(s[3], float)
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-4, atol=1e-8)
+
+
 def test_mn_lookahead_total_variance(pkg):
     """exp_total_variance: deepcopy + add_rating + fit_normal + grid sum per rating value
     (mn_active_pmf.py:600-696); evaluated here against a by-hand composition."""
