@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2h': only section J .. P")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2i': only section J .. Q")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -139,6 +139,9 @@ def main():
         return
     if args.only == 'r2h':
         round2h(np, active_pmf, save, seed, _print)
+        return
+    if args.only == 'r2i':
+        round2i(np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -480,6 +483,7 @@ def main():
     round2f(np, active_pmf, save, seed, _print)
     round2g(np, bayes_pmf, save, seed, _print)
     round2h(np, active_pmf, save, seed, _print)
+    round2i(np, mn_active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -648,6 +652,23 @@ def round2h(np, active_pmf, save, seed, _print):
     init = res['_initial_apmf']
     out.update(init_users=init.users, init_items=init.items, init_mean=init.mean, init_cov=init.cov)
     save('trace_c1_full', **out)
+
+
+def round2i(np, mn_active_pmf, save, seed, _print):
+    """Q. The matrix-normal lookahead criteria with refit_lookahead (mn_active_pmf.py:660-672: every hypothesis
+    re-fits the MAP estimate, restarts the approximation from it and fits that) on the state of section E2."""
+    g = np.load(os.path.join(HERE, 'lookahead_c1_mn.npz'))
+    a = mn_active_pmf.MNActivePMF(g['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5),
+                                  discrete_expectations=True, refit_lookahead=True)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+    cand = tuple(int(x) for x in g['cand'])
+    out = dict(cand=np.array(cand))
+    for key in ('exp_total_variance', 'exp_approx_entropy', 'onestep_ge_3_5'):
+        seed(46)
+        out[key] = getattr(a, key)(cand)
+        _print('MN refit lookahead: %s = %r' % (key, out[key]))
+    save('lookahead_c1_mn_refit', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -540,6 +540,26 @@ def test_full_lookahead_golden(pkg):
         assert abs(got - g[key]) <= 5e-4 * abs(g[key]), (key, got, float(g[key]))
 
 
+def test_mn_refit_lookahead_golden(pkg, monkeypatch):
+    """The lookahead criteria with refit_lookahead (mn_active_pmf.py:660-672: every hypothesis re-fits the
+    MAP estimate - do_fit -, restarts the approximation from it and fits that) against values recorded from
+    the real reference (make_golden.py section Q), from the batched evaluation and from the
+    per-hypothesis one."""
+    g0 = load_golden('lookahead_c1_mn')
+    g = load_golden('lookahead_c1_mn_refit')
+    cand = tuple(int(x) for x in g['cand'])
+    for batch in ('1', '0'):
+        monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', batch)
+        a = pkg.mn.MNActivePMF(g0['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5),
+                               discrete_expectations=True, refit_lookahead=True)
+        a.users, a.items = g0['users'].copy(), g0['items'].copy()
+        a.mean, a.cov_useritems, a.cov_latents = g0['mean'].copy(), g0['cov_useritems'].copy(), g0['cov_latents'].copy()
+        for key in ('exp_total_variance', 'exp_approx_entropy', 'onestep_ge_3_5'):
+            seed(46)
+            got = getattr(a, key)(cand)
+            assert abs(got - g[key]) <= 5e-4 * abs(g[key]), (batch, key, got, float(g[key]))
+
+
 # ------------------------------------------------------------------ the reference's own checks
 @pytest.mark.parametrize('subtract_mean', [False, True])
 def test_pmf_check_grad_like_reference_notebook(pkg, subtract_mean):
