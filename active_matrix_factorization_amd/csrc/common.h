@@ -31,6 +31,9 @@ struct apmf_ctx {
     // threads), with the function that destroys it - libapmf_hip.so itself has no BLAS dependency
     void *blas;
     void (*blas_destroy)(void *);
+    // further handles for the slow lanes of k6_batch.hip (created at a lane's first pass, kept for the
+    // context's life: creating one costs tens of milliseconds - seconds when the library is cold)
+    void *lane_blas[4];
     // 4 KB of pinned host memory for small read-backs (apmf_d2h)
     void *rd_pin;
 };

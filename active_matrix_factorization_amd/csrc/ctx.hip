@@ -134,6 +134,8 @@ int apmf_ctx_destroy(apmf_ctx *ctx)
         delete[] ctx->prof_ev;
     }
     if (ctx->blas && ctx->blas_destroy) ctx->blas_destroy(ctx->blas);
+    for (int l = 0; l < 4; l++)
+        if (ctx->lane_blas[l] && ctx->blas_destroy) ctx->blas_destroy(ctx->lane_blas[l]);
     pool_release(ctx);
     delete ctx->pool;
     (void)hipStreamDestroy(ctx->own);

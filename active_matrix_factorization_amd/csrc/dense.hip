@@ -237,6 +237,28 @@ int apmf_dense_handle(apmf_ctx *ctx, void **out)
     return APMF_OK;
 }
 
+// handle of slow lane `lane` (0 .. 3) of this context, bound to `stream`
+int apmf_dense_lane_handle(apmf_ctx *ctx, int lane, hipStream_t stream, void **out)
+{
+    APMF_REQUIRE(ctx && out && lane >= 0 && lane < 4, "bad lane");
+    rocblas_handle h0;
+    APMF_TRY(handle_for(ctx, &h0));          // makes sure blas_destroy is set (and the library initialised)
+    if (!ctx->lane_blas[lane]) {
+        rocblas_handle h = nullptr;
+        if (rocblas_create_handle(&h) != rocblas_status_success) {
+            apmf_set_error("rocblas_create_handle failed for a slow lane");
+            return APMF_EHIP;
+        }
+        ctx->lane_blas[lane] = h;
+    }
+    if (rocblas_set_stream((rocblas_handle)ctx->lane_blas[lane], stream) != rocblas_status_success) {
+        apmf_set_error("rocblas_set_stream failed");
+        return APMF_EHIP;
+    }
+    *out = ctx->lane_blas[lane];
+    return APMF_OK;
+}
+
 int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, int *h_projected)
 {
     APMF_REQUIRE(ctx && d_mat, "NULL operand");

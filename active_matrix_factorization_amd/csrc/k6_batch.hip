@@ -49,6 +49,7 @@
 #include "common.h"
 
 extern "C" int apmf_dense_handle(apmf_ctx *ctx, void **out);
+extern "C" int apmf_dense_lane_handle(apmf_ctx *ctx, int lane, hipStream_t stream, void **out);
 
 extern "C" int apmf_dense_project_psd(apmf_ctx *ctx, double *d_mat, int N, double min_eig, int *h_projected);
 extern "C" int apmf_dense_inv_logdet(apmf_ctx *ctx, const double *d_mat, int N, double *d_inv, double *h_logdet);
@@ -1086,7 +1087,7 @@ constexpr int SEL_SLOTS = 3 + 2 * (MAX_LANES + 1);   // 0 active, 1 gradient, 2 
 struct EigSet {
     hipStream_t stream = nullptr;
     hipEvent_t ev = nullptr;
-    void *handle = nullptr;            // rocblas_handle, created at the first pass
+    void *handle = nullptr;            // rocblas_handle of the lane (owned by the context)
     double **ptrs = nullptr;           // [H]
     double *evals = nullptr, *evE = nullptr;   // [H][N]
     int *evinfo = nullptr;             // [H]
@@ -1448,7 +1449,8 @@ int apmf_mn_batch_destroy(apmf_ctx *ctx, apmf_mn_batch *b)
     for (int l = 1; l <= MAX_LANES; l++) {
         EigSet &e = b->eig[l];
         if (e.stream) (void)hipStreamSynchronize(e.stream);
-        if (e.handle) (void)rocblas_destroy_handle((rocblas_handle)e.handle);
+        // the lane's handle outlives this batch (it is the context's): take it off the stream that goes away
+        if (e.handle) (void)rocblas_set_stream((rocblas_handle)e.handle, b->ctx->stream);
         if (e.stream) (void)hipStreamDestroy(e.stream);
         if (e.ev) (void)hipEventDestroy(e.ev);
     }
@@ -1852,15 +1854,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 parked.clear();
                 P.masks.clear();
                 for (int h : P.list) P.masks.push_back(b->hs_host[h].slow);
-                if (!e.handle) {
-                    rocblas_handle hnd = nullptr;
-                    if (rocblas_create_handle(&hnd) != rocblas_status_success ||
-                        rocblas_set_stream(hnd, e.stream) != rocblas_status_success) {
-                        apmf_set_error("rocblas_create_handle failed for a slow lane");
-                        return APMF_EHIP;
-                    }
-                    e.handle = hnd;
-                }
+                APMF_TRY(apmf_dense_lane_handle(ctx, free_lane, e.stream, &e.handle));     // the context's, kept
                 // the main stream is idle here (read_status synchronised it): the lane may start at once
                 hipStream_t saved = ctx->stream;
                 ctx->stream = e.stream;
