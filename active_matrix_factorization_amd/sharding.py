@@ -87,7 +87,7 @@ class Comm(object):
     store on MASTER_PORT - is skipped."""
 
     def __init__(self, rank=0, world=1, addr='127.0.0.1', port=None, ctx=None, rccl=None, tag='',
-                 timeout=120., span=32):
+                 timeout=300., span=32):
         self.rank, self.world = int(rank), int(world)
         self.ctx = ctx
         self._peers = None        # rank 0: sockets of ranks 1..world-1
