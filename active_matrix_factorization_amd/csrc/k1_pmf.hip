@@ -120,8 +120,15 @@ __device__ __forceinline__ double row_pass(const PmfParams &p, int lane, int sub
     const int d = p.d;
     const int k = lane % DP, g = lane / DP;
     const bool kok = k < d;
+    const int kc = kok ? k : 0;
     double acc = 0.;
-    for (int64_t t0 = beg + sub * G + g; t0 < end; t0 += (int64_t)STRIDE * UN) {
+    const int64_t span = end - (beg + sub * G);      // wave-uniform trip count
+    if (span <= 0) return acc;
+    // every load unconditional (entries past the end are read at the row's last entry, padding lanes
+    // at k = 0) and masked afterwards: a predicated load is a branch around the instruction, and a trip
+    // of those is a chain of waits instead of UN loads in flight
+    const int64_t last = end - 1;
+    for (int64_t t0 = beg + sub * G + g, done = 0; done < span; t0 += (int64_t)STRIDE * UN, done += (int64_t)STRIDE * UN) {
         int32_t c[UN];
         double r[UN], y[UN];
         bool ok[UN];
@@ -129,17 +136,19 @@ __device__ __forceinline__ double row_pass(const PmfParams &p, int lane, int sub
         for (int u = 0; u < UN; u++) {
             const int64_t t = t0 + (int64_t)u * STRIDE;
             ok[u] = t < end;
-            c[u] = ok[u] ? idx[t] : 0;
-            r[u] = ok[u] ? val[t] : 0.;
+            const int64_t tc = ok[u] ? t : last;
+            c[u] = idx[tc];
+            r[u] = val[tc];
         }
 #pragma unroll
-        for (int u = 0; u < UN; u++) y[u] = (ok[u] && kok) ? Y[(size_t)c[u] * d + k] : 0.;
+        for (int u = 0; u < UN; u++) y[u] = Y[(size_t)c[u] * d + kc];
 #pragma unroll
         for (int u = 0; u < UN; u++) {
-            const double pred = group_sum<DP>(xk * y[u]) + p.mean_add;
+            const double yv = (ok[u] && kok) ? y[u] : 0.;
+            const double pred = group_sum<DP>(xk * yv) + p.mean_add;
             if (GRAD) {
                 const double w = ok[u] ? (r[u] - pred) / p.sig : 0.;
-                acc += y[u] * w;
+                acc += yv * w;
             } else {
                 const double e = ok[u] ? (r[u] - pred) : 0.;
                 if (k == 0) acc += e * e;
