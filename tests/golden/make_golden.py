@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2i': only section J .. Q")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2j': only section J .. R")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -142,6 +142,9 @@ def main():
         return
     if args.only == 'r2i':
         round2i(np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r2j':
+        round2j(np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -484,6 +487,7 @@ def main():
     round2g(np, bayes_pmf, save, seed, _print)
     round2h(np, active_pmf, save, seed, _print)
     round2i(np, mn_active_pmf, save, seed, _print)
+    round2j(np, mn_active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -669,6 +673,26 @@ def round2i(np, mn_active_pmf, save, seed, _print):
         out[key] = getattr(a, key)(cand)
         _print('MN refit lookahead: %s = %r' % (key, out[key]))
     save('lookahead_c1_mn_refit', **out)
+
+
+def round2j(np, mn_active_pmf, save, seed, _print):
+    """R. One selection step of the matrix-normal loop under a LOOKAHEAD criterion (mn_active_pmf.py:660-755):
+    compare(['total-variance'], steps=2) on config 1 - every one of the 90 unrated entries x 5 rating values
+    is a deepcopy + add_rating + fit_normal to convergence + full-grid sum in the reference - under seed 47:
+    the pick, the evaluation grid and the RMSEs."""
+    g = np.load(os.path.join(HERE, 'trace_c1_mn.npz'))
+    real, ratings = g['real'], g['ratings']
+    t0 = time.perf_counter()
+    seed(47)
+    res = mn_active_pmf.compare(['total-variance'], real, ratings.copy(), rating_vals=(1, 2, 3, 4, 5), latent_d=2,
+                                do_threading=False, steps=2, discrete_exp=True)
+    steps = res['total-variance']
+    _print('lookahead selection step: pick %s, %.0f s' % (steps[1][2], time.perf_counter() - t0))
+    init = res['_initial_apmf']
+    save('trace_c1_mn_lookahead', real=real, ratings=ratings, seed=47, n_rated=np.array([s[0] for s in steps]),
+         rmse=np.array([s[1] for s in steps], dtype=np.float64), pick=np.array(steps[1][2]),
+         vals=np.array(steps[1][3], dtype=np.float64), init_users=init.users, init_items=init.items,
+         init_mean=init.mean, init_cov_useritems=init.cov_useritems, init_cov_latents=init.cov_latents)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):
