@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
 
 // Enqueue the factorisation of `njobs` matrices (all N x N).  The jobs' info words must have
 // been zeroed (or preset non-zero to skip a job) by the caller, on the same stream.
-static inline int chol_lower_jobs(apmf_ctx *ctx, const ChJobs &J, int njobs, int N)
+static inline int chol_lower_jobs_on(hipStream_t stream, const ChJobs &J, int njobs, int N)
 {
     if (njobs <= 0) return APMF_OK;
     // few matrices: the chain of launches is what costs, so each update launch also factors the next
@@ -430,19 +430,24 @@ static inline int chol_lower_jobs(apmf_ctx *ctx, const ChJobs &J, int njobs, int
                                   (int)next_lds);
     for (int k = 0; k < N; k += CH_NB) {
         const int nb = N - k < CH_NB ? N - k : CH_NB;
-        if (k == 0 || !next) hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, ctx->stream, J, N, k);
+        if (k == 0 || !next) hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, stream, J, N, k);
         const int rest = N - k - nb;
         if (rest > 0) {
-            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, ctx->stream, J, N, k);
+            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, stream, J, N, k);
             const int tiles = (rest + 63) / 64;
             if (next)
                 hipLaunchKernelGGL(k_chol_update<true>, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), next_lds,
-                                   ctx->stream, J, N, k);
+                                   stream, J, N, k);
             else
                 hipLaunchKernelGGL(k_chol_update<false>, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), 0,
-                                   ctx->stream, J, N, k);
+                                   stream, J, N, k);
         }
     }
     APMF_CHECK_LAUNCH();
     return APMF_OK;
+}
+
+static inline int chol_lower_jobs(apmf_ctx *ctx, const ChJobs &J, int njobs, int N)
+{
+    return chol_lower_jobs_on(ctx->stream, J, njobs, N);
 }

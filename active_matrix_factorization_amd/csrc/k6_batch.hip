@@ -983,6 +983,302 @@ __global__ __launch_bounds__(256) void kb_rebuild(const Refs R, const int *__res
     }
 }
 
+// ---- the same projection through the FEW eigenpairs below min_eig ------------------------------------------
+// A trial matrix that fails the certificate has, in practice, one eigenvalue below min_eig (two or three now
+// and then), well separated from the rest of the spectrum: V max(L, min_eig) V' is then
+// A + sum_{l_k < min_eig} (min_eig - l_k) v_k v_k', and the few pairs (l_k, v_k) cost a fraction of the full
+// eigendecomposition (12.5 ms of some 3000 dependent small kernels in rocSOLVER at 519 x 519):
+//   bracket   Cholesky of A - s I for a ladder of shifts s below min_eig, all in ONE batched factorisation
+//             (the jobs of a launch are independent): the largest shift that factors is a certified lower
+//             bound of the smallest eigenvalue, within a factor 2 of its distance to min_eig;
+//   iterate   inverse iteration x <- L^-T L^-1 x with the explicit triangular inverse of that factor (two
+//             matrix-vector launches per step), until the residual |A x - l x| of the Rayleigh pair is at
+//             rounding level;
+//   deflate   A <- A + (t - l) v v' moves the pair to the top of the spectrum; the certificate of the deflated
+//             matrix (one more Cholesky) says whether another eigenvalue is below min_eig - then once more.
+// Every sum has a fixed order and a hypothesis' arithmetic does not depend on the others of the pass, so the
+// result is the same alone or in any batch.  Anything unusual (no convergence, more than LP_KMAX pairs, a
+// smallest eigenvalue far below the ladder) falls back to the full eigendecomposition.
+constexpr int LP_NS = 14;      // jobs of a bracket: the certificate, 12 shifts, one below every eigenvalue
+constexpr int LP_KMAX = 6;     // eigenpairs found one after the other
+constexpr int LP_RS = 4;       // row splits of the transposed product
+constexpr int LP_CAP = 16;     // hypotheses per chunk (lists travel as kernel arguments)
+
+struct LpRefs {
+    double *Wk;       // [cap][LP_NS][N * N] shifted copies, factored in place
+    double *Linv;     // [cap][N * N]        strictly-lower blocks of the chosen factor's inverse
+    double *linv;     // [cap * LP_NS][nbk][64 * 64] inverses of the factors' diagonal blocks
+    double *zp;       // [cap][LP_RS][N]     partial sums of the iterate
+    double *u;        // [cap][N]
+    double *xh;       // [cap][N]            the normalised iterate
+    double *wv;       // [cap][N]            A xh
+    double *vecs;     // [cap][LP_KMAX][N]
+    double *lam;      // [cap][LP_KMAX]
+    double *out;      // [cap][2]            Rayleigh quotient, residual norm
+    unsigned long long *norm;   // [cap][2]  bit patterns of |A|_inf and max |a_ii| (non-negative doubles order like integers)
+    ChJob *jobs;      // [cap * LP_NS]
+    int *info;        // [cap * LP_NS]
+    int N, nbk;
+};
+
+struct LpList {
+    int n;
+    int y[LP_CAP];    // slot in the chunk
+    int h[LP_CAP];    // hypothesis
+    int a[LP_CAP];    // per-kernel meaning: chosen job / pair index / number of pairs
+};
+
+__device__ __forceinline__ double block_sum_256(double v, double *sh)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// |A|_inf and max |a_ii| of the working copy (W) of each listed hypothesis: a wave per row
+__global__ __launch_bounds__(256) void lp_norms(const Refs R, const LpRefs L, const LpList S)
+{
+    const int q = blockIdx.y, y = S.y[q], N = L.N;
+    const double *__restrict__ A = tabp(R, T_S_W, S.h[q]);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    double s = 0;
+    for (int c0 = 0; c0 < N; c0 += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = A[(size_t)row * N + min(c0 + k * 64 + lane, N - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s += c0 + k * 64 + lane < N ? fabs(v[k]) : 0.;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        atomicMax(L.norm + 2 * y, (unsigned long long)__double_as_longlong(s));
+        atomicMax(L.norm + 2 * y + 1, (unsigned long long)__double_as_longlong(fabs(A[(size_t)row * N + row])));
+    }
+}
+
+// the shift of job t of a bracket
+__device__ __forceinline__ double lp_shift_of(const LpRefs &L, int y, int t, double diag, double min_eig)
+{
+    if (t == 0) return min_eig + 1e-10 * fmax(fabs(diag), fabs(min_eig));       // the certificate of the fast path
+    const double ninf = __longlong_as_double((long long)L.norm[2 * y]);
+    const double scale = __longlong_as_double((long long)L.norm[2 * y + 1]);
+    if (t == LP_NS - 1) return -(2.02 * ninf + fabs(min_eig));                   // below every eigenvalue (deflated or not)
+    return min_eig - scale * exp2((double)(t - (LP_NS - 1)));                    // scale * 2^-12 ... scale / 2
+}
+
+// jobs t0 .. t0 + nt - 1 of each listed hypothesis: lower triangle of W - shift I into the job's slot, the job record
+__global__ __launch_bounds__(256) void lp_shift(const Refs R, const LpRefs L, const LpList S, int t0, int nt, double min_eig)
+{
+    const int q = blockIdx.y / nt, t = t0 + blockIdx.y % nt, y = S.y[q], N = L.N;
+    const int job = y * LP_NS + t;
+    const double *__restrict__ A = tabp(R, T_S_W, S.h[q]);
+    double *__restrict__ D = L.Wk + (size_t)job * N * N;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ChJob j;
+        j.A = D;
+        j.info = L.info + job;
+        j.linv = L.linv + (size_t)job * L.nbk * CH_NB * CH_NB;
+        j.linv_keep = 1;
+        L.info[job] = 0;
+        L.jobs[q * nt + (t - t0)] = j;
+    }
+    const size_t nn = (size_t)N * N;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / N), j = (int)(e % N);
+        if (j > i) continue;
+        const double v = A[e];
+        D[e] = i == j ? v - lp_shift_of(L, y, t, v, min_eig) : v;
+    }
+}
+
+// start vector: the same fixed pattern for every hypothesis (any vector with a component along the wanted
+// eigenvector does)
+__global__ void lp_init(const LpRefs L, const LpList S)
+{
+    const int y = S.y[blockIdx.y], N = L.N;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const unsigned int x = (unsigned int)i * 2654435761u + 12345u;
+    double *z = L.zp + (size_t)y * LP_RS * N;
+    z[i] = (double)((x >> 8) & 0xffff) / 65536. - .5 + 1. / 131072.;
+    for (int s = 1; s < LP_RS; s++) z[(size_t)s * N + i] = 0.;
+}
+
+// x = sum of the partial sums, normalised, into LDS (every block of a launch computes the same values)
+__device__ __forceinline__ void lp_load_x(const LpRefs &L, int y, double *xs, double *sh)
+{
+    const int N = L.N;
+    const double *__restrict__ z = L.zp + (size_t)y * LP_RS * N;
+    double ss = 0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const double v = (z[i] + z[N + i]) + (z[2 * (size_t)N + i] + z[3 * (size_t)N + i]);
+        xs[i] = v;
+        ss += v * v;
+    }
+    const double inv = 1. / sqrt(block_sum_256(ss, sh));
+    for (int i = threadIdx.x; i < N; i += 256) xs[i] *= inv;
+    __syncthreads();
+}
+
+// u = L^-1 xh: 16 rows per block, 4 per wave; the strictly-lower blocks come from Linv, the diagonal block
+// from the factor's kept inverses
+__global__ __launch_bounds__(256) void lp_fwd(const LpRefs L, const LpList S)
+{
+    extern __shared__ double xs[];
+    __shared__ double sh[4];
+    const int q = blockIdx.y, y = S.y[q], N = L.N;
+    lp_load_x(L, y, xs, sh);
+    const double *__restrict__ Li = L.Linv + (size_t)y * N * N;
+    const double *__restrict__ Dg = L.linv + (size_t)(y * LP_NS + S.a[q]) * L.nbk * CH_NB * CH_NB;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * 16 + w * 4;
+    const int bi = (blockIdx.x * 16) / 64;           // the 16 rows of a block lie in one block row
+    double acc[4] = {0., 0., 0., 0.};
+    for (int cb = 0; cb < bi; cb++) {
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = Li[(size_t)min(r0 + k, N - 1) * N + cb * 64 + lane];
+        const double x = xs[cb * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] += v[k] * x;
+    }
+    {
+        const double *__restrict__ D = Dg + (size_t)bi * CH_NB * CH_NB;
+        const double x = bi * 64 + lane < N ? xs[bi * 64 + lane] : 0.;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rl = min(r0 + k, N - 1) - bi * 64;
+            acc[k] += lane <= rl ? D[rl * CH_NB + lane] * x : 0.;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0 && r0 + k < N) L.u[(size_t)y * N + r0 + k] = s;
+    }
+}
+
+// z = L^-T u, as LP_RS partial sums: block (column block j, split s) takes the rows j*64 + s*4 + w + 16 t
+__global__ __launch_bounds__(256) void lp_bwd(const LpRefs L, const LpList S)
+{
+    __shared__ double red[4][64];
+    const int q = blockIdx.y, y = S.y[q], N = L.N;
+    const int j = blockIdx.x / LP_RS, s = blockIdx.x % LP_RS;
+    const double *__restrict__ Li = L.Linv + (size_t)y * N * N;
+    const double *__restrict__ D = L.linv + ((size_t)(y * LP_NS + S.a[q]) * L.nbk + j) * CH_NB * CH_NB;
+    const double *__restrict__ u = L.u + (size_t)y * N;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = j * 64 + lane, cc = min(c, N - 1);
+    double acc = 0.;
+    for (int r = j * 64 + s * 4 + w; r < N; r += 16 * 4) {
+        double v[4], ur[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rr = min(r + 16 * k, N - 1);
+            const int rl = rr - j * 64;
+            const double *p = rl < 64 ? D + rl * CH_NB + lane : Li + (size_t)rr * N + cc;
+            v[k] = *p;
+            ur[k] = u[rr];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int rr = r + 16 * k;
+            acc += (rr < N && c <= rr) ? v[k] * ur[k] : 0.;
+        }
+    }
+    red[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < N)
+        L.zp[((size_t)y * LP_RS + s) * N + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// wv = W xh (the hypothesis' working matrix, full rows); block 0 also leaves xh
+__global__ __launch_bounds__(256) void lp_resid(const Refs R, const LpRefs L, const LpList S)
+{
+    extern __shared__ double xs[];
+    __shared__ double sh[4];
+    const int q = blockIdx.y, y = S.y[q], N = L.N;
+    lp_load_x(L, y, xs, sh);
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < N; i += 256) L.xh[(size_t)y * N + i] = xs[i];
+    const double *__restrict__ A = tabp(R, T_S_W, S.h[q]);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * 16 + w * 4;
+    double acc[4] = {0., 0., 0., 0.};
+    for (int c0 = 0; c0 < N; c0 += 64) {
+        double v[4];
+        const int c = min(c0 + lane, N - 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = A[(size_t)min(r0 + k, N - 1) * N + c];
+        const double x = c0 + lane < N ? xs[c] : 0.;
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] += v[k] * x;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0 && r0 + k < N) L.wv[(size_t)y * N + r0 + k] = s;
+    }
+}
+
+// out = {l = xh' A xh, |A xh - l xh|}
+__global__ __launch_bounds__(256) void lp_final(const LpRefs L, const LpList S)
+{
+    __shared__ double sh[4];
+    const int y = S.y[blockIdx.x], N = L.N;
+    const double *__restrict__ x = L.xh + (size_t)y * N, *__restrict__ w = L.wv + (size_t)y * N;
+    double s = 0;
+    for (int i = threadIdx.x; i < N; i += 256) s += x[i] * w[i];
+    const double lam = block_sum_256(s, sh);
+    double rr = 0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const double e = w[i] - lam * x[i];
+        rr += e * e;
+    }
+    const double res = sqrt(block_sum_256(rr, sh));
+    if (threadIdx.x == 0) {
+        L.out[2 * y] = lam;
+        L.out[2 * y + 1] = res;
+    }
+}
+
+// keep the pair (slot a) and move it to the top of the working matrix' spectrum: W += (t - l) xh xh'
+__global__ __launch_bounds__(256) void lp_commit(const Refs R, const LpRefs L, const LpList S)
+{
+    const int q = blockIdx.y, y = S.y[q], N = L.N, k = S.a[q];
+    const double *__restrict__ x = L.xh + (size_t)y * N;
+    const double lam = L.out[2 * y];
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < N; i += 256) L.vecs[((size_t)y * LP_KMAX + k) * N + i] = x[i];
+        if (threadIdx.x == 0) L.lam[y * LP_KMAX + k] = lam;
+    }
+    const double coef = __longlong_as_double((long long)L.norm[2 * y]) - lam;
+    double *__restrict__ A = tabp(R, T_S_W, S.h[q]);
+    const size_t nn = (size_t)N * N;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / N), j = (int)(e % N);
+        A[e] += coef * (x[i] * x[j]);
+    }
+}
+
+// cand += sum_k (min_eig - l_k) v_k v_k' over the a pairs of each listed hypothesis
+__global__ __launch_bounds__(256) void lp_apply(const Refs R, const LpRefs L, const LpList S, double min_eig)
+{
+    const int q = blockIdx.y, y = S.y[q], N = L.N, nk = S.a[q];
+    double *__restrict__ C = tabp(R, T_S_CAND, S.h[q]);
+    const double *__restrict__ V = L.vecs + (size_t)y * LP_KMAX * N;
+    const size_t nn = (size_t)N * N;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / N), j = (int)(e % N);
+        double add = 0.;
+        for (int k = 0; k < nk; k++) add += (min_eig - L.lam[y * LP_KMAX + k]) * (V[(size_t)k * N + i] * V[(size_t)k * N + j]);
+        C[e] += add;
+    }
+}
+
 // ---- K2 inputs from the resident states ----------------------------------------------------------------
 // contiguous (B, ...) arrays of the current points of the selected hypotheses: mean (B, N, d),
 // cross (B, n, ld) = cov_useritems[:n, n:], diag (B, N), omega (B, d, d); T = double or float
@@ -1093,13 +1389,20 @@ struct EigSet {
     int *evinfo = nullptr;             // [H]
     ChJob *jobs = nullptr;             // [H] job list of the re-factorisations
     int slot0 = 0;                     // selection-list slots slot0, slot0 + 1
+    // projection through the lowest eigenpairs: workspace (low_ensure), chunk size
+    LpRefs lp;
+    int lp_cap = 0;
+    double **lp_tab = nullptr;         // [T_COUNT][lp_cap * LP_NS] job table for the triangular inverse
+    int *lp_sel = nullptr;             // [lp_cap] device selection list
+    int *lp_host = nullptr;            // pinned: info words, selection, norms, Rayleigh pairs
+    int n_full = 0;                    // matrices of the last pass that went through the full eigendecomposition
 };
 
 struct apmf_mn_batch {
     apmf_ctx *ctx;
     const apmf_ratings *r;
     Refs R;                       // device pointers
-    void *blocks[64];             // every device allocation, for destroy
+    void *blocks[128];            // every device allocation, for destroy
     int nblocks;
     HypState *hs_host;            // pinned mirror
     int *sel_host;                // pinned, SEL_SLOTS * H ints
@@ -1217,6 +1520,13 @@ int write_ld(apmf_mn_batch *b, int h, const double *ld_s, const double *ld_o)
 struct SlowS {
     std::vector<int> proj, refac;
     void *handle = nullptr;
+    // projection through the lowest eigenpairs (the default; APMF_BATCH_EIG=full: always the full decomposition)
+    bool low = false;
+    hipStream_t stream = nullptr;
+    EigSet *set = nullptr;
+    int *dsel = nullptr;               // the set's first selection-list slot
+    double min_eig = 0.;
+    std::vector<int> full;             // hypotheses that go through the full eigendecomposition
 };
 
 // the batch's device references with the eigen buffers of one set
@@ -1230,53 +1540,294 @@ Refs set_refs(const apmf_mn_batch *b, const EigSet &e)
     return R;
 }
 
+// ---- host side of the projection through the few lowest eigenpairs (kernels lp_* above) -------------------
+// workspace of a set, allocated by the search thread on first use
+int low_ensure(apmf_mn_batch *b, EigSet &e)
+{
+    if (e.lp_cap) return APMF_OK;
+    const Refs &R = b->R;
+    const size_t nn = (size_t)R.N * R.N, blk = (size_t)CH_NB * CH_NB;
+    int cap = (int)std::min<size_t>(LP_CAP, std::max<size_t>(1, (size_t)1536e6 / (LP_NS * nn * sizeof(double))));
+    cap = std::min(cap, R.H);
+    const size_t nj = (size_t)cap * LP_NS;
+    LpRefs L;
+    memset(&L, 0, sizeof(L));
+    L.N = R.N;
+    L.nbk = R.nbk;
+    int rc = APMF_OK;
+#define LA(ptr, bytes)                                                                          \
+    do {                                                                                        \
+        if (rc == APMF_OK && b->nblocks >= (int)(sizeof(b->blocks) / sizeof(b->blocks[0]))) rc = APMF_ENOMEM; \
+        if (rc == APMF_OK) rc = balloc(b, (bytes), (void **)&(ptr));                            \
+    } while (0)
+    LA(L.Wk, nj * nn * sizeof(double));
+    LA(L.Linv, (size_t)cap * nn * sizeof(double));
+    LA(L.linv, nj * R.nbk * blk * sizeof(double));
+    LA(L.zp, (size_t)cap * (LP_RS + 3 + LP_KMAX) * R.N * sizeof(double));
+    LA(L.lam, (size_t)cap * (LP_KMAX + 2 + 2) * sizeof(double));
+    LA(L.jobs, nj * sizeof(ChJob));
+    LA(L.info, (nj + cap) * sizeof(int));
+    LA(e.lp_tab, (size_t)T_COUNT * nj * sizeof(double *));
+#undef LA
+    if (rc == APMF_OK && hipHostMalloc((void **)&e.lp_host, (nj + cap) * sizeof(int) + 4 * (size_t)cap * sizeof(double),
+                                       hipHostMallocDefault) != hipSuccess)
+        rc = APMF_ENOMEM;
+    if (rc != APMF_OK) {
+        apmf_set_error("out of memory for the eigenpair workspace (N=%d)", R.N);
+        return rc;
+    }
+    L.u = L.zp + (size_t)cap * LP_RS * R.N;
+    L.xh = L.u + (size_t)cap * R.N;
+    L.wv = L.xh + (size_t)cap * R.N;
+    L.vecs = L.wv + (size_t)cap * R.N;
+    L.out = L.lam + (size_t)cap * LP_KMAX;
+    L.norm = (unsigned long long *)(L.out + 2 * (size_t)cap);
+    e.lp_sel = L.info + nj;
+    // the table the triangular-inverse kernel reads: "hypothesis" = job; F = the job's factor, W = its slot's Linv
+    std::vector<double *> tab((size_t)T_COUNT * nj, nullptr);
+    for (size_t j = 0; j < nj; j++) {
+        tab[(size_t)T_S_F * nj + j] = L.Wk + j * nn;
+        tab[(size_t)T_S_W * nj + j] = L.Linv + (j / LP_NS) * nn;
+    }
+    APMF_TRY(apmf_h2d(b->ctx, e.lp_tab, tab.data(), tab.size() * sizeof(double *)));
+    e.lp = L;
+    e.lp_cap = cap;
+    return APMF_OK;
+}
+
+// Projection of the listed hypotheses' trial matrices (cand; W holds a copy) through their eigenpairs below
+// min_eig; every launch goes to `st`, and the call returns with the stream drained.  Hypotheses it cannot
+// finish are appended to `fallback` with cand untouched.  Thread-safe with respect to the search thread: it
+// only touches the set's own buffers and the listed hypotheses' cand / W.
+int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vector<int> &hyps, double min_eig,
+                std::vector<int> &fallback)
+{
+    const LpRefs &L = e.lp;
+    const int N = R.N, cap = e.lp_cap, nj = cap * LP_NS;
+    int *info_h = e.lp_host, *sel_h = info_h + nj;
+    double *out_h = (double *)(sel_h + cap);            // (nj + cap is even: LP_NS is)
+    unsigned long long *norm_h = (unsigned long long *)(out_h + 2 * (size_t)cap);
+    static const bool debug = getenv("APMF_DEBUG_LOW") != nullptr;
+    Refs R2 = R;                       // the triangular inverse of the chosen factors, through the job table
+    R2.tab = e.lp_tab;
+    R2.H = nj;
+    R2.linvF = L.linv;
+    const size_t xs_bytes = (size_t)N * sizeof(double);
+    const dim3 g_rows((N + 15) / 16), g_mat((unsigned)std::min<size_t>(((size_t)N * N + 255) / 256, 1024));
+    auto sync_read = [&](void *dst, const void *src, size_t bytes) -> int {
+        APMF_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+        APMF_CHECK_HIP(hipStreamSynchronize(st));
+        return APMF_OK;
+    };
+    for (size_t c0 = 0; c0 < hyps.size(); c0 += cap) {
+        const int nc = (int)std::min<size_t>(cap, hyps.size() - c0);
+        std::vector<int> todo(nc), npairs(nc, 0), rung(nc, 0);
+        std::vector<char> failed(nc, 0);
+        for (int y = 0; y < nc; y++) todo[y] = y;
+        auto list_of = [&](const std::vector<int> &ys) {
+            LpList S;
+            memset(&S, 0, sizeof(S));
+            S.n = (int)ys.size();
+            for (int q = 0; q < S.n; q++) {
+                S.y[q] = ys[q];
+                S.h[q] = hyps[c0 + ys[q]];
+            }
+            return S;
+        };
+        APMF_CHECK_HIP(hipMemsetAsync(L.norm, 0, 2 * (size_t)cap * sizeof(unsigned long long), st));
+        {
+            const LpList S = list_of(todo);
+            hipLaunchKernelGGL(lp_norms, dim3((N + 3) / 4, nc), dim3(256), 0, st, R, L, S);
+        }
+        for (int round = 0; !todo.empty(); round++) {
+            if (round > 0) {
+                // has the deflated matrix anything left below min_eig?  its certificate, alone
+                const LpList S = list_of(todo);
+                hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, S.n), dim3(256), 0, st, R, L, S, 0, 1, min_eig);
+                APMF_CHECK_LAUNCH();
+                ChJobs J;
+                memset(&J, 0, sizeof(J));
+                J.list = L.jobs;
+                APMF_TRY(chol_lower_jobs_on(st, J, S.n, N));
+                APMF_TRY(sync_read(info_h, L.info, (size_t)nj * sizeof(int)));
+                std::vector<int> rest;
+                for (int y : todo)
+                    if (info_h[y * LP_NS] != 0) rest.push_back(y);
+                todo.swap(rest);
+                if (todo.empty()) break;
+            }
+            if (round >= LP_KMAX) {
+                for (int y : todo) failed[y] = 1;
+                break;
+            }
+            // bracket: the ladder of shifts, one batched factorisation
+            LpList S = list_of(todo);
+            hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, S.n * (LP_NS - 1)), dim3(256), 0, st, R, L, S, 1, LP_NS - 1, min_eig);
+            APMF_CHECK_LAUNCH();
+            {
+                ChJobs J;
+                memset(&J, 0, sizeof(J));
+                J.list = L.jobs;
+                APMF_TRY(chol_lower_jobs_on(st, J, S.n * (LP_NS - 1), N));
+            }
+            if (round == 0)
+                APMF_CHECK_HIP(hipMemcpyAsync(norm_h, L.norm, 2 * (size_t)cap * sizeof(unsigned long long),
+                                              hipMemcpyDeviceToHost, st));
+            APMF_TRY(sync_read(info_h, L.info, (size_t)nj * sizeof(int)));
+            {
+                std::vector<int> ok;
+                for (int y : todo) {
+                    int t = 1;
+                    while (t < LP_NS && info_h[y * LP_NS + t] != 0) t++;
+                    // (the last rung is below every eigenvalue; one that sits there converges too slowly to bother)
+                    if (t >= LP_NS - 1) { failed[y] = 1; continue; }
+                    sel_h[ok.size()] = y * LP_NS + t;
+                    rung[y] = t;
+                    ok.push_back(y);
+                }
+                todo.swap(ok);
+                if (todo.empty()) break;
+                S = list_of(todo);
+                for (int q = 0; q < S.n; q++) S.a[q] = rung[S.y[q]];
+            }
+            APMF_CHECK_HIP(hipMemcpyAsync(e.lp_sel, sel_h, (size_t)S.n * sizeof(int), hipMemcpyHostToDevice, st));
+            for (int k = 0; k + 1 < R.nbk; k++)
+                hipLaunchKernelGGL(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), S.n), dim3(256), 0, st, R2, e.lp_sel, k);
+            hipLaunchKernelGGL(lp_init, dim3((N + 255) / 256, S.n), dim3(256), 0, st, L, S);
+            APMF_CHECK_LAUNCH();
+            // inverse iteration, the Rayleigh pair and its residual looked at every few steps
+            std::vector<int> run = todo;
+            std::vector<double> prev(nc, 1e300);
+            std::vector<char> conv(nc, 0);
+            for (int chk = 0; chk < 48 && !run.empty(); chk++) {
+                LpList T = list_of(run);
+                for (int q = 0; q < T.n; q++) T.a[q] = rung[T.y[q]];
+                for (int it = 0; it < (chk == 0 ? 12 : 6); it++) {
+                    hipLaunchKernelGGL(lp_fwd, dim3(g_rows.x, T.n), dim3(256), xs_bytes, st, L, T);
+                    hipLaunchKernelGGL(lp_bwd, dim3(R.nbk * LP_RS, T.n), dim3(256), 0, st, L, T);
+                }
+                hipLaunchKernelGGL(lp_resid, dim3(g_rows.x, T.n), dim3(256), xs_bytes, st, R, L, T);
+                hipLaunchKernelGGL(lp_final, dim3(T.n), dim3(256), 0, st, L, T);
+                APMF_CHECK_LAUNCH();
+                APMF_TRY(sync_read(out_h, L.out, 2 * (size_t)cap * sizeof(double)));
+                std::vector<int> more;
+                for (int y : run) {
+                    const double res = out_h[2 * y + 1];
+                    double ninf;
+                    memcpy(&ninf, norm_h + 2 * y, sizeof(double));       // |A|_inf of the undeflated matrix
+                    if (debug) fprintf(stderr, "[low] h %d round %d check %d: lambda %.17g res %.3e\n", hyps[c0 + y], round, chk,
+                                       out_h[2 * y], res);
+                    const bool good = res <= 1e-15 * ninf || (res <= 1e-12 * ninf && res > .5 * prev[y]);
+                    prev[y] = res;
+                    if (good && res == res) conv[y] = 1;
+                    else more.push_back(y);
+                }
+                run.swap(more);
+            }
+            for (int y : run) failed[y] = 1;
+            // pairs below min_eig are kept and deflated; a smallest eigenvalue that is not below ends the hypothesis
+            std::vector<int> keep;
+            for (int y : todo) {
+                if (!conv[y]) continue;
+                if (out_h[2 * y] < min_eig) keep.push_back(y);
+            }
+            if (!keep.empty()) {
+                LpList K = list_of(keep);
+                for (int q = 0; q < K.n; q++) K.a[q] = npairs[keep[q]]++;
+                hipLaunchKernelGGL(lp_commit, dim3(g_mat.x, K.n), dim3(256), 0, st, R, L, K);
+                APMF_CHECK_LAUNCH();
+            }
+            todo.swap(keep);
+        }
+        std::vector<int> app;
+        for (int y = 0; y < nc; y++) {
+            if (failed[y]) fallback.push_back(hyps[c0 + y]);
+            else if (npairs[y] > 0) app.push_back(y);
+        }
+        if (!app.empty()) {
+            LpList A = list_of(app);
+            for (int q = 0; q < A.n; q++) A.a[q] = npairs[app[q]];
+            hipLaunchKernelGGL(lp_apply, dim3(g_mat.x, A.n), dim3(256), 0, st, R, L, A, min_eig);
+            APMF_CHECK_LAUNCH();
+        }
+        APMF_CHECK_HIP(hipStreamSynchronize(st));     // the next chunk reuses the buffers the host reads
+    }
+    return APMF_OK;
+}
+
 // handle: bound to the current stream by the caller
-int slow_S_pre(apmf_mn_batch *b, const EigSet &e, void *handle, const std::vector<int> &list,
-               const std::vector<int> &masks, SlowS &w)
+int slow_S_pre(apmf_mn_batch *b, EigSet &e, void *handle, const std::vector<int> &list,
+               const std::vector<int> &masks, SlowS &w, double min_eig)
 {
     const Refs R = set_refs(b, e);
     hipStream_t st = b->ctx->stream;
     w.proj.clear();
     w.refac.clear();
+    w.full.clear();
     w.handle = handle;
+    w.stream = st;
+    w.set = &e;
+    w.min_eig = min_eig;
+    w.dsel = b->sel_dev + (size_t)e.slot0 * R.H;
+    static const bool full_only = getenv("APMF_BATCH_EIG") && !strcmp(getenv("APMF_BATCH_EIG"), "full");
+    w.low = !full_only;
+    e.n_full = 0;
     for (size_t q = 0; q < list.size(); q++) {
         if (masks[q] & SLOW_CERT_S) w.proj.push_back(list[q]);
         if (masks[q] & (SLOW_CERT_S | SLOW_FACT_S)) w.refac.push_back(list[q]);
     }
     if (w.proj.empty()) return APMF_OK;
+    if (w.low) APMF_TRY(low_ensure(b, e));
     const size_t nn = (size_t)R.N * R.N;
     const int np = (int)w.proj.size();
     const int *dsel;
     APMF_TRY(upload_sel(b, e.slot0, w.proj, &dsel));
     hipLaunchKernelGGL(kb_copy, g2(nn, np, 256), dim3(256), 0, st, R, dsel, (int)T_S_CAND, (int)T_S_W, nn);
-    hipLaunchKernelGGL(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
+    if (!w.low) hipLaunchKernelGGL(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
 
-// thread-safe with respect to everything but the handle
-rocblas_status slow_S_solve(const Refs &R, const SlowS &w)
+// thread-safe with respect to everything but the handle and the set
+rocblas_status slow_S_solve(const Refs &R, SlowS &w)
 {
     if (w.proj.empty()) return rocblas_status_success;
+    hipStream_t st = w.stream;
+    if (w.low) {
+        if (low_project(R, *w.set, st, w.proj, w.min_eig, w.full) != APMF_OK) return rocblas_status_internal_error;
+        if (w.full.empty()) return rocblas_status_success;
+        // the leftovers: a fresh copy of their trial matrices, the pointer list
+        const int nf = (int)w.full.size();
+        const size_t nn = (size_t)R.N * R.N;
+        if (hipMemcpyAsync(w.dsel, w.full.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)      // (w.full is pageable: the copy is staged before the call returns anyway)
+            return rocblas_status_internal_error;
+        hipLaunchKernelGGL(kb_copy, g2(nn, nf, 256), dim3(256), 0, st, R, w.dsel, (int)T_S_CAND, (int)T_S_W, nn);
+        hipLaunchKernelGGL(kb_ptrs, dim3((nf + 63) / 64), dim3(64), 0, st, R, w.dsel, nf, (int)T_S_W);
+        if (hipGetLastError() != hipSuccess) return rocblas_status_internal_error;
+    } else {
+        w.full = w.proj;
+    }
     // (replaying the call from a captured hipGraph was tried: same 12.5 ms per pass - the ~3000 small
     // kernels of a 519 x 519 syevd execute one after the other either way)
     return rocsolver_dsyevd_batched((rocblas_handle)w.handle, rocblas_evect_original, rocblas_fill_lower, R.N, R.ptrs,
-                                    R.N, R.evals, R.N, R.evE, R.N, R.evinfo, (int)w.proj.size());
+                                    R.N, R.evals, R.N, R.evE, R.N, R.evinfo, (int)w.full.size());
 }
 
-int slow_S_post(apmf_mn_batch *b, const EigSet &e, const SlowS &w, rocblas_status rs, bool trial, double min_eig)
+int slow_S_post(apmf_mn_batch *b, EigSet &e, const SlowS &w, rocblas_status rs, bool trial, double min_eig)
 {
     const Refs R = set_refs(b, e);
     hipStream_t st = b->ctx->stream;
     const int tS = trial ? T_S_CAND : T_S_CUR;
     const size_t nn = (size_t)R.N * R.N;
     if (rs != rocblas_status_success) {
-        apmf_set_error("rocsolver_dsyevd_batched failed: rocblas_status %d", (int)rs);
+        apmf_set_error("eigen-projection of a batch failed: rocblas_status %d", (int)rs);
         return APMF_EHIP;
     }
-    if (!w.proj.empty()) {
-        const int *dsel = b->sel_dev + (size_t)e.slot0 * R.H;      // uploaded by slow_S_pre
-        hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, (int)w.proj.size()), dim3(256), 0, st, R, dsel,
+    e.n_full = (int)w.full.size();
+    if (!w.full.empty()) {
+        const int *dsel = b->sel_dev + (size_t)e.slot0 * R.H;      // uploaded by slow_S_pre / slow_S_solve
+        hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, (int)w.full.size()), dim3(256), 0, st, R, dsel,
                            min_eig);
         APMF_CHECK_LAUNCH();
     }
@@ -1298,8 +1849,9 @@ int slow_S_enqueue(apmf_mn_batch *b, const std::vector<int> &list, const std::ve
     SlowS w;
     void *hv = nullptr;
     APMF_TRY(apmf_dense_handle(b->ctx, &hv));      // binds the handle to the current stream
-    APMF_TRY(slow_S_pre(b, b->eig[0], hv, list, masks, w));
-    return slow_S_post(b, b->eig[0], w, slow_S_solve(set_refs(b, b->eig[0]), w), trial, min_eig);
+    APMF_TRY(slow_S_pre(b, b->eig[0], hv, list, masks, w, min_eig));
+    const rocblas_status rs = slow_S_solve(set_refs(b, b->eig[0]), w);
+    return slow_S_post(b, b->eig[0], w, rs, trial, min_eig);
 }
 
 // Host side of the same, once the enqueued work has completed: convergence of the eigensolver, LU
@@ -1310,10 +1862,9 @@ int slow_finish(apmf_mn_batch *b, const EigSet &e, const std::vector<int> &list,
     const Refs R = set_refs(b, e);
     const int H = R.H, N = R.N, d = R.d;
     const int tS = trial ? T_S_CAND : T_S_CUR, tO = trial ? T_O_CAND : T_O_CUR, tOI = trial ? T_OI_CAND : T_OI_CUR;
-    int np = 0;
+    const int np = e.n_full;
     bool any_refac = false, any_o = false;
     for (size_t q = 0; q < list.size(); q++) {
-        if (masks[q] & SLOW_CERT_S) np++;
         if (masks[q] & (SLOW_CERT_S | SLOW_FACT_S)) any_refac = true;
         if (masks[q] & (SLOW_CERT_O | SLOW_INV_O)) any_o = true;
     }
@@ -1454,6 +2005,8 @@ int apmf_mn_batch_destroy(apmf_ctx *ctx, apmf_mn_batch *b)
         if (e.stream) (void)hipStreamDestroy(e.stream);
         if (e.ev) (void)hipEventDestroy(e.ev);
     }
+    for (int l = 0; l <= MAX_LANES; l++)
+        if (b->eig[l].lp_host) (void)hipHostFree(b->eig[l].lp_host);
     if (b->hs_host) (void)hipHostFree(b->hs_host);
     if (b->sel_host) (void)hipHostFree(b->sel_host);
     delete b;
@@ -1741,7 +2294,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         if (!P.solving) return APMF_OK;
         if (P.thr.joinable()) P.thr.join();
         P.solving = false;
-        const EigSet &e = b->eig[l + 1];
+        EigSet &e = b->eig[l + 1];
         hipStream_t saved = ctx->stream;
         ctx->stream = e.stream;
         int rc = slow_S_post(b, e, P.w, P.rs, true, min_eig);
@@ -1858,7 +2411,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 // the main stream is idle here (read_status synchronised it): the lane may start at once
                 hipStream_t saved = ctx->stream;
                 ctx->stream = e.stream;
-                int rc = slow_S_pre(b, e, e.handle, P.list, P.masks, P.w);
+                int rc = slow_S_pre(b, e, e.handle, P.list, P.masks, P.w, min_eig);
                 ctx->stream = saved;
                 if (rc != APMF_OK) return rc;
                 P.enq.store(0, std::memory_order_relaxed);

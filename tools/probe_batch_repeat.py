@@ -17,10 +17,13 @@ a = mn.MNActivePMF(ratings, latent_d=d, rating_values=range(1, 6), discrete_expe
 a.do_fit(); a.initialize_approx(); a.fit_normal()
 pool = sorted(a.unrated)[:2]
 out = []
-for lanes in ('3', '1', '3'):
+import time
+for lanes in (sys.argv[1].split(',') if len(sys.argv) > 1 else ('3', '1', '3')):
     os.environ['APMF_BATCH_LANES'] = lanes
+    t = time.perf_counter()
     vals = a._get_key_vals(pool, mn.KEY_FUNCS['total-variance'])
+    print('lanes %s: %.3f s' % (lanes, time.perf_counter() - t), flush=True)
     out.append(vals)
     print(lanes, [repr(float(x)) for x in vals], flush=True)
-assert out[0] == out[1] == out[2], 'batched lookahead values differ between runs / lane counts'
+assert all(o == out[0] for o in out), 'batched lookahead values differ between runs / lane counts'
 print('identical')
