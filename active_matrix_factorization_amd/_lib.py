@@ -108,6 +108,7 @@ _DENSE_SIGS.update({
     'apmf_mn_batch_create': (_i, [_vp, _vp, _i, _i, _i64, C.POINTER(_vp)]),
     'apmf_mn_batch_destroy': (_i, [_vp, _vp]),
     'apmf_mn_batch_size': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    'apmf_mn_batch_fit_stats': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     'apmf_mn_batch_set_state': (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     'apmf_mn_batch_set_extra': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'apmf_mn_batch_get_state': (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -419,6 +420,13 @@ class MNBatch(object):
                                              int(max_steps), trace.ctypes.data if self.trace_cap else None,
                                              steps.ctypes.data, conv.ctypes.data))
         return lr_io, kl_io, steps, conv.astype(bool), trace
+
+    def fit_stats(self):
+        """Counters of the last fit(): search iterations, trial points, projections finished through the lowest
+        eigenpairs / through the full eigendecomposition."""
+        v = [C.c_int64(0) for _ in range(4)]
+        _check(self._dense.apmf_mn_batch_fit_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(('iterations', 'trials', 'proj_low', 'proj_full'), (int(x.value) for x in v)))
 
     def kl(self, sig, sig_u, sig_v):
         out = np.empty(self.H)

@@ -1060,8 +1060,13 @@ __global__ __launch_bounds__(256) void lp_norms(const Refs R, const LpRefs L, co
 }
 
 // the shift of job t of a bracket
-__device__ __forceinline__ double lp_shift_of(const LpRefs &L, int y, int t, double diag, double min_eig)
+__device__ __forceinline__ double lp_shift_of(const LpRefs &L, int y, int t, double diag, double min_eig, int local)
 {
+    if (local) {
+        // ladder below the current Rayleigh pair: an eigenvalue lies within the residual norm of the quotient
+        const double rho = L.out[2 * y], res = L.out[2 * y + 1];
+        return rho - (res * exp2((double)(t - 1)) * (1. + 1e-6) + 4e-16 * fabs(rho));
+    }
     if (t == 0) return min_eig + 1e-10 * fmax(fabs(diag), fabs(min_eig));       // the certificate of the fast path
     const double ninf = __longlong_as_double((long long)L.norm[2 * y]);
     const double scale = __longlong_as_double((long long)L.norm[2 * y + 1]);
@@ -1070,7 +1075,8 @@ __device__ __forceinline__ double lp_shift_of(const LpRefs &L, int y, int t, dou
 }
 
 // jobs t0 .. t0 + nt - 1 of each listed hypothesis: lower triangle of W - shift I into the job's slot, the job record
-__global__ __launch_bounds__(256) void lp_shift(const Refs R, const LpRefs L, const LpList S, int t0, int nt, double min_eig)
+__global__ __launch_bounds__(256) void lp_shift(const Refs R, const LpRefs L, const LpList S, int t0, int nt, double min_eig,
+                                                int local)
 {
     const int q = blockIdx.y / nt, t = t0 + blockIdx.y % nt, y = S.y[q], N = L.N;
     const int job = y * LP_NS + t;
@@ -1090,7 +1096,7 @@ __global__ __launch_bounds__(256) void lp_shift(const Refs R, const LpRefs L, co
         const int i = (int)(e / N), j = (int)(e % N);
         if (j > i) continue;
         const double v = A[e];
-        D[e] = i == j ? v - lp_shift_of(L, y, t, v, min_eig) : v;
+        D[e] = i == j ? v - lp_shift_of(L, y, t, v, min_eig, local) : v;
     }
 }
 
@@ -1419,6 +1425,7 @@ struct apmf_mn_batch {
     long st_iters, st_trials, st_grads, st_slow[4], st_slow_grad;
     double st_slow_s, st_lane_s;
     long st_lane_passes, st_lane_hyps;
+    long st_proj_low, st_proj_full;      // eigen-projections finished through the lowest eigenpairs / the full decomposition
 };
 
 namespace {
@@ -1643,7 +1650,7 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
             if (round > 0) {
                 // has the deflated matrix anything left below min_eig?  its certificate, alone
                 const LpList S = list_of(todo);
-                hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, S.n), dim3(256), 0, st, R, L, S, 0, 1, min_eig);
+                hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, S.n), dim3(256), 0, st, R, L, S, 0, 1, min_eig, 0);
                 APMF_CHECK_LAUNCH();
                 ChJobs J;
                 memset(&J, 0, sizeof(J));
@@ -1662,7 +1669,7 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
             }
             // bracket: the ladder of shifts, one batched factorisation
             LpList S = list_of(todo);
-            hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, S.n * (LP_NS - 1)), dim3(256), 0, st, R, L, S, 1, LP_NS - 1, min_eig);
+            hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, S.n * (LP_NS - 1)), dim3(256), 0, st, R, L, S, 1, LP_NS - 1, min_eig, 0);
             APMF_CHECK_LAUNCH();
             {
                 ChJobs J;
@@ -1697,12 +1704,15 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
             APMF_CHECK_LAUNCH();
             // inverse iteration, the Rayleigh pair and its residual looked at every few steps
             std::vector<int> run = todo;
-            std::vector<double> prev(nc, 1e300);
+            std::vector<double> prev(nc, 0.);
             std::vector<char> conv(nc, 0);
+            std::vector<int> nladder(nc, 0);
+            for (int y : run) memcpy(&prev[y], norm_h + 2 * y, sizeof(double));      // |x| = 1: the first residual is below |A|
             for (int chk = 0; chk < 48 && !run.empty(); chk++) {
                 LpList T = list_of(run);
                 for (int q = 0; q < T.n; q++) T.a[q] = rung[T.y[q]];
-                for (int it = 0; it < (chk == 0 ? 12 : 6); it++) {
+                const int its = chk == 0 ? 12 : 6;
+                for (int it = 0; it < its; it++) {
                     hipLaunchKernelGGL(lp_fwd, dim3(g_rows.x, T.n), dim3(256), xs_bytes, st, L, T);
                     hipLaunchKernelGGL(lp_bwd, dim3(R.nbk * LP_RS, T.n), dim3(256), 0, st, L, T);
                 }
@@ -1710,19 +1720,62 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
                 hipLaunchKernelGGL(lp_final, dim3(T.n), dim3(256), 0, st, L, T);
                 APMF_CHECK_LAUNCH();
                 APMF_TRY(sync_read(out_h, L.out, 2 * (size_t)cap * sizeof(double)));
-                std::vector<int> more;
+                std::vector<int> more, closer;
                 for (int y : run) {
                     const double res = out_h[2 * y + 1];
                     double ninf;
                     memcpy(&ninf, norm_h + 2 * y, sizeof(double));       // |A|_inf of the undeflated matrix
                     if (debug) fprintf(stderr, "[low] h %d round %d check %d: lambda %.17g res %.3e\n", hyps[c0 + y], round, chk,
                                        out_h[2 * y], res);
-                    const bool good = res <= 1e-15 * ninf || (res <= 1e-12 * ninf && res > .5 * prev[y]);
+                    if (!(res == res)) { failed[y] = 1; continue; }
+                    const double target = 1e-15 * ninf;
+                    const bool good = res <= target || (res <= 1e-12 * ninf && res > .5 * prev[y]);
+                    if (good) {
+                        conv[y] = 1;
+                    } else {
+                        more.push_back(y);
+                        // steps still needed at the rate just seen; a shift closer to the eigenvalue (a factorisation:
+                        // some 40 steps' worth) pays when the next eigenvalue is not much further from the shift
+                        const double gain = log(prev[y] / res) / its;
+                        const double need = gain > 0 ? log(res / target) / gain : 1e9;
+                        if (need > 40. && nladder[y] < 4) closer.push_back(y);
+                    }
                     prev[y] = res;
-                    if (good && res == res) conv[y] = 1;
-                    else more.push_back(y);
                 }
                 run.swap(more);
+                if (!closer.empty()) {
+                    // ladder of shifts below the Rayleigh pair, one batched factorisation, the closest rung that factors
+                    LpList C = list_of(closer);
+                    hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, C.n * (LP_NS - 2)), dim3(256), 0, st, R, L, C, 1, LP_NS - 2, min_eig, 1);
+                    APMF_CHECK_LAUNCH();
+                    ChJobs J;
+                    memset(&J, 0, sizeof(J));
+                    J.list = L.jobs;
+                    APMF_TRY(chol_lower_jobs_on(st, J, C.n * (LP_NS - 2), N));
+                    APMF_TRY(sync_read(info_h, L.info, (size_t)nj * sizeof(int)));
+                    std::vector<int> ok;
+                    for (int y : closer) {
+                        nladder[y]++;
+                        int t = 1;
+                        while (t < LP_NS - 1 && info_h[y * LP_NS + t] != 0) t++;
+                        if (t >= LP_NS - 1) {            // (the slot of the factor in use has been overwritten)
+                            failed[y] = 1;
+                            run.erase(std::remove(run.begin(), run.end(), y), run.end());
+                            continue;
+                        }
+                        sel_h[ok.size()] = y * LP_NS + t;
+                        rung[y] = t;
+                        ok.push_back(y);
+                    }
+                    if (!ok.empty()) {
+                        APMF_CHECK_HIP(hipMemcpyAsync(e.lp_sel, sel_h, ok.size() * sizeof(int), hipMemcpyHostToDevice, st));
+                        for (int k = 0; k + 1 < R.nbk; k++)
+                            hipLaunchKernelGGL(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), (int)ok.size()), dim3(256), 0, st, R2,
+                                               e.lp_sel, k);
+                        APMF_CHECK_LAUNCH();
+                        for (int y : ok) prev[y] = 1e300;        // the rate of the old shift says nothing about the new one
+                    }
+                }
             }
             for (int y : run) failed[y] = 1;
             // pairs below min_eig are kept and deflated; a smallest eigenvalue that is not below ends the hypothesis
@@ -1769,8 +1822,8 @@ int slow_S_pre(apmf_mn_batch *b, EigSet &e, void *handle, const std::vector<int>
     w.set = &e;
     w.min_eig = min_eig;
     w.dsel = b->sel_dev + (size_t)e.slot0 * R.H;
-    static const bool full_only = getenv("APMF_BATCH_EIG") && !strcmp(getenv("APMF_BATCH_EIG"), "full");
-    w.low = !full_only;
+    const char *mode = getenv("APMF_BATCH_EIG");      // "full": always the full eigendecomposition (comparison runs)
+    w.low = !(mode && !strcmp(mode, "full"));
     e.n_full = 0;
     for (size_t q = 0; q < list.size(); q++) {
         if (masks[q] & SLOW_CERT_S) w.proj.push_back(list[q]);
@@ -1825,6 +1878,8 @@ int slow_S_post(apmf_mn_batch *b, EigSet &e, const SlowS &w, rocblas_status rs, 
         return APMF_EHIP;
     }
     e.n_full = (int)w.full.size();
+    b->st_proj_full += (long)w.full.size();
+    b->st_proj_low += (long)(w.proj.size() - w.full.size());
     if (!w.full.empty()) {
         const int *dsel = b->sel_dev + (size_t)e.slot0 * R.H;      // uploaded by slow_S_pre / slow_S_solve
         hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, (int)w.full.size()), dim3(256), 0, st, R, dsel,
@@ -2059,10 +2114,10 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     BA(R.part, (size_t)H * R.n * 3 * sizeof(double));
     BA(R.out4, (size_t)H * 4 * sizeof(double));
     BA(R.oc, (size_t)H * sizeof(OmegaConsts));
-    // eigen sets: the synchronous one and one per slow lane: a lane per ~4 hypotheses, at most 3 (measured at
-    // H = 10, 94 x 425: 1 lane 2.15 s, 2: 2.00 s, 3: 1.84 s, 4: 2.52 s - concurrent passes of ~3000 small
-    // kernels each slow one another and the main stream down)
-    b->nlanes = std::max(1, std::min(3, (H + 3) / 4));
+    // eigen sets: the synchronous one and one per slow lane.  One lane: a pass is a couple of ms of launches
+    // (measured at 94 x 425: H = 10 - 1 lane 1.11 s, 2: 1.30 s; H = 250 - 1 lane 6.6 s, 2: 7.0 s; concurrent
+    // launch-heavy host threads slow one another and the main stream down).  APMF_BATCH_LANES: up to MAX_LANES.
+    b->nlanes = 1;
     if (const char *e = getenv("APMF_BATCH_LANES")) b->nlanes = std::max(1, std::min(MAX_LANES, atoi(e)));
     for (int l = 0; l <= b->nlanes; l++) {
         EigSet &e = b->eig[l];
@@ -2132,6 +2187,17 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     b->fvalid_cand.assign(H, 0);
     b->oivalid.assign(H, 0);
     *out = b;
+    return APMF_OK;
+}
+
+int apmf_mn_batch_fit_stats(const apmf_mn_batch *b, int64_t *iterations, int64_t *trials, int64_t *proj_low,
+                            int64_t *proj_full)
+{
+    APMF_REQUIRE(b, "NULL batch");
+    if (iterations) *iterations = b->st_iters;
+    if (trials) *trials = b->st_trials;
+    if (proj_low) *proj_low = b->st_proj_low;
+    if (proj_full) *proj_full = b->st_proj_full;
     return APMF_OK;
 }
 
@@ -2233,6 +2299,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     b->st_slow[0] = b->st_slow[1] = b->st_slow[2] = b->st_slow[3] = 0;
     b->st_slow_s = b->st_lane_s = 0.;
     b->st_lane_passes = b->st_lane_hyps = 0;
+    b->st_proj_low = b->st_proj_full = 0;
     const auto t_fit = std::chrono::steady_clock::now();
     // a hypothesis whose KL is known AND whose factor / inverse are in place resumes directly
     std::vector<int> init;
@@ -2454,9 +2521,10 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             fprintf(stderr,
                     "[apmf batch] H=%d N=%d: %ld iterations, %ld trials, %ld gradients (%ld without factor); slow "
                     "exits: projection S %ld, factor S %ld, projection O %ld, inverse O %ld, %.3f s; lane: %ld passes, %ld "
-                    "hypotheses, busy %.3f s; total %.3f s\n",
+                    "hypotheses, busy %.3f s; projections: %ld by eigenpairs, %ld full; total %.3f s\n",
                     H, R.N, b->st_iters, b->st_trials, b->st_grads, b->st_slow_grad, b->st_slow[0], b->st_slow[1],
                     b->st_slow[2], b->st_slow[3], b->st_slow_s, b->st_lane_passes, b->st_lane_hyps, b->st_lane_s,
+                    b->st_proj_low, b->st_proj_full,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fit).count());
     for (int h = 0; h < H; h++) {
         const HypState &s = b->hs_host[h];

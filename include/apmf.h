@@ -338,6 +338,11 @@ int apmf_mn_batch_get_state(apmf_ctx *ctx, apmf_mn_batch *b, int h, double *d_me
 int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double sigma_u_sq,
                       double sigma_v_sq, double min_eig, double *h_lr, double *h_old_kl,
                       int64_t max_steps, double *h_kl_trace, int64_t *h_steps, int *h_converged);
+/* Counters of the last apmf_mn_batch_fit (each nullable): iterations of the search loop, trial points
+ * evaluated, and the project_psd calls (mn_active_pmf.py:42-67) that really clipped eigenvalues - how many
+ * were finished through the few eigenpairs below min_eig, how many through the full eigendecomposition. */
+int apmf_mn_batch_fit_stats(const apmf_mn_batch *b, int64_t *iterations, int64_t *trials, int64_t *proj_low,
+                            int64_t *proj_full);
 /* kl_divergence() of every current point (mn_kl_divergence, matrix_normal_exps_cy.pyx:159-213). */
 int apmf_mn_batch_kl(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double sigma_u_sq,
                      double sigma_v_sq, double *h_kl);

@@ -278,3 +278,59 @@ def test_batch_slow_lanes_same_states(ctx, lanes, monkeypatch):
         alone = run([h])[0]
         for x, y in zip(together[h], alone):
             assert np.array_equal(x, y)
+
+
+def test_batch_projection_by_eigenpairs_equals_full_decomposition(ctx, monkeypatch):
+    """project_psd (mn_active_pmf.py:42-67) rebuilds V max(L, min_eig) V' from a full eigh; the batched fit
+    finds only the eigenpairs below min_eig (shift bracketed by one batched Cholesky, inverse iteration,
+    deflation + certificate) and adds (min_eig - l) v v'.  Same trial matrices either way: a search that clips
+    at many of its trial points must go through the same accept / reject decisions and end in the same states
+    up to the rounding of the two routes, and the eigenpair route must have done the work (the ladder of
+    shifts does not reach: full decomposition, which APMF_BATCH_EIG=full forces everywhere)."""
+    n, m, d, H = 30, 40, 3, 5
+    N = n + m
+    rs, ratings, mean, S, O = _problem(n, m, d, 4242)
+    sig, su, sv = 1.0, 10.0, 10.0
+    w, v = np.linalg.eigh(S)
+    states = []
+    for h in range(H):
+        # one to three eigenvalues near the threshold, the rest of the spectrum well above it
+        k = 1 + h % 3
+        Sh = (v * np.concatenate([np.full(k, 1.5e-5 + 2e-6 * h), w[k:]])) @ v.T
+        states.append((Sh + Sh.T) / 2)
+    rt = ctx.ratings(ratings, n, m)
+
+    def run(mode):
+        if mode:
+            monkeypatch.setenv('APMF_BATCH_EIG', mode)
+        else:
+            monkeypatch.delenv('APMF_BATCH_EIG', raising=False)
+        b = ctx.mn_batch(rt, d, H, trace_cap=64)
+        b.set_state(ctx.array(np.stack([mean] * H)), ctx.array(np.stack(states)), ctx.array(np.stack([O] * H)),
+                    per_hypothesis=7)
+        lr, kl, nsteps, conv, trace = b.fit(sig, su, sv, 1e-5, 1e-3, max_steps=25)
+        st = b.fit_stats()
+        out = []
+        dm, ds, do = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+        for q in range(H):
+            b.get_state(q, dm, ds, do)
+            out.append((dm.to_host(), ds.to_host(), do.to_host(), float(kl[q]), int(nsteps[q]), float(lr[q])))
+        b.free()
+        return out, st
+
+    low, st_low = run(None)
+    full, st_full = run('full')
+    assert st_full['proj_low'] == 0 and st_full['proj_full'] > 0
+    assert st_low['proj_low'] + st_low['proj_full'] == st_full['proj_full']          # the same trial points clipped
+    # (the first trial points of this search are wildly indefinite - more eigenvalues below min_eig than the
+    # eigenpair route takes on, LP_KMAX = 6 - so both routes are exercised; at the shape of configs[3] every
+    # projection of a lookahead goes through the eigenpairs: profiles/r02_lookahead_*.json)
+    assert st_low['proj_low'] > 0 and st_low['proj_full'] > 0
+    assert st_low['trials'] == st_full['trials']
+    for a, b_ in zip(low, full):
+        assert a[4] == b_[4] and a[5] == b_[5]                  # accepted steps, learning rate
+        np.testing.assert_allclose(a[3], b_[3], rtol=1e-10)     # KL
+        for x, y in zip(a[:3], b_[:3]):
+            np.testing.assert_allclose(x, y, rtol=0, atol=1e-10 * np.abs(y).max())
+        assert np.linalg.eigvalsh(a[1]).min() >= 1e-5 * (1 - 1e-6)
+
