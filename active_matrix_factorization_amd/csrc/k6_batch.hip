@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void kb_rebuild(const Refs R, const int *__res
 constexpr int LP_NS = 14;      // jobs of a bracket: the certificate, 12 shifts, one below every eigenvalue
 constexpr int LP_KMAX = 6;     // eigenpairs found one after the other
 constexpr int LP_RS = 4;       // row splits of the transposed product
-constexpr int LP_CAP = 16;     // hypotheses per chunk (lists travel as kernel arguments)
+constexpr int LP_CAP = 48;     // hypotheses per chunk (lists travel as kernel arguments)
 
 struct LpRefs {
     double *Wk;       // [cap][LP_NS][N * N] shifted copies, factored in place
