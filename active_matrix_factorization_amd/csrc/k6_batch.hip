@@ -1823,7 +1823,7 @@ int slow_S_pre(apmf_mn_batch *b, EigSet &e, void *handle, const std::vector<int>
     w.min_eig = min_eig;
     w.dsel = b->sel_dev + (size_t)e.slot0 * R.H;
     const char *mode = getenv("APMF_BATCH_EIG");      // "full": always the full eigendecomposition (comparison runs)
-    w.low = !(mode && !strcmp(mode, "full"));
+    w.low = !(mode && !strcmp(mode, "full")) && (size_t)R.N * sizeof(double) <= 48 * 1024;    // (the iterate lives in LDS)
     e.n_full = 0;
     for (size_t q = 0; q < list.size(); q++) {
         if (masks[q] & SLOW_CERT_S) w.proj.push_back(list[q]);

@@ -179,11 +179,17 @@ def test_batched_equals_alone_bitwise(ctx, shape, max_steps, H):
     b.free()
 
 
-def test_batch_slow_path_projection(ctx):
+@pytest.mark.parametrize('route', ['eigenpairs', 'full'])
+def test_batch_slow_path_projection(ctx, route, monkeypatch):
     """A trial point whose covariance really needs its spectrum clipped (the certificate fails):
-    the hypothesis leaves the batch for the eigendecomposition route and comes back; the others
-    are unaffected.  Checked against a NumPy restatement of one search iteration."""
+    the hypothesis leaves the batch for the projection - through its eigenpairs below min_eig (the
+    default) or through the full eigendecomposition - and comes back; the others are unaffected.
+    Checked against a NumPy restatement of one search iteration (eigh + clip + rebuild)."""
     import mn_grad_numpy as ref
+    if route == 'full':
+        monkeypatch.setenv('APMF_BATCH_EIG', 'full')
+    else:
+        monkeypatch.delenv('APMF_BATCH_EIG', raising=False)
     n, m, d = 20, 25, 3
     N = n + m
     rs, ratings, mean, S, O = _problem(n, m, d, 4242)
@@ -238,6 +244,12 @@ def test_batch_slow_path_projection(ctx):
         b.get_state(h, None, dS, None)
         np.testing.assert_allclose(dS.to_host(), cand[1], rtol=1e-8, atol=1e-10)
     assert clipped, 'the test problem no longer exercises the projection branch'
+    st = b.fit_stats()
+    # (the first trial point of hypothesis 0 has more eigenvalues below min_eig than the eigenpair route takes
+    # on and goes through the full decomposition either way; the halved step's five go through the eigenpairs)
+    assert st['proj_low' if route == 'eigenpairs' else 'proj_full'] >= 1
+    if route == 'full':
+        assert st['proj_low'] == 0
     b.free()
 
 
