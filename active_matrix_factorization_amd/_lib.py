@@ -108,7 +108,8 @@ _DENSE_SIGS.update({
     'apmf_mn_batch_create': (_i, [_vp, _vp, _i, _i, _i64, C.POINTER(_vp)]),
     'apmf_mn_batch_destroy': (_i, [_vp, _vp]),
     'apmf_mn_batch_size': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
-    'apmf_mn_batch_fit_stats': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    'apmf_mn_batch_fit_stats': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
+                                     C.POINTER(_i64)]),
     'apmf_mn_batch_set_state': (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     'apmf_mn_batch_set_extra': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'apmf_mn_batch_get_state': (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -423,10 +424,10 @@ class MNBatch(object):
 
     def fit_stats(self):
         """Counters of the last fit(): search iterations, trial points, projections finished through the lowest
-        eigenpairs / through the full eigendecomposition."""
-        v = [C.c_int64(0) for _ in range(4)]
+        eigenpairs / through the full eigendecomposition, trial certificates settled by the eigenvalue bound."""
+        v = [C.c_int64(0) for _ in range(5)]
         _check(self._dense.apmf_mn_batch_fit_stats(self._h, *[C.byref(x) for x in v]))
-        return dict(zip(('iterations', 'trials', 'proj_low', 'proj_full'), (int(x.value) for x in v)))
+        return dict(zip(('iterations', 'trials', 'proj_low', 'proj_full', 'cert_by_bound'), (int(x.value) for x in v)))
 
     def kl(self, sig, sig_u, sig_v):
         out = np.empty(self.H)

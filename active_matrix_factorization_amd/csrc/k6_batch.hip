@@ -82,6 +82,7 @@ struct HypState {
     long long steps;              // accepted steps of this call
     long long max_steps;          // < 0: no limit
     int status, need_grad, slow, accepted;
+    int cert_skipped, inv_ok;     // trial certificates settled by the eigenvalue bound; the bound's input is current
 };
 
 struct OmegaConsts {
@@ -104,6 +105,9 @@ struct Refs {
     double *evals, *evE;  // [H][N] eigenvalues / rocSOLVER's E
     int *evinfo;          // [H]
     double *trace;        // [H][trace_cap]
+    double *invp;         // [H][nbk (nbk + 1) / 2] partial sums of |S^-1|_F^2 at the current point (kb_lauum)
+    double *stepp;        // [H][nt32 (nt32 + 1) / 2] partial sums of |lr g_S|_F^2 of the trial (kb_trial_S)
+    int *skipword;        // one int, 1: the info word of a factorisation job that is not to run
     int *ei, *ej;         // extra rating of the hypothesis (ei < 0: none)
     double *ev;
     int H, n, m, d, N, nbk, trace_cap;
@@ -195,13 +199,23 @@ __global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__res
     double *__restrict__ W = tabp(R, T_S_W, h);
     const int i0 = ti * 32, j0 = tj * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    double step2 = 0.;        // this block's share of |lr g|_F^2 >= |cur - cand|_F^2 (both tiles of the pair)
     for (int r = ty; r < 32; r += 8) {
         const int i = i0 + r, j = j0 + tx;
-        A[r][tx] = (i < N && j < N) ? __dsub_rn(cur[(size_t)i * N + j], __dmul_rn(lr, g[(size_t)i * N + j])) : 0.;
+        const double sa = (i < N && j < N) ? __dmul_rn(lr, g[(size_t)i * N + j]) : 0.;
+        A[r][tx] = (i < N && j < N) ? __dsub_rn(cur[(size_t)i * N + j], sa) : 0.;
         const int i2 = j0 + r, j2 = i0 + tx;
-        B[r][tx] = (i2 < N && j2 < N) ? __dsub_rn(cur[(size_t)i2 * N + j2], __dmul_rn(lr, g[(size_t)i2 * N + j2])) : 0.;
+        const double sb = (i2 < N && j2 < N) ? __dmul_rn(lr, g[(size_t)i2 * N + j2]) : 0.;
+        B[r][tx] = (i2 < N && j2 < N) ? __dsub_rn(cur[(size_t)i2 * N + j2], sb) : 0.;
+        step2 += sa * sa + (ti != tj ? sb * sb : 0.);
     }
-    __syncthreads();
+    {
+        __shared__ double red[4];
+        step2 = wave_sum(step2);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = step2;
+        __syncthreads();
+        if (threadIdx.x == 0) R.stepp[(size_t)h * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
     if (ti != tj) {
         for (int r = ty; r < 32; r += 8) {
             // upper tile element (i, j), i < j, and the element (j0 + r, i0 + tx) of the lower tile
@@ -234,11 +248,39 @@ __device__ __forceinline__ void make_jobs_one(const Refs &R, int y, int h, int m
 
 // mean and cov_latents parts of the trial point (cov_latents symmetrised like project_psd does);
 // jobs != nullptr: also the hypothesis' pair of factorisation jobs (certificate + factor)
+// The certificate of a trial point - no eigenvalue of cand below min_eig - without its factorisation, when
+// the step is short: l_min(cand) >= l_min(cur) - |cur - cand|_2 (Weyl) >= 1 / |cur^-1|_F - |lr g|_F, and the
+// gradient at the current point has just computed cur^-1 (kb_lauum leaves the partial sums of its squared
+// entries).  If that is >= min_eig the shifted factorisation is not run (its job gets an info word that
+// says "skip", the certificate's own stays 0 = passed); either way the trial's arithmetic is the same.
+__device__ __forceinline__ int cert_by_bound(const Refs &R, int h, int nstep, double min_eig)
+{
+    // one wave
+    const int lane = threadIdx.x & 63;
+    if (!R.hs[h].inv_ok) return 0;
+    const int ninv = R.nbk * (R.nbk + 1) / 2;
+    double a = 0., b = 0.;
+    for (int i = lane; i < ninv; i += 64) a += R.invp[(size_t)h * ninv + i];
+    for (int i = lane; i < nstep; i += 64) b += R.stepp[(size_t)h * nstep + i];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    return a > 0. && .99 / sqrt(a) - sqrt(b) >= min_eig * (1. + 1e-6);
+}
+
 __global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *__restrict__ sel,
-                                                      ChJob *__restrict__ jobs)
+                                                      ChJob *__restrict__ jobs, int nstep, double min_eig)
 {
     const int h = sel[blockIdx.y];
-    if (jobs && blockIdx.x == 0 && threadIdx.x == 0) make_jobs_one(R, (int)blockIdx.y, h, 2, jobs);
+    if (jobs && blockIdx.x == 0 && threadIdx.x < 64) {
+        const int skip = cert_by_bound(R, h, nstep, min_eig);
+        if (threadIdx.x == 0) {
+            make_jobs_one(R, (int)blockIdx.y, h, 2, jobs);
+            if (skip) {
+                jobs[2 * blockIdx.y].info = R.skipword;
+                R.hs[h].cert_skipped++;
+            }
+        }
+    }
     const double lr = R.hs[h].lr;
     const size_t nm = (size_t)R.N * R.d, dd = (size_t)R.d * R.d;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -762,6 +804,7 @@ __device__ __forceinline__ void decide_one(const Refs &R, int h, int mode, int f
         s.cur_ld_s = s.ld_s;
         s.cur_ld_o = s.ld_o;
         s.need_grad = 1;
+        s.inv_ok = 0;
         s.accepted = 1;
         if (s.status == ST_ACTIVE && s.max_steps >= 0 && s.steps >= s.max_steps) s.status = ST_PAUSED;
     } else {
@@ -915,12 +958,25 @@ __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restr
     }
     // the identity padding of a short last block must not leak into the sums: rows beyond N of a
     // padded Linv are unit vectors whose columns are beyond N too, and those outputs are dropped
+    double inv2 = 0.;        // this tile's share of |S^-1|_F^2 (cert_by_bound)
     TILE_FOR_EACH(u, v, r) {
         const int rr = ti * 64 + tile_row(u, r), cc = tj * 64 + tile_col(v);
         if (rr < N && cc < N && (ti != tj || cc <= rr)) {
             const double val = -half_mult * acc[u][v][r] * (rr == cc ? 1. : 2.);
             G[(size_t)rr * N + cc] = val;
             if (rr != cc) G[(size_t)cc * N + rr] = val;
+            inv2 += acc[u][v][r] * acc[u][v][r] * (rr == cc ? 1. : 2.);
+        }
+    }
+    {
+        __shared__ double red[4];
+        inv2 = wave_sum(inv2);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = inv2;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            R.invp[(size_t)h * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+            if (blockIdx.x == 0) R.hs[h].inv_ok = 1;
         }
     }
 }
@@ -1426,6 +1482,7 @@ struct apmf_mn_batch {
     double st_slow_s, st_lane_s;
     long st_lane_passes, st_lane_hyps;
     long st_proj_low, st_proj_full;      // eigen-projections finished through the lowest eigenpairs / the full decomposition
+    long st_cert_skipped;                // trial certificates settled by the eigenvalue bound instead of a factorisation
 };
 
 namespace {
@@ -2114,6 +2171,9 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     BA(R.part, (size_t)H * R.n * 3 * sizeof(double));
     BA(R.out4, (size_t)H * 4 * sizeof(double));
     BA(R.oc, (size_t)H * sizeof(OmegaConsts));
+    BA(R.invp, (size_t)H * (R.nbk * (R.nbk + 1) / 2) * sizeof(double));
+    BA(R.stepp, (size_t)H * (((N + 31) / 32) * ((N + 31) / 32 + 1) / 2) * sizeof(double));
+    BA(R.skipword, sizeof(int));
     // eigen sets: the synchronous one and one per slow lane.  One lane: a pass is a couple of ms of launches
     // (measured at 94 x 425: H = 10 - 1 lane 1.11 s, 2: 1.30 s; H = 250 - 1 lane 6.6 s, 2: 7.0 s; concurrent
     // launch-heavy host threads slow one another and the main stream down).  APMF_BATCH_LANES: up to MAX_LANES.
@@ -2169,6 +2229,8 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
         tab[(size_t)T_OI_CAND * H + h] = O_store + ((size_t)4 * H + h) * dd;
     }
     rc = apmf_h2d(ctx, R.tab, tab.data(), tab.size() * sizeof(double *));
+    const int one = 1;
+    if (rc == APMF_OK) rc = apmf_h2d(ctx, R.skipword, &one, sizeof(int));
     if (rc == APMF_OK) rc = apmf_memset(ctx, R.ei, 0xFF, (size_t)H * sizeof(int));     // -1: no extra rating
     if (rc == APMF_OK) rc = apmf_memset(ctx, R.ej, 0xFF, (size_t)H * sizeof(int));
     if (rc == APMF_OK) rc = apmf_memset(ctx, R.ev, 0, (size_t)H * sizeof(double));
@@ -2191,9 +2253,10 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
 }
 
 int apmf_mn_batch_fit_stats(const apmf_mn_batch *b, int64_t *iterations, int64_t *trials, int64_t *proj_low,
-                            int64_t *proj_full)
+                            int64_t *proj_full, int64_t *cert_by_bound)
 {
     APMF_REQUIRE(b, "NULL batch");
+    if (cert_by_bound) *cert_by_bound = b->st_cert_skipped;
     if (iterations) *iterations = b->st_iters;
     if (trials) *trials = b->st_trials;
     if (proj_low) *proj_low = b->st_proj_low;
@@ -2294,12 +2357,15 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         s.need_grad = 1;
         s.slow = 0;
         s.accepted = 0;
+        s.cert_skipped = 0;
+        s.inv_ok = 0;
     }
     b->st_iters = b->st_trials = b->st_grads = b->st_slow_grad = 0;
     b->st_slow[0] = b->st_slow[1] = b->st_slow[2] = b->st_slow[3] = 0;
     b->st_slow_s = b->st_lane_s = 0.;
     b->st_lane_passes = b->st_lane_hyps = 0;
     b->st_proj_low = b->st_proj_full = 0;
+    b->st_cert_skipped = 0;
     const auto t_fit = std::chrono::steady_clock::now();
     // a hypothesis whose KL is known AND whose factor / inverse are in place resumes directly
     std::vector<int> init;
@@ -2332,6 +2398,9 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     // independent, so the order in which they advance changes nothing.  APMF_BATCH_ASYNC=0: the
     // parked hypotheses are dealt with on the main stream instead (debugging).
     const bool use_lane = !(getenv("APMF_BATCH_ASYNC") && getenv("APMF_BATCH_ASYNC")[0] == '0');
+    // APMF_BATCH_CERT=factor: every trial's certificate by its factorisation, never by the eigenvalue bound
+    // (comparison runs: the results are the same bits either way)
+    const double bound_eig = (getenv("APMF_BATCH_CERT") && !strcmp(getenv("APMF_BATCH_CERT"), "factor")) ? INFINITY : min_eig;
     std::vector<int> active, grad, parked, decided, osync;
     std::vector<char> is_parked(H, 0);
     // One pass of a lane: busy from the moment it takes the parked hypotheses; `solving` while its worker
@@ -2431,7 +2500,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             const int nt32 = (R.N + 31) / 32;
             hipLaunchKernelGGL(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig);
             hipLaunchKernelGGL(kb_trial_small, dim3((unsigned)(((size_t)R.N * R.d + (size_t)R.d * R.d + 255) / 256), na),
-                               dim3(256), 0, st, R, dsel, R.jobs);
+                               dim3(256), 0, st, R, dsel, R.jobs, nt32 * (nt32 + 1) / 2, bound_eig);
             APMF_CHECK_LAUNCH();
             {
                 ChJobs J;
@@ -2516,15 +2585,17 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         }
         finish_decided(decided);
     }
+    for (int h = 0; h < H; h++) b->st_cert_skipped += b->hs_host[h].cert_skipped;
     if (const char *e = getenv("APMF_BATCH_STATS"))
         if (e[0] == '1')
             fprintf(stderr,
                     "[apmf batch] H=%d N=%d: %ld iterations, %ld trials, %ld gradients (%ld without factor); slow "
                     "exits: projection S %ld, factor S %ld, projection O %ld, inverse O %ld, %.3f s; lane: %ld passes, %ld "
-                    "hypotheses, busy %.3f s; projections: %ld by eigenpairs, %ld full; total %.3f s\n",
+                    "hypotheses, busy %.3f s; projections: %ld by eigenpairs, %ld full; %ld certificates by the eigenvalue "
+                    "bound; total %.3f s\n",
                     H, R.N, b->st_iters, b->st_trials, b->st_grads, b->st_slow_grad, b->st_slow[0], b->st_slow[1],
                     b->st_slow[2], b->st_slow[3], b->st_slow_s, b->st_lane_passes, b->st_lane_hyps, b->st_lane_s,
-                    b->st_proj_low, b->st_proj_full,
+                    b->st_proj_low, b->st_proj_full, b->st_cert_skipped,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fit).count());
     for (int h = 0; h < H; h++) {
         const HypState &s = b->hs_host[h];

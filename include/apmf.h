@@ -339,10 +339,12 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                       double sigma_v_sq, double min_eig, double *h_lr, double *h_old_kl,
                       int64_t max_steps, double *h_kl_trace, int64_t *h_steps, int *h_converged);
 /* Counters of the last apmf_mn_batch_fit (each nullable): iterations of the search loop, trial points
- * evaluated, and the project_psd calls (mn_active_pmf.py:42-67) that really clipped eigenvalues - how many
- * were finished through the few eigenpairs below min_eig, how many through the full eigendecomposition. */
+ * evaluated, the project_psd calls (mn_active_pmf.py:42-67) that really clipped eigenvalues - how many
+ * were finished through the few eigenpairs below min_eig, how many through the full eigendecomposition -
+ * and the trial points whose "nothing to clip" was certified by an eigenvalue bound (Weyl, from the inverse
+ * the gradient computes) without factoring the shifted matrix. */
 int apmf_mn_batch_fit_stats(const apmf_mn_batch *b, int64_t *iterations, int64_t *trials, int64_t *proj_low,
-                            int64_t *proj_full);
+                            int64_t *proj_full, int64_t *cert_by_bound);
 /* kl_divergence() of every current point (mn_kl_divergence, matrix_normal_exps_cy.pyx:159-213). */
 int apmf_mn_batch_kl(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double sigma_u_sq,
                      double sigma_v_sq, double *h_kl);

@@ -346,3 +346,43 @@ def test_batch_projection_by_eigenpairs_equals_full_decomposition(ctx, monkeypat
             np.testing.assert_allclose(x, y, rtol=0, atol=1e-10 * np.abs(y).max())
         assert np.linalg.eigvalsh(a[1]).min() >= 1e-5 * (1 - 1e-6)
 
+
+def test_batch_certificate_by_eigenvalue_bound_same_bits(ctx, monkeypatch):
+    """A trial point needs project_psd's eigh only to learn that nothing is clipped; the batched fit certifies
+    that by factoring cand - (min_eig + delta) I - or, when the step is short, by
+    l_min(cand) >= 1 / |cur^-1|_F - |lr g|_F >= min_eig from the inverse the gradient has just computed, without
+    that factorisation.  Either way the trial's arithmetic is the same: states, KL traces, steps and learning
+    rates bit for bit (APMF_BATCH_CERT=factor switches the bound off)."""
+    n, m, d, H = 40, 55, 3, 4
+    N = n + m
+    rs, ratings, mean, S, O = _problem(n, m, d, 321, per_row=2)
+    ex = _unrated(rs, ratings, n, m, H)
+    rt = ctx.ratings(ratings, n, m)
+
+    def run(mode):
+        if mode:
+            monkeypatch.setenv('APMF_BATCH_CERT', mode)
+        else:
+            monkeypatch.delenv('APMF_BATCH_CERT', raising=False)
+        b = ctx.mn_batch(rt, d, H, trace_cap=64)
+        b.set_state(ctx.array(.1 * mean), ctx.array(np.eye(N)), ctx.array(np.eye(d)))
+        b.set_extra([e[0] for e in ex], [e[1] for e in ex], [1., 5., 3., 2.])
+        lr, kl, nsteps, conv, trace = b.fit(1., 10., 10., 1e-5, 1e-4, max_steps=60)
+        st = b.fit_stats()
+        out = []
+        dm, ds, do = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+        for q in range(H):
+            b.get_state(q, dm, ds, do)
+            out.append((dm.to_host(), ds.to_host(), do.to_host(), trace[q, :int(nsteps[q])].copy(), int(nsteps[q]),
+                        float(lr[q])))
+        b.free()
+        return out, st
+
+    bound, st_b = run(None)
+    fact, st_f = run('factor')
+    assert st_f['cert_by_bound'] == 0
+    assert 0 < st_b['cert_by_bound'] <= st_b['trials'] and st_b['trials'] == st_f['trials']
+    for a, b_ in zip(bound, fact):
+        for x, y in zip(a, b_):
+            assert np.array_equal(x, y)
+
