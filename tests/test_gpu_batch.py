@@ -179,8 +179,9 @@ def test_batched_equals_alone_bitwise(ctx, shape, max_steps, H):
     b.free()
 
 
+@pytest.mark.parametrize('shape', [(20, 25, 3), (70, 95, 3)])
 @pytest.mark.parametrize('route', ['eigenpairs', 'full'])
-def test_batch_slow_path_projection(ctx, route, monkeypatch):
+def test_batch_slow_path_projection(ctx, route, shape, monkeypatch):
     """A trial point whose covariance really needs its spectrum clipped (the certificate fails):
     the hypothesis leaves the batch for the projection - through its eigenpairs below min_eig (the
     default) or through the full eigendecomposition - and comes back; the others are unaffected.
@@ -190,7 +191,7 @@ def test_batch_slow_path_projection(ctx, route, monkeypatch):
         monkeypatch.setenv('APMF_BATCH_EIG', 'full')
     else:
         monkeypatch.delenv('APMF_BATCH_EIG', raising=False)
-    n, m, d = 20, 25, 3
+    n, m, d = shape              # N = 45: one 64-column panel; N = 165: three, the last one short
     N = n + m
     rs, ratings, mean, S, O = _problem(n, m, d, 4242)
     sig, su, sv = 1.0, 10.0, 10.0
