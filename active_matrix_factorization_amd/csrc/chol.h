@@ -15,6 +15,7 @@
 // the machine cost what one does.  A job's arithmetic never depends on the other jobs of the
 // launch: the factor of a matrix is bit-identical whether it is factored alone or in a batch.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 
 constexpr int CH_NB = 64;
@@ -414,6 +415,70 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
     }
 }
 
+// The same updates, one block COLUMN at a time (many matrices per launch, where memory traffic is what costs):
+// tile (i, j) of block column j takes the updates of ALL earlier panels k < j in one go - old -= P_ik P_jk',
+// panel after panel in the order and with the roundings of k_chol_update, so the factor is the same bits -
+// but stays in registers in between instead of going through memory once per panel: half the traffic.
+__global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
+{
+    const ChJob job = ch_job(J, blockIdx.y);
+    double *__restrict__ A = job.A;
+    constexpr int KS = 32, KP = KS + 2;
+    __shared__ double stat_lds[2 * 64 * KP];
+    double (*Pi)[KP] = (double (*)[KP])stat_lds;
+    double (*Pj)[KP] = Pi + 64;
+    const int j0 = jb * CH_NB, i0 = j0 + (int)blockIdx.x * 64;
+    f64x4 old[2][2];
+    TILE_FOR_EACH(u, v, r) {
+        const int i = min(i0 + tile_row(u, r), N - 1), j = min(j0 + tile_col(v), N - 1);
+        old[u][v][r] = A[(size_t)i * N + j];
+    }
+    TileRegs<64, KS> pi, pj;
+    pi.load(A, N, i0, 0, N, N);
+    pj.load(A, N, j0, 0, N, N);
+    if (*job.info != 0) return;
+    f64x4 acc[2][2] = {};
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int r0 = 32 * (w >> 1) + li, c0 = 32 * (w & 1) + li;
+    for (int kc = 0; kc < j0; kc += KS) {              // half-panels: columns [kc, kc + KS) of the factor so far
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < pi.PER; q++) {
+            const int r = pi.row(q), c = pi.col(q);
+            Pi[r][c] = i0 + r < N ? pi.v[q] : 0.;
+            Pj[r][c] = j0 + r < N ? pj.v[q] : 0.;
+        }
+        if (kc + KS < j0) {
+            pi.load(A, N, i0, kc + KS, N, N);
+            pj.load(A, N, j0, kc + KS, N, N);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += 4) {
+            const int kk = k0 + g;
+            double a[2], b[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) { a[u] = Pi[r0 + 16 * u][kk]; b[u] = Pj[c0 + 16 * u][kk]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int v = 0; v < 2; v++)
+                    acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+        }
+        if ((kc + KS) % CH_NB == 0) {                 // a panel is complete: its update, rounded like k_chol_update's
+            TILE_FOR_EACH(u, v, r) {
+                old[u][v][r] = old[u][v][r] - acc[u][v][r];
+                acc[u][v][r] = 0.;
+            }
+        }
+    }
+    TILE_FOR_EACH(u, v, r) {
+        const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
+        if (i < N && j <= i) A[(size_t)i * N + j] = old[u][v][r];
+    }
+}
+
 } // namespace
 
 // Enqueue the factorisation of `njobs` matrices (all N x N).  The jobs' info words must have
@@ -428,6 +493,20 @@ static inline int chol_lower_jobs_on(hipStream_t stream, const ChJobs &J, int nj
     if (next && next_lds > 64 * 1024)      // (67.6 KB; set per call: the attribute is per device)
         (void)hipFuncSetAttribute((const void *)k_chol_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)next_lds);
+    static const bool by_column = !(getenv("APMF_CHOL_COL") && getenv("APMF_CHOL_COL")[0] == '0');   // 0: comparison runs
+    if (!next && by_column) {
+        // many matrices: block column by block column, each tile updated once with all earlier panels
+        const int nbk = (N + CH_NB - 1) / CH_NB;
+        for (int jb = 0; jb < nbk; jb++) {
+            const int k = jb * CH_NB;
+            if (jb > 0) hipLaunchKernelGGL(k_chol_col, dim3(nbk - jb, njobs), dim3(256), 0, stream, J, N, jb);
+            hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, stream, J, N, k);
+            const int rest = N - k - CH_NB;
+            if (rest > 0) hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, stream, J, N, k);
+        }
+        APMF_CHECK_LAUNCH();
+        return APMF_OK;
+    }
     for (int k = 0; k < N; k += CH_NB) {
         const int nb = N - k < CH_NB ? N - k : CH_NB;
         if (k == 0 || !next) hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, stream, J, N, k);

@@ -133,13 +133,15 @@ def _fit_alone(ctx, ratings, n, m, d, mean, S, O, sig, su, sv, max_steps, cap):
 
 
 @pytest.mark.parametrize('shape,max_steps,H', [((24, 17, 5), 25, 5), ((94, 425, 5), 6, 5), ((60, 75, 3), -1, 5),
-                                                ((70, 90, 4), 12, 20)])
+                                                ((70, 90, 4), 12, 20), ((94, 425, 5), 4, 20)])
 def test_batched_equals_alone_bitwise(ctx, shape, max_steps, H):
     """H hypotheses fitted in one batch == each fitted alone on a container rebuilt with its extra
     rating appended (what deepcopy + add_rating + fit_normal does): states, KL traces, step counts
     and learning rates bit-for-bit.  (94, 425, 5) is BASELINE.json configs[3]'s shape.  H = 20 puts 40
     matrices in a factorisation launch: the chain then factors diagonal blocks in launches of their own
-    (csrc/chol.h), while a fit run alone factors them inside the update launch - same bits."""
+    (csrc/chol.h) and updates the factor block column by block column (each tile takes all earlier panels in one
+    go, from registers), while a fit run alone updates panel by panel and factors the diagonal blocks inside the
+    update launch - same bits (at N = 519 a tile takes up to 8 panels)."""
     n, m, d = shape
     N = n + m
     rs, ratings, mean, S, O = _problem(n, m, d, 77 + n, per_row=2)
