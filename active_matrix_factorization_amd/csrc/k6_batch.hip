@@ -200,14 +200,29 @@ __global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__res
     const int i0 = ti * 32, j0 = tj * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     double step2 = 0.;        // this block's share of |lr g|_F^2 >= |cur - cand|_F^2 (both tiles of the pair)
-    for (int r = ty; r < 32; r += 8) {
-        const int i = i0 + r, j = j0 + tx;
-        const double sa = (i < N && j < N) ? __dmul_rn(lr, g[(size_t)i * N + j]) : 0.;
-        A[r][tx] = (i < N && j < N) ? __dsub_rn(cur[(size_t)i * N + j], sa) : 0.;
-        const int i2 = j0 + r, j2 = i0 + tx;
-        const double sb = (i2 < N && j2 < N) ? __dmul_rn(lr, g[(size_t)i2 * N + j2]) : 0.;
-        B[r][tx] = (i2 < N && j2 < N) ? __dsub_rn(cur[(size_t)i2 * N + j2], sb) : 0.;
-        step2 += sa * sa + (ti != tj ? sb * sb : 0.);
+    {
+        // all 16 loads of the thread are requested (at clamped addresses) before any is used
+        double gv[4][2], cv[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = ty + 8 * q;
+            const size_t ea = (size_t)min(i0 + r, N - 1) * N + min(j0 + tx, N - 1);
+            const size_t eb = (size_t)min(j0 + r, N - 1) * N + min(i0 + tx, N - 1);
+            gv[q][0] = g[ea];
+            cv[q][0] = cur[ea];
+            gv[q][1] = g[eb];
+            cv[q][1] = cur[eb];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = ty + 8 * q;
+            const bool oka = i0 + r < N && j0 + tx < N, okb = j0 + r < N && i0 + tx < N;
+            const double sa = oka ? __dmul_rn(lr, gv[q][0]) : 0.;
+            const double sb = okb ? __dmul_rn(lr, gv[q][1]) : 0.;
+            A[r][tx] = oka ? __dsub_rn(cv[q][0], sa) : 0.;
+            B[r][tx] = okb ? __dsub_rn(cv[q][1], sb) : 0.;
+            step2 += sa * sa + (ti != tj ? sb * sb : 0.);
+        }
     }
     {
         __shared__ double red[4];
