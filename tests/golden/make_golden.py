@@ -676,23 +676,29 @@ def round2i(np, mn_active_pmf, save, seed, _print):
 
 
 def round2j(np, mn_active_pmf, save, seed, _print):
-    """R. One selection step of the matrix-normal loop under a LOOKAHEAD criterion (mn_active_pmf.py:660-755):
-    compare(['total-variance'], steps=2) on config 1 - every one of the 90 unrated entries x 5 rating values
-    is a deepcopy + add_rating + fit_normal to convergence + full-grid sum in the reference - under seed 47:
-    the pick, the evaluation grid and the RMSEs."""
+    """R. One selection step of the matrix-normal loop under the LOOKAHEAD criteria (mn_active_pmf.py:660-755):
+    compare([...], steps=2) on config 1 - every one of the 90 unrated entries x 5 rating values is a deepcopy +
+    add_rating + fit_normal to convergence (+ a full-grid sum / an entropy / a count) in the reference - under
+    seed 47: per criterion the pick, the evaluation grid and the RMSEs."""
     g = np.load(os.path.join(HERE, 'trace_c1_mn.npz'))
     real, ratings = g['real'], g['ratings']
+    keys = ['total-variance', 'uv-entropy', '1step-ge-3.5']
     t0 = time.perf_counter()
     seed(47)
-    res = mn_active_pmf.compare(['total-variance'], real, ratings.copy(), rating_vals=(1, 2, 3, 4, 5), latent_d=2,
+    res = mn_active_pmf.compare(keys, real, ratings.copy(), rating_vals=(1, 2, 3, 4, 5), latent_d=2,
                                 do_threading=False, steps=2, discrete_exp=True)
-    steps = res['total-variance']
-    _print('lookahead selection step: pick %s, %.0f s' % (steps[1][2], time.perf_counter() - t0))
     init = res['_initial_apmf']
-    save('trace_c1_mn_lookahead', real=real, ratings=ratings, seed=47, n_rated=np.array([s[0] for s in steps]),
-         rmse=np.array([s[1] for s in steps], dtype=np.float64), pick=np.array(steps[1][2]),
-         vals=np.array(steps[1][3], dtype=np.float64), init_users=init.users, init_items=init.items,
-         init_mean=init.mean, init_cov_useritems=init.cov_useritems, init_cov_latents=init.cov_latents)
+    out = dict(real=real, ratings=ratings, seed=47, keys=np.array(keys), init_users=init.users, init_items=init.items,
+               init_mean=init.mean, init_cov_useritems=init.cov_useritems, init_cov_latents=init.cov_latents)
+    for key in keys:
+        steps = res[key]
+        _print('lookahead selection step (%s): pick %s' % (key, steps[1][2]))
+        out[key + '_n_rated'] = np.array([s[0] for s in steps])
+        out[key + '_rmse'] = np.array([s[1] for s in steps], dtype=np.float64)
+        out[key + '_pick'] = np.array(steps[1][2])
+        out[key + '_vals'] = np.array(steps[1][3], dtype=np.float64)
+    _print('  %.0f s' % (time.perf_counter() - t0))
+    save('trace_c1_mn_lookahead', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

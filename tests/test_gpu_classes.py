@@ -281,25 +281,27 @@ def test_config1_selection_trace(pkg):
 
 
 def test_config1_lookahead_selection_step(pkg):
-    """One selection step of the matrix-normal loop under the LOOKAHEAD criterion 'total-variance'
-    (mn_active_pmf.py:660-755 under compare(): 90 unrated entries x 5 rating values, each a hypothesis fitted
-    to convergence in the reference) on config 1 under seed 47: the pick the REAL reference made (exact), its
-    evaluation grid over all 90 candidates (this package fits all 450 hypotheses in one device batch) and the
-    RMSE after the re-fit."""
+    """One selection step of the matrix-normal loop under the LOOKAHEAD criteria 'total-variance', 'uv-entropy'
+    and '1step-ge-3.5' (mn_active_pmf.py:660-755 under compare(): 90 unrated entries x 5 rating values, each a
+    hypothesis fitted to convergence in the reference) on config 1 under seed 47: per criterion the pick the REAL
+    reference made (exact), its evaluation grid over all 90 candidates (this package fits all 450 hypotheses in
+    one device batch) and the RMSE after the re-fit."""
     g = load_golden('trace_c1_mn_lookahead')
+    keys = [str(k) for k in g['keys']]
     seed(int(g['seed']))
-    res = pkg.mn.compare(['total-variance'], g['real'], g['ratings'].copy(), rating_vals=(1, 2, 3, 4, 5),
+    res = pkg.mn.compare(keys, g['real'], g['ratings'].copy(), rating_vals=(1, 2, 3, 4, 5),
                          latent_d=2, do_threading=False, steps=2, discrete_exp=True)
-    steps = res['total-variance']
-    assert [s[0] for s in steps] == list(g['n_rated'])
-    ref, got = g['vals'], np.asarray(steps[1][3], float)
-    assert np.array_equal(np.isnan(got), np.isnan(ref))
-    ok = ~np.isnan(ref)
-    # every hypothesis is a gradient ascent stopped on a 1e-4 change of the KL bound: converged values agree to
-    # the stopping tolerance's effect on the total variance, not to rounding
-    np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-3)
-    assert tuple(steps[1][2]) == tuple(g['pick'])                      # selected entry: exact
-    np.testing.assert_allclose([s[1] for s in steps], g['rmse'], rtol=1e-4)
+    for key in keys:
+        steps = res[key]
+        assert [s[0] for s in steps] == list(g[key + '_n_rated'])
+        ref, got = g[key + '_vals'], np.asarray(steps[1][3], float)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        # every hypothesis is a gradient descent stopped on a small change of the KL bound: converged values agree to
+        # the stopping tolerance's effect on the criterion, not to rounding
+        np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-3, atol=2e-3 * np.abs(ref[ok]).max())
+        assert tuple(steps[1][2]) == tuple(g[key + '_pick']), key            # selected entry: exact
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-4)
 
 
 def test_config1_bayes_selection_trace(pkg):
