@@ -1087,6 +1087,7 @@ struct LpRefs {
     double *lam;      // [cap][LP_KMAX]
     double *out;      // [cap][2]            Rayleigh quotient, residual norm
     unsigned long long *norm;   // [cap][2]  bit patterns of |A|_inf and max |a_ii| (non-negative doubles order like integers)
+    double *slb;      // [cap]               a lower bound of the trial matrix' smallest eigenvalue (-inf: none)
     ChJob *jobs;      // [cap * LP_NS]
     int *info;        // [cap * LP_NS]
     int N, nbk;
@@ -1109,11 +1110,23 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh)
 }
 
 // |A|_inf and max |a_ii| of the working copy (W) of each listed hypothesis: a wave per row
-__global__ __launch_bounds__(256) void lp_norms(const Refs R, const LpRefs L, const LpList S)
+__global__ __launch_bounds__(256) void lp_norms(const Refs R, const LpRefs L, const LpList S, int use_bound)
 {
     const int q = blockIdx.y, y = S.y[q], N = L.N;
     const double *__restrict__ A = tabp(R, T_S_W, S.h[q]);
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // l_min(trial) >= 1 / |cur^-1|_F - |lr g|_F (cert_by_bound's quantities; the trial is this hypothesis' last):
+        // rungs of the ladder below that are known to factor, and only the first of them is needed
+        const int h = S.h[q];
+        const int ninv = R.nbk * (R.nbk + 1) / 2, nt32 = (N + 31) / 32, nstep = nt32 * (nt32 + 1) / 2;
+        double a = 0., b = 0.;
+        for (int i = lane; i < ninv; i += 64) a += R.invp[(size_t)h * ninv + i];
+        for (int i = lane; i < nstep; i += 64) b += R.stepp[(size_t)h * nstep + i];
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (lane == 0) L.slb[y] = (use_bound && R.hs[h].inv_ok && a > 0.) ? .99 / sqrt(a) - 1.01 * sqrt(b) : -INFINITY;
+    }
     if (row >= N) return;
     double s = 0;
     for (int c0 = 0; c0 < N; c0 += 64 * 8) {
@@ -1153,15 +1166,19 @@ __global__ __launch_bounds__(256) void lp_shift(const Refs R, const LpRefs L, co
     const int job = y * LP_NS + t;
     const double *__restrict__ A = tabp(R, T_S_W, S.h[q]);
     double *__restrict__ D = L.Wk + (size_t)job * N * N;
+    // a rung whose predecessor already lies below the eigenvalue bound adds nothing: the predecessor factors
+    // (ladder of the first kind only; the shifts of a ladder grow with t)
+    const bool idle = !local && t >= 2 && lp_shift_of(L, y, t - 1, 0., min_eig, 0) < L.slb[y];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ChJob j;
         j.A = D;
         j.info = L.info + job;
         j.linv = L.linv + (size_t)job * L.nbk * CH_NB * CH_NB;
         j.linv_keep = 1;
-        L.info[job] = 0;
+        L.info[job] = idle ? -1 : 0;          // non-zero: the factorisation kernels pass over the job, the host over the rung
         L.jobs[q * nt + (t - t0)] = j;
     }
+    if (idle) return;
     const size_t nn = (size_t)N * N;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nn; e += (size_t)gridDim.x * 256) {
         const int i = (int)(e / N), j = (int)(e % N);
@@ -1643,7 +1660,7 @@ int low_ensure(apmf_mn_batch *b, EigSet &e)
     LA(L.Linv, (size_t)cap * nn * sizeof(double));
     LA(L.linv, nj * R.nbk * blk * sizeof(double));
     LA(L.zp, (size_t)cap * (LP_RS + 3 + LP_KMAX) * R.N * sizeof(double));
-    LA(L.lam, (size_t)cap * (LP_KMAX + 2 + 2) * sizeof(double));
+    LA(L.lam, (size_t)cap * (LP_KMAX + 2 + 2 + 1) * sizeof(double));
     LA(L.jobs, nj * sizeof(ChJob));
     LA(L.info, (nj + cap) * sizeof(int));
     LA(e.lp_tab, (size_t)T_COUNT * nj * sizeof(double *));
@@ -1661,6 +1678,7 @@ int low_ensure(apmf_mn_batch *b, EigSet &e)
     L.vecs = L.wv + (size_t)cap * R.N;
     L.out = L.lam + (size_t)cap * LP_KMAX;
     L.norm = (unsigned long long *)(L.out + 2 * (size_t)cap);
+    L.slb = (double *)(L.norm + 2 * (size_t)cap);
     e.lp_sel = L.info + nj;
     // the table the triangular-inverse kernel reads: "hypothesis" = job; F = the job's factor, W = its slot's Linv
     std::vector<double *> tab((size_t)T_COUNT * nj, nullptr);
@@ -1678,7 +1696,7 @@ int low_ensure(apmf_mn_batch *b, EigSet &e)
 // min_eig; every launch goes to `st`, and the call returns with the stream drained.  Hypotheses it cannot
 // finish are appended to `fallback` with cand untouched.  Thread-safe with respect to the search thread: it
 // only touches the set's own buffers and the listed hypotheses' cand / W.
-int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vector<int> &hyps, double min_eig,
+int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vector<int> &hyps, double min_eig, bool trial,
                 std::vector<int> &fallback)
 {
     const LpRefs &L = e.lp;
@@ -1716,7 +1734,7 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
         APMF_CHECK_HIP(hipMemsetAsync(L.norm, 0, 2 * (size_t)cap * sizeof(unsigned long long), st));
         {
             const LpList S = list_of(todo);
-            hipLaunchKernelGGL(lp_norms, dim3((N + 3) / 4, nc), dim3(256), 0, st, R, L, S);
+            hipLaunchKernelGGL(lp_norms, dim3((N + 3) / 4, nc), dim3(256), 0, st, R, L, S, trial ? 1 : 0);
         }
         for (int round = 0; !todo.empty(); round++) {
             if (round > 0) {
@@ -1919,7 +1937,8 @@ rocblas_status slow_S_solve(const Refs &R, SlowS &w)
     if (w.proj.empty()) return rocblas_status_success;
     hipStream_t st = w.stream;
     if (w.low) {
-        if (low_project(R, *w.set, st, w.proj, w.min_eig, w.full) != APMF_OK) return rocblas_status_internal_error;
+        // (the projected matrix is always a trial point: SLOW_CERT_S is only raised by a trial's certificate)
+        if (low_project(R, *w.set, st, w.proj, w.min_eig, true, w.full) != APMF_OK) return rocblas_status_internal_error;
         if (w.full.empty()) return rocblas_status_success;
         // the leftovers: a fresh copy of their trial matrices, the pointer list
         const int nf = (int)w.full.size();
