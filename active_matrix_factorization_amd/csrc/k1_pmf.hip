@@ -1190,10 +1190,16 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     const int dp = dp_for(d);
     const RowDesc *desc = (const RowDesc *)r->desc;
     long long it = 0;
-    for (;;) {
-        if (max_steps == 0) break;
-        const long long remaining = max_steps < 0 ? 1 << 20 : max_steps - h_state->steps;
-        const int chunk = (int)std::min<long long>(std::max<long long>(remaining + 1, 2), 16);
+    // Chunks of <= 16 launches, the state read back after each.  A launch past the end of the search passes the
+    // state through untouched, so the NEXT chunk can be enqueued before the read-back of the current one has
+    // arrived (the stream never drains: the read-back round trip cost 2 us per launch): done whenever plenty of
+    // steps are left; a call for a step or two behaves as before.
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (int q = 0; q < 2; q++)
+            if (ev[q]) (void)hipEventDestroy(ev[q]);
+    };
+    auto enqueue_chunk = [&](int chunk, int slot) -> int {
         for (int c = 0; c < chunk; c++, it++) {
             FitState *s_in = d_state + (it & 1), *s_out = d_state + ((it + 1) & 1);
             double *p_in = d_part + (size_t)(it & 1) * FIT_GRID_MAX * 3, *p_out = d_part + (size_t)((it + 1) & 1) * FIT_GRID_MAX * 3;
@@ -1207,12 +1213,47 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
 #undef FIT_ITER
         }
         APMF_CHECK_LAUNCH();
-        APMF_CHECK_HIP(hipMemcpyAsync(h_state, d_state + (it & 1), sizeof(FitState), hipMemcpyDeviceToHost,
+        APMF_CHECK_HIP(hipMemcpyAsync(h_state + slot, d_state + (it & 1), sizeof(FitState), hipMemcpyDeviceToHost,
                                       ctx->stream));
-        APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-        if (h_state->converged || (max_steps >= 0 && h_state->steps >= max_steps)) break;
+        if (!ev[slot]) APMF_CHECK_HIP(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        APMF_CHECK_HIP(hipEventRecord(ev[slot], ctx->stream));
+        return APMF_OK;
+    };
+    FitState last = *h_state;          // the state as the host last saw it
+    if (max_steps != 0) {
+        int rc = APMF_OK;
+        int slot = 0;                  // read-back slot of the oldest chunk in flight
+        bool ahead = false;            // a second chunk is in flight behind it
+        auto chunk_for = [&](const FitState &st) {
+            const long long remaining = max_steps < 0 ? 1 << 20 : max_steps - st.steps;
+            return (int)std::min<long long>(std::max<long long>(remaining + 1, 2), 16);
+        };
+        rc = enqueue_chunk(chunk_for(last), slot);
+        while (rc == APMF_OK) {
+            // plenty left: keep the stream fed while the read-back travels
+            if (!ahead && (max_steps < 0 || max_steps - last.steps > 48)) {
+                rc = enqueue_chunk(16, slot ^ 1);
+                if (rc != APMF_OK) break;
+                ahead = true;
+            }
+            if (hipEventSynchronize(ev[slot]) != hipSuccess) { rc = APMF_EHIP; apmf_set_error("hipEventSynchronize failed"); break; }
+            last = h_state[slot];
+            if (last.converged || (max_steps >= 0 && last.steps >= max_steps)) break;
+            if (ahead) {
+                slot ^= 1;             // the chunk behind becomes the oldest
+                ahead = false;
+            } else {
+                rc = enqueue_chunk(chunk_for(last), slot);
+            }
+        }
+        if (rc != APMF_OK) {
+            (void)hipStreamSynchronize(ctx->stream);
+            cleanup();
+            return rc;
+        }
     }
-    const FitState fin = *h_state;
+    cleanup();
+    const FitState fin = last;         // (not through the pinned block: a read-back of the chunk behind may still land there)
     if (fin.cur) {
         APMF_CHECK_HIP(hipMemcpyAsync(d_U, tU, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
         APMF_CHECK_HIP(hipMemcpyAsync(d_V, tV, nv * 8, hipMemcpyDeviceToDevice, ctx->stream));
