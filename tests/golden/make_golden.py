@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2j': only section J .. R")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2k': only section J .. S")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -145,6 +145,9 @@ def main():
         return
     if args.only == 'r2j':
         round2j(np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r2k':
+        round2k(np, bayes_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -488,6 +491,7 @@ def main():
     round2h(np, active_pmf, save, seed, _print)
     round2i(np, mn_active_pmf, save, seed, _print)
     round2j(np, mn_active_pmf, save, seed, _print)
+    round2k(np, bayes_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -699,6 +703,24 @@ def round2j(np, mn_active_pmf, save, seed, _print):
         out[key + '_vals'] = np.array(steps[1][3], dtype=np.float64)
     _print('  %.0f s' % (time.perf_counter() - t0))
     save('trace_c1_mn_lookahead', **out)
+
+
+def round2k(np, bayes_pmf, save, seed, _print):
+    """S. One selection step of the Bayesian loop under its LOOKAHEAD criterion 'exp-variance'
+    (bayes_pmf.py:457-468,560-605 under compare_active -> full_test): on config 1 every unrated entry x rating
+    value is a copy + add_rating + MAP re-fit + a Gibbs chain of 30 samples in the reference, sequentially
+    (procs=0) under seed 48: the pick (arg-min), the evaluation grid, the RMSEs."""
+    g = np.load(os.path.join(HERE, 'trace_c1_mn.npz'))
+    real, ratings = g['real'], g['ratings']
+    t0 = time.perf_counter()
+    seed(48)
+    res = bayes_pmf.compare_active(['exp-variance'], 2, real, ratings.copy(), rating_vals=(1, 2, 3, 4, 5), num_steps=2,
+                                   procs=0, num_samps=8, subtract_mean=False)
+    steps = res['exp-variance']
+    _print('bayes lookahead selection step: pick %s, %.0f s' % (steps[1][2], time.perf_counter() - t0))
+    save('trace_c1_bayes_lookahead', real=real, ratings=ratings, seed=48, n_rated=np.array([s[0] for s in steps]),
+         rmse=np.array([s[1] for s in steps], dtype=np.float64), pick=np.array(steps[1][2]),
+         vals=np.array(steps[1][3], dtype=np.float64))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -327,6 +327,26 @@ def test_config1_bayes_selection_trace(pkg):
             np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-5, atol=1e-9)
 
 
+def test_config1_bayes_lookahead_selection_step(pkg):
+    """One selection step of the Bayesian loop under its LOOKAHEAD criterion 'exp-variance' (bayes_pmf.py:457-468,
+    560-605 under compare_active -> full_test): 90 unrated entries x 5 rating values, each a copy + add_rating +
+    MAP re-fit + a Gibbs chain of 30 samples - the chains run as one device batch here, their random draws in
+    the order of the sequential evaluation - on config 1 under seed 48: the REAL reference's pick (the
+    arg-min, exact), its evaluation grid and the RMSEs."""
+    g = load_golden('trace_c1_bayes_lookahead')
+    seed(int(g['seed']))
+    res = pkg.bayes.compare_active(['exp-variance'], 2, g['real'], g['ratings'].copy(), rating_vals=(1, 2, 3, 4, 5),
+                                   num_steps=2, procs=0, num_samps=8, subtract_mean=False)
+    steps = res['exp-variance']
+    assert [s[0] for s in steps] == list(g['n_rated'])
+    ref, got = g['vals'], np.asarray(steps[1][3], float)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5)
+    assert tuple(int(x) for x in steps[1][2]) == tuple(int(x) for x in g['pick'])      # selected entry: exact
+    np.testing.assert_allclose([s[1] for s in steps], g['rmse'], rtol=1e-5)
+
+
 def test_config1_full_selection_trace(pkg):
     """The full-covariance selection loop end to end (active_pmf.py:933-1090: compare -> full_test -> fit ->
     initialize_approx (a random covariance from the seeded NumPy stream) -> fit_normal -> score -> pick ->
