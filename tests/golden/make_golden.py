@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2k': only section J .. S")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2l': only section J .. T")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -148,6 +148,9 @@ def main():
         return
     if args.only == 'r2k':
         round2k(np, bayes_pmf, save, seed, _print)
+        return
+    if args.only == 'r2l':
+        round2l(np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -492,6 +495,7 @@ def main():
     round2i(np, mn_active_pmf, save, seed, _print)
     round2j(np, mn_active_pmf, save, seed, _print)
     round2k(np, bayes_pmf, save, seed, _print)
+    round2l(np, mn_active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -721,6 +725,29 @@ def round2k(np, bayes_pmf, save, seed, _print):
     save('trace_c1_bayes_lookahead', real=real, ratings=ratings, seed=48, n_rated=np.array([s[0] for s in steps]),
          rmse=np.array([s[1] for s in steps], dtype=np.float64), pick=np.array(steps[1][2]),
          vals=np.array(steps[1][3], dtype=np.float64))
+
+
+def round2l(np, mn_active_pmf, save, seed, _print):
+    """T. configs[3] (DrugBank 94 x 425 rank 5) under the LOOKAHEAD criterion: pick_query_point over a pool of
+    three unrated entries by exp_total_variance (mn_active_pmf.py:660-696, 701-729) from the converged
+    approximation of section G - six hypothesis re-fits to convergence, about 5 minutes each in the reference:
+    the three criterion values and the pick (the arg-min)."""
+    g = np.load(os.path.join(HERE, 'mn_c4_94x425_d5.npz'))
+    MN = mn_active_pmf.MNActivePMF
+    a = MN(g['ratings'].copy(), latent_d=5, rating_values=(0., 1.), discrete_expectations=True)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    a.mean, a.cov_useritems, a.cov_latents = g['mean_fit'].copy(), g['cov_useritems_fit'].copy(), g['cov_latents_fit'].copy()
+    unrated = sorted(a.unrated)
+    pool = [unrated[11], unrated[12], unrated[20011]]
+    assert tuple(int(x) for x in g['cand']) == tuple(pool[0])
+    t0 = time.perf_counter()
+    vals = []
+    for ij in pool:
+        vals.append(a.exp_total_variance(ij))
+        _print('c4 pool: %s -> %r, %.0f s' % (ij, vals[-1], time.perf_counter() - t0))
+    pick = pool[int(np.argmin(vals))]          # what pick_query_point returns for a criterion whose chooser is min (:109, :729)
+    save('lookahead_c4_pool', pool=np.array(pool), vals=np.array(vals, dtype=np.float64), pick=np.array(pick))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -1038,6 +1038,25 @@ def test_configs3_golden_lookahead(pkg):
     assert vals[0] == got
 
 
+def test_configs3_golden_lookahead_pool_pick(pkg):
+    """configs[3] under the lookahead criterion, as a selection: pick_query_point over a pool of three unrated
+    entries by exp_total_variance from the reference's converged approximation - six hypothesis re-fits to
+    convergence, half an hour in the reference (make_golden.py section T), one device batch here: its three
+    criterion values (2e-4, the stopping tolerance of the re-fits) and its pick (the arg-min, exact)."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lookahead_c4_pool.npz')):
+        pytest.skip('tests/golden/lookahead_c4_pool.npz not generated (make_golden.py --only r2l: half an hour)')
+    g = load_golden('mn_c4_94x425_d5')
+    t = load_golden('lookahead_c4_pool')
+    a = _c4_model(pkg, g, 'fit')
+    pool = [tuple(int(x) for x in ij) for ij in t['pool']]
+    key = pkg.mn.KEY_FUNCS['total-variance']
+    vals = np.asarray(a._get_key_vals(pool, key), float)
+    np.testing.assert_allclose(vals, t['vals'], rtol=2e-4)
+    assert abs(float(t['vals'][0]) - float(g['exp_total_variance'])) <= 1e-9 * abs(float(g['exp_total_variance']))
+    assert a.pick_query_point(pool=pool, key=key) == tuple(int(x) for x in t['pick'])
+
+
 def test_headline_shape_golden_scoring_and_selection(pkg):
     """BASELINE.json's metric shape - 943 x 1682, rank 10 - recorded from the real reference
     (make_golden.py section J: approx_pred_means_vars over all 1 586 126 entries, pick_query_point over
