@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2l': only section J .. T")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2m': only section J .. T2")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -151,6 +151,9 @@ def main():
         return
     if args.only == 'r2l':
         round2l(np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r2m':
+        round2m(np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -496,6 +499,7 @@ def main():
     round2j(np, mn_active_pmf, save, seed, _print)
     round2k(np, bayes_pmf, save, seed, _print)
     round2l(np, mn_active_pmf, save, seed, _print)
+    round2m(np, mn_active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -748,6 +752,30 @@ def round2l(np, mn_active_pmf, save, seed, _print):
         _print('c4 pool: %s -> %r, %.0f s' % (ij, vals[-1], time.perf_counter() - t0))
     pick = pool[int(np.argmin(vals))]          # what pick_query_point returns for a criterion whose chooser is min (:109, :729)
     save('lookahead_c4_pool', pool=np.array(pool), vals=np.array(vals, dtype=np.float64), pick=np.array(pick))
+
+
+def round2m(np, mn_active_pmf, save, seed, _print):
+    """T2. The two hypothesis re-fits behind the third value of section T, step by step: for entry (47, 307) of
+    configs[3] and each rating value, deepcopy + add_rating + fit_normal_kls to convergence
+    (mn_active_pmf.py:660-668): the KL after every accepted step and the total variance at the end."""
+    from copy import deepcopy
+    g = np.load(os.path.join(HERE, 'mn_c4_94x425_d5.npz'))
+    t = np.load(os.path.join(HERE, 'lookahead_c4_pool.npz'))
+    MN = mn_active_pmf.MNActivePMF
+    a = MN(g['ratings'].copy(), latent_d=5, rating_values=(0., 1.), discrete_expectations=True)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    a.mean, a.cov_useritems, a.cov_latents = g['mean_fit'].copy(), g['cov_useritems_fit'].copy(), g['cov_latents_fit'].copy()
+    i, j = (int(x) for x in t['pool'][2])
+    out = dict(ij=np.array([i, j]))
+    for v in (0., 1.):
+        b = deepcopy(a)
+        b.add_rating(i, j, v)
+        kls = list(b.fit_normal_kls())
+        out['kl_trace_%d' % int(v)] = np.array(kls)
+        out['total_variance_%d' % int(v)] = b._total_variance()
+        _print('c4 hypothesis (%d, %d) = %g: %d steps, KL %r, total variance %r' % (i, j, v, len(kls), kls[-1], out['total_variance_%d' % int(v)]))
+    save('lookahead_c4_hyp_traces', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -1041,20 +1041,37 @@ def test_configs3_golden_lookahead(pkg):
 def test_configs3_golden_lookahead_pool_pick(pkg):
     """configs[3] under the lookahead criterion, as a selection: pick_query_point over a pool of three unrated
     entries by exp_total_variance from the reference's converged approximation - six hypothesis re-fits to
-    convergence, half an hour in the reference (make_golden.py section T), one device batch here: its three
-    criterion values (2e-4, the stopping tolerance of the re-fits) and its pick (the arg-min, exact)."""
-    import os
-    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'lookahead_c4_pool.npz')):
-        pytest.skip('tests/golden/lookahead_c4_pool.npz not generated (make_golden.py --only r2l: half an hour)')
+    convergence, half an hour in the reference (make_golden.py section T), one device batch here.  The pick (the
+    arg-min) is the reference's; two of the three criterion values agree to 1e-7.  The third does not, and
+    section T2 (the reference's own KL traces of its two hypotheses) shows why: for rating value 1 the 651
+    accepted steps agree throughout (total variance to 1e-12); for value 0 the traces agree to 1e-10 for 150
+    steps, then drift (the search is chaotic), and the stopping rule - an accepted step that
+    improves the KL by less than 0.005 - fires on a chance small step at step 259 here and at step 522 there."""
+    from copy import deepcopy
     g = load_golden('mn_c4_94x425_d5')
     t = load_golden('lookahead_c4_pool')
+    tr = load_golden('lookahead_c4_hyp_traces')
     a = _c4_model(pkg, g, 'fit')
     pool = [tuple(int(x) for x in ij) for ij in t['pool']]
     key = pkg.mn.KEY_FUNCS['total-variance']
     vals = np.asarray(a._get_key_vals(pool, key), float)
-    np.testing.assert_allclose(vals, t['vals'], rtol=2e-4)
+    np.testing.assert_allclose(vals[:2], t['vals'][:2], rtol=2e-6)
+    np.testing.assert_allclose(vals[2], t['vals'][2], rtol=.1)
     assert abs(float(t['vals'][0]) - float(g['exp_total_variance'])) <= 1e-9 * abs(float(g['exp_total_variance']))
     assert a.pick_query_point(pool=pool, key=key) == tuple(int(x) for x in t['pick'])
+    # the two hypotheses of the third entry, step by step
+    i, j = (int(x) for x in tr['ij'])
+    assert (i, j) == pool[2]
+    for v in (0, 1):
+        b = deepcopy(a)
+        b.add_rating(i, j, float(v))
+        kls = np.array(list(b.fit_normal_kls()))
+        ref = tr['kl_trace_%d' % v]
+        np.testing.assert_allclose(kls[:120], ref[:120], rtol=1e-9)
+        if v == 1:
+            assert kls.size == ref.size
+            np.testing.assert_allclose(kls, ref, rtol=1e-7)
+            np.testing.assert_allclose(b._total_variance(), tr['total_variance_1'], rtol=1e-8)
 
 
 def test_headline_shape_golden_scoring_and_selection(pkg):
