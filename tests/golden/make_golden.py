@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2m': only section J .. T2")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -154,6 +154,9 @@ def main():
         return
     if args.only == 'r2m':
         round2m(np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r2n':
+        round2n(np, active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -500,6 +503,7 @@ def main():
     round2k(np, bayes_pmf, save, seed, _print)
     round2l(np, mn_active_pmf, save, seed, _print)
     round2m(np, mn_active_pmf, save, seed, _print)
+    round2n(np, active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -776,6 +780,24 @@ def round2m(np, mn_active_pmf, save, seed, _print):
         out['total_variance_%d' % int(v)] = b._total_variance()
         _print('c4 hypothesis (%d, %d) = %g: %d steps, KL %r, total variance %r' % (i, j, v, len(kls), kls[-1], out['total_variance_%d' % int(v)]))
     save('lookahead_c4_hyp_traces', **out)
+
+
+def round2n(np, active_pmf, save, seed, _print):
+    """U. One selection step of the full-covariance loop under the LOOKAHEAD criterion 'total-variance'
+    (active_pmf.py:560-640 under compare()): config 1, every unrated entry x rating value a deepcopy + add_rating +
+    fit_normal to convergence of the (n+m)d x (n+m)d approximation, under seed 49 (initialize_approx draws its
+    random covariance from it): the pick, the evaluation grid, the RMSEs."""
+    g = np.load(os.path.join(HERE, 'trace_c1_mn.npz'))
+    real, ratings = g['real'], g['ratings']
+    t0 = time.perf_counter()
+    seed(49)
+    res = active_pmf.compare(['total-variance'], latent_d=2, do_threading=False, steps=2, discrete_exp=True,
+                             real_ratings_vals=(real, ratings.copy(), (1, 2, 3, 4, 5)))
+    steps = res['total-variance']
+    _print('full-covariance lookahead selection step: pick %s, %.0f s' % (steps[1][2], time.perf_counter() - t0))
+    save('trace_c1_full_lookahead', real=real, ratings=ratings, seed=49, n_rated=np.array([s[0] for s in steps]),
+         rmse=np.array([s[1] for s in steps], dtype=np.float64), pick=np.array(steps[1][2]),
+         vals=np.array(steps[1][3], dtype=np.float64))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):
