@@ -288,13 +288,14 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
         return res
 
     def __deepcopy__(self, memodict):
+        rec = self._recipe_clone()
         res = type(self)(self.ratings, self.latent_d, self.rating_values,
-                         self.discrete_expectations)
-        res.__setstate__(deepcopy(self.__getstate__(), memodict))
+                         self.discrete_expectations, **({} if rec is None else {'knowable': rec}))
+        res.__setstate__(deepcopy(self.__getstate__(_pairs=rec is None), memodict))
         return res
 
-    def __getstate__(self):
-        state = super(_ActiveBase, self).__getstate__()
+    def __getstate__(self, _pairs=True):
+        state = super(_ActiveBase, self).__getstate__(_pairs)
         state['__dict__'] = self._extra_dict()
         state['__dict__'].pop('lookahead_comm', None)       # a communicator is not model state
         return state
@@ -322,6 +323,12 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             extra = np.array(extra, ndmin=2)
             dev.cand.remove(dev.ctx, [(int(i), int(j)) for i, j in extra[:, :2]])
             dev.cand.count = self._n_unrated()
+
+    def _is_rated(self, i, j):
+        rec = self.__dict__.get('_pairs_recipe')
+        if rec is not None:
+            return bool(rec.rated_mask[i, j])
+        return (i, j) in self.rated
 
     def _candidates(self):
         dev = self._device()
@@ -529,6 +536,16 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
         deep copy re-fitted on its own, a few at a time on worker threads."""
         batch = getattr(self, '_lookahead_batch', None)
         if batch is not None and len(hyps) > 0 and lookahead_batched():
+            # what calculate_fn's deepcopy + add_rating would have done besides the arithmetic: refuse a
+            # hypothesis about an entry that is already rated (pmf_cy.pyx:143-150), and - when the reference
+            # evaluates in-process (procs == 1; its default hands the pool to forked workers, whose draws the
+            # parent never sees) - consume the n d + m d uniform draws of every copy's constructor
+            # (pmf_cy.pyx:74-75), so that a seeded run continues with the same random stream
+            for i, j, _ in hyps:
+                if self._is_rated(i, j):
+                    raise ValueError("can't rate already rated items")
+            if procs == 1:
+                np.random.random(len(hyps) * (self.num_users + self.num_items) * self.latent_d)
             return batch(hyps, fn, pass_v)
         # the copies are made here, in order: their constructors draw from the global RNG
         models = [self._hypothesis_model(i, j, v) for i, j, v in hyps]

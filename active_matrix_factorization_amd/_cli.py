@@ -31,13 +31,31 @@ class _RestrictedUnpickler(pickle.Unpickler):
         ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'range'), ('builtins', 'complex'),
         ('collections', 'OrderedDict'), ('copyreg', '_reconstructor'), ('builtins', 'object'),
     }
-    _OWN_MODULES = ('pmf_cy', 'mn_active_pmf', 'active_pmf', 'bayes_pmf', '_active_base')
+    # model classes a results / model file may name, per module of this package.  A bare module name
+    # (what the reference's own pickles say: 'mn_active_pmf.MNActivePMF') is resolved to THIS package's
+    # module of that name, never to whatever 'mn_active_pmf' happens to be importable from sys.path.
+    _OWN_CLASSES = {
+        'pmf_cy': ('ProbabilisticMatrixFactorization', '_PairsRecipe'),
+        'mn_active_pmf': ('MNActivePMF',),
+        'active_pmf': ('ActivePMF',),
+        'bayes_pmf': ('BayesianPMF',),
+    }
 
     def find_class(self, module, name):
-        base = module.split('.')[-1]
-        own = base in self._OWN_MODULES and (module == base or module.startswith('active_matrix_factorization_amd.'))
-        if (module, name) in self._ALLOWED or own:
+        if (module, name) in self._ALLOWED:
             return super().find_class(module, name)
+        base = module.rpartition('.')[2]
+        pkg = __package__ or ''
+        # protocol-4 pickles resolve dotted names attribute by attribute ('os.getcwd' through a module
+        # that imports os): only plain class names from the explicit list, and the object found must be
+        # a class defined in that very module
+        if '.' not in name and name in self._OWN_CLASSES.get(base, ()) and \
+                module in (base, (pkg + '.' + base) if pkg else base):
+            import importlib
+            mod = importlib.import_module((pkg + '.' + base) if pkg else base)
+            obj = getattr(mod, name, None)
+            if isinstance(obj, type) and obj.__module__ == mod.__name__:
+                return obj
         raise pickle.UnpicklingError("refusing to load %s.%s from a pickle: only NumPy arrays, builtin "
                                      "containers and this package's model classes are accepted (convert the "
                                      "file to .npz)" % (module, name))

@@ -64,6 +64,7 @@ _SIGS = {
     'apmf_pmf_gradient': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, _vp, _vp]),
     'apmf_pmf_gradient_rows': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, _vp]),
     'apmf_pmf_ll_terms': (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _i, _i, _i, _i, C.POINTER(_dbl)]),
+    'apmf_pmf_ll_terms_dev': (_i, [_vp, _vp, _vp, _vp, _i, _i, _dbl, _i, _i, _i, _i, _vp]),
     'apmf_pmf_log_likelihood': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl,
                                      C.POINTER(_dbl), C.POINTER(_dbl)]),
     'apmf_pmf_fit_lls': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, C.POINTER(_dbl),
@@ -109,7 +110,8 @@ _DENSE_SIGS.update({
     'apmf_mn_batch_destroy': (_i, [_vp, _vp]),
     'apmf_mn_batch_size': (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     'apmf_mn_batch_fit_stats': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
-                                     C.POINTER(_i64)]),
+                                     C.POINTER(_i64), C.POINTER(_i64)]),
+    'apmf_mn_batch_launch_count': (_i, [C.POINTER(_i64)]),
     'apmf_mn_batch_set_state': (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     'apmf_mn_batch_set_extra': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'apmf_mn_batch_get_state': (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -129,6 +131,8 @@ _COMM_SIGS = {
     'apmf_comm_destroy': (_i, [_vp]),
     'apmf_comm_rank': (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     'apmf_comm_allgather': (_i, [_vp, _vp, _vp, _vp, _sz]),
+    'apmf_comm_allgather_multi': (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    'apmf_comm_version': (_i, [C.POINTER(_i)]),
     'apmf_comm_allreduce_f64': (_i, [_vp, _vp, _vp, _vp, _sz]),
     'apmf_comm_barrier': (_i, [_vp, _vp]),
 }
@@ -213,14 +217,39 @@ class _LateTorchGuard(object):
     importing torch later in the same process - into an ImportError that says what to do.
     (torch imported first is fine: the dense library then binds to the copies torch loaded.)"""
 
+    _MESSAGE = (
+        "import torch after active_matrix_factorization_amd has loaded libapmf_dense.so: PyTorch's "
+        "bundled rocBLAS / rocSOLVER clash with the system copies already loaded and the process "
+        "would crash.  Import torch BEFORE the first use of this package (or run the two in "
+        "separate processes); APMF_ALLOW_LATE_TORCH=1 disables this check.")
+
     def find_spec(self, name, path=None, target=None):
-        if name == 'torch' and 'torch' not in sys.modules and os.environ.get('APMF_ALLOW_LATE_TORCH') != '1':
-            raise ImportError(
-                "import torch after active_matrix_factorization_amd has loaded libapmf_dense.so: PyTorch's "
-                "bundled rocBLAS / rocSOLVER clash with the system copies already loaded and the process "
-                "would crash.  Import torch BEFORE the first use of this package (or run the two in "
-                "separate processes); APMF_ALLOW_LATE_TORCH=1 disables this check.")
+        if name != 'torch' or 'torch' in sys.modules or os.environ.get('APMF_ALLOW_LATE_TORCH') == '1':
+            return None
+        # availability probes (importlib.util.find_spec('torch')) get the real answer - None, or a spec -
+        # and only an actual import, which runs the spec's loader, raises
+        spec = None
+        for finder in sys.meta_path:
+            if finder is self or not hasattr(finder, 'find_spec'):
+                continue
+            spec = finder.find_spec(name, path, target)
+            if spec is not None:
+                break
+        if spec is None:
+            return None
+        spec.loader = _RefuseLoader(self._MESSAGE)
+        return spec
+
+
+class _RefuseLoader(object):
+    def __init__(self, message):
+        self.message = message
+
+    def create_module(self, spec):
         return None
+
+    def exec_module(self, module):
+        raise ImportError(self.message)
 
 
 def _open_dense():
@@ -425,9 +454,10 @@ class MNBatch(object):
     def fit_stats(self):
         """Counters of the last fit(): search iterations, trial points, projections finished through the lowest
         eigenpairs / through the full eigendecomposition, trial certificates settled by the eigenvalue bound."""
-        v = [C.c_int64(0) for _ in range(5)]
+        v = [C.c_int64(0) for _ in range(6)]
         _check(self._dense.apmf_mn_batch_fit_stats(self._h, *[C.byref(x) for x in v]))
-        return dict(zip(('iterations', 'trials', 'proj_low', 'proj_full', 'cert_by_bound'), (int(x.value) for x in v)))
+        return dict(zip(('iterations', 'trials', 'proj_low', 'proj_full', 'cert_by_bound', 'gradients'),
+                        (int(x.value) for x in v)))
 
     def kl(self, sig, sig_u, sig_v):
         out = np.empty(self.H)
@@ -461,6 +491,13 @@ class MNBatch(object):
         _check(self._dense.apmf_mn_batch_score_grid(self.ctx._h, self._h, int(h0), int(B), int(bool(f32)), ld,
                                                     _ptr(mask), _ptr(var), _ptr(pmean), _ptr(dsum), int(want),
                                                     _ptr(best_val), _ptr(best_idx)))
+
+
+def batch_launch_count():
+    """Kernel launches enqueued by the batch engine (k6_batch.hip) in this process so far."""
+    v = _i64(0)
+    _check(load_dense().apmf_mn_batch_launch_count(C.byref(v)))
+    return int(v.value)
 
 
 class Context(object):
@@ -586,6 +623,11 @@ class Context(object):
                                            int(bool(subtract_mean)), mean_rating, u_lo, u_hi, v_lo, v_hi,
                                            t))
         return np.array(t[:], np.float64)
+
+    def pmf_ll_terms_dev(self, rt, dU, dV, d, subtract_mean, mean_rating, u_lo, u_hi, v_lo, v_hi, out3):
+        """the three sums of pmf_ll_terms left on the device (out3: pointer / DeviceArray), no host sync"""
+        _check(self._lib.apmf_pmf_ll_terms_dev(self._h, rt._h, _ptr(dU), _ptr(dV), d, int(bool(subtract_mean)),
+                                               mean_rating, u_lo, u_hi, v_lo, v_hi, _ptr(out3)))
 
     def pmf_log_likelihood(self, rt, dU, dV, d, sig, sig_u, sig_v, subtract_mean, mean_rating):
         ll, sq = _dbl(), _dbl()

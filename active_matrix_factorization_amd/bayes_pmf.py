@@ -97,12 +97,13 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
         return res
 
     def __deepcopy__(self, memodict):
-        res = BayesianPMF(self.ratings, self.latent_d)
-        res.__setstate__(deepcopy(self.__getstate__(), memodict))
+        rec = self._recipe_clone()
+        res = BayesianPMF(self.ratings, self.latent_d, **({} if rec is None else {'knowable': rec}))
+        res.__setstate__(deepcopy(self.__getstate__(_pairs=rec is None), memodict))
         return res
 
-    def __getstate__(self):
-        state = super(BayesianPMF, self).__getstate__()
+    def __getstate__(self, _pairs=True):
+        state = super(BayesianPMF, self).__getstate__(_pairs)
         state['__dict__'] = self._extra_dict()
         return state
 

@@ -18,6 +18,12 @@
 #include <stdlib.h>
 #include "common.h"
 
+// every launch of this header goes through APMF_LAUNCH so that a translation unit can count them
+// (k6_batch.hip: launches per hypothesis, a tracked number of the lookahead)
+#ifndef APMF_LAUNCH
+#define APMF_LAUNCH hipLaunchKernelGGL
+#endif
+
 constexpr int CH_NB = 64;
 constexpr int CH_FUSE_JOBS = 32;   // up to this many matrices per launch: update + next diagonal block in one launch
 
@@ -499,26 +505,26 @@ static inline int chol_lower_jobs_on(hipStream_t stream, const ChJobs &J, int nj
         const int nbk = (N + CH_NB - 1) / CH_NB;
         for (int jb = 0; jb < nbk; jb++) {
             const int k = jb * CH_NB;
-            if (jb > 0) hipLaunchKernelGGL(k_chol_col, dim3(nbk - jb, njobs), dim3(256), 0, stream, J, N, jb);
-            hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, stream, J, N, k);
+            if (jb > 0) APMF_LAUNCH(k_chol_col, dim3(nbk - jb, njobs), dim3(256), 0, stream, J, N, jb);
+            APMF_LAUNCH(k_chol_diag, dim3(1, njobs), dim3(256), 0, stream, J, N, k);
             const int rest = N - k - CH_NB;
-            if (rest > 0) hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, stream, J, N, k);
+            if (rest > 0) APMF_LAUNCH(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, stream, J, N, k);
         }
         APMF_CHECK_LAUNCH();
         return APMF_OK;
     }
     for (int k = 0; k < N; k += CH_NB) {
         const int nb = N - k < CH_NB ? N - k : CH_NB;
-        if (k == 0 || !next) hipLaunchKernelGGL(k_chol_diag, dim3(1, njobs), dim3(256), 0, stream, J, N, k);
+        if (k == 0 || !next) APMF_LAUNCH(k_chol_diag, dim3(1, njobs), dim3(256), 0, stream, J, N, k);
         const int rest = N - k - nb;
         if (rest > 0) {
-            hipLaunchKernelGGL(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, stream, J, N, k);
+            APMF_LAUNCH(k_chol_panel, dim3((rest + 63) / 64, njobs), dim3(256), 0, stream, J, N, k);
             const int tiles = (rest + 63) / 64;
             if (next)
-                hipLaunchKernelGGL(k_chol_update<true>, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), next_lds,
+                APMF_LAUNCH(k_chol_update<true>, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), next_lds,
                                    stream, J, N, k);
             else
-                hipLaunchKernelGGL(k_chol_update<false>, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), 0,
+                APMF_LAUNCH(k_chol_update<false>, dim3(tiles * (tiles + 1) / 2, njobs), dim3(256), 0,
                                    stream, J, N, k);
         }
     }

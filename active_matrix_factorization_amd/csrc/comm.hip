@@ -105,6 +105,42 @@ int apmf_comm_allgather(apmf_ctx *ctx, apmf_comm *c, const void *d_send, void *d
     return APMF_OK;
 }
 
+// `count` all-gathers as ONE group (ncclGroupStart / End: RCCL aggregates them into a single launch):
+// d_recv[k] (world * bytes[k]) <- every rank's d_send[k] (bytes[k]).  The exchange step of a sharded fit_lls
+// trial - U and V blocks of both speculative branches plus the log-likelihood partial sums - is one such
+// group: one collective per trial instead of two all-gathers and an all-reduce.
+int apmf_comm_allgather_multi(apmf_ctx *ctx, apmf_comm *c, int count, const void *const *d_send, void *const *d_recv,
+                              const size_t *bytes_per_rank)
+{
+    APMF_REQUIRE(ctx && c, "NULL operand");
+    APMF_REQUIRE(count >= 0 && count <= 16, "bad group size %d (0..16)", count);
+    if (count == 0) return APMF_OK;
+    APMF_REQUIRE(d_send && d_recv && bytes_per_rank, "NULL operand");
+    for (int k = 0; k < count; k++)
+        APMF_REQUIRE(bytes_per_rank[k] == 0 || (d_send[k] && d_recv[k]), "NULL buffer in group entry %d", k);
+    APMF_CHECK_NCCL(ncclGroupStart());
+    ncclResult_t first = ncclSuccess;
+    for (int k = 0; k < count; k++) {
+        if (bytes_per_rank[k] == 0) continue;
+        ncclResult_t r = ncclAllGather(d_send[k], d_recv[k], bytes_per_rank[k], ncclInt8, c->nccl, ctx->stream);
+        if (r != ncclSuccess && first == ncclSuccess) first = r;
+    }
+    ncclResult_t end = ncclGroupEnd();        // always closed, even after a failed enqueue
+    if (first != ncclSuccess || end != ncclSuccess) {
+        apmf_set_error("grouped ncclAllGather failed: %s", ncclGetErrorString(first != ncclSuccess ? first : end));
+        return APMF_EHIP;
+    }
+    return APMF_OK;
+}
+
+// RCCL's version code (e.g. 22106), for the one-line diagnostic a rank prints when it joins
+int apmf_comm_version(int *version)
+{
+    APMF_REQUIRE(version, "NULL operand");
+    APMF_CHECK_NCCL(ncclGetVersion(version));
+    return APMF_OK;
+}
+
 // d_recv[i] <- sum over ranks of d_send[i]   (in place allowed)
 int apmf_comm_allreduce_f64(apmf_ctx *ctx, apmf_comm *c, const double *d_send, double *d_recv, size_t count)
 {

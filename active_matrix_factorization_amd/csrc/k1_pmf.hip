@@ -1121,6 +1121,25 @@ int apmf_pmf_ll_terms(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, c
     return APMF_OK;
 }
 
+int apmf_pmf_ll_terms_dev(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V, int d,
+                          int subtract_mean, double mean_rating, int user_lo, int user_hi, int item_lo,
+                          int item_hi, double *d_terms3)
+{
+    APMF_TRY(check_common(ctx, r, d, 1., 1., 1.));
+    APMF_REQUIRE(d_U && d_V && d_terms3, "NULL operand");
+    APMF_REQUIRE(0 <= user_lo && user_lo <= user_hi && user_hi <= r->n && 0 <= item_lo &&
+                     item_lo <= item_hi && item_hi <= r->m, "bad row ranges");
+    const PmfParams p = make_params(r, d, 1., 1., 1., subtract_mean, mean_rating);
+    const int nparts = ll_parts(r, user_lo, user_hi, item_lo, item_hi);
+    void *w;
+    APMF_TRY(apmf_ws(ctx, 1, (size_t)nparts * 24 + 128, &w));
+    double *d_part = (double *)w;
+    double *d_out = d_part + (size_t)nparts * 3;
+    APMF_TRY(launch_ll(ctx, r, p, 1., d_U, d_V, d_part, d_out, user_lo, user_hi, item_lo, item_hi));
+    APMF_CHECK_HIP(hipMemcpyAsync(d_terms3, d_out + 1, 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return APMF_OK;
+}
+
 #ifdef APMF_K1_TIMING
 int apmf_k1_stamps(unsigned long long *h_out)
 {

@@ -45,6 +45,15 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+// every kernel launch of the batch engine is counted (apmf_mn_batch_launch_count): the chain of dependent
+// launches per hypothesis-step is what bounds small batches, so it is a tracked number
+static std::atomic<long long> g_k6_launches{0};
+#define APMF_LAUNCH(...)                                              \
+    do {                                                              \
+        g_k6_launches.fetch_add(1, std::memory_order_relaxed);        \
+        hipLaunchKernelGGL(__VA_ARGS__);                              \
+    } while (0)
+
 #include "chol.h"
 #include "common.h"
 
@@ -1567,10 +1576,10 @@ int launch_value(apmf_mn_batch *b, const int *sel, int nsel, int tm, int ts, int
     const Refs &R = b->R;
     hipStream_t st = b->ctx->stream;
     if (with_rowconst)
-        hipLaunchKernelGGL(kb_rowconst, dim3((R.N + 255) / 256, nsel), dim3(256), 0, st, R, sel, tm, ts, to);
-    DISPATCH_DP6(dp6_for(R.d), hipLaunchKernelGGL((kb_value_rows<DP>), dim3((R.n + 3) / 4, nsel), dim3(256), 0, st,
+        APMF_LAUNCH(kb_rowconst, dim3((R.N + 255) / 256, nsel), dim3(256), 0, st, R, sel, tm, ts, to);
+    DISPATCH_DP6(dp6_for(R.d), APMF_LAUNCH((kb_value_rows<DP>), dim3((R.n + 3) / 4, nsel), dim3(256), 0, st,
                                                  R, sel, tm, ts, b->r->ptr[0], b->r->idx[0], b->r->val[0]));
-    hipLaunchKernelGGL(kb_value_finish, dim3(nsel), dim3(256), 0, st, R, sel, tm, mode, forced, sigma_sq, sigma_u_sq);
+    APMF_LAUNCH(kb_value_finish, dim3(nsel), dim3(256), 0, st, R, sel, tm, mode, forced, sigma_sq, sigma_u_sq);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -1582,13 +1591,13 @@ int launch_factor(apmf_mn_batch *b, const int *sel, int nsel, int mode, ChJob *j
 {
     const Refs &R = b->R;
     if (!jobs) jobs = R.jobs;
-    hipLaunchKernelGGL(kb_make_jobs, dim3((nsel + 63) / 64), dim3(64), 0, b->ctx->stream, R, sel, nsel, mode, jobs);
+    APMF_LAUNCH(kb_make_jobs, dim3((nsel + 63) / 64), dim3(64), 0, b->ctx->stream, R, sel, nsel, mode, jobs);
     APMF_CHECK_LAUNCH();
     ChJobs J;
     memset(&J, 0, sizeof(J));
     J.list = jobs;
     APMF_TRY(chol_lower_jobs(b->ctx, J, mode == 2 ? 2 * nsel : nsel, R.N));
-    hipLaunchKernelGGL(kb_logdet, dim3(nsel), dim3(64), 0, b->ctx->stream, R, sel);
+    APMF_LAUNCH(kb_logdet, dim3(nsel), dim3(64), 0, b->ctx->stream, R, sel);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -1734,13 +1743,13 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
         APMF_CHECK_HIP(hipMemsetAsync(L.norm, 0, 2 * (size_t)cap * sizeof(unsigned long long), st));
         {
             const LpList S = list_of(todo);
-            hipLaunchKernelGGL(lp_norms, dim3((N + 3) / 4, nc), dim3(256), 0, st, R, L, S, trial ? 1 : 0);
+            APMF_LAUNCH(lp_norms, dim3((N + 3) / 4, nc), dim3(256), 0, st, R, L, S, trial ? 1 : 0);
         }
         for (int round = 0; !todo.empty(); round++) {
             if (round > 0) {
                 // has the deflated matrix anything left below min_eig?  its certificate, alone
                 const LpList S = list_of(todo);
-                hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, S.n), dim3(256), 0, st, R, L, S, 0, 1, min_eig, 0);
+                APMF_LAUNCH(lp_shift, dim3(g_mat.x, S.n), dim3(256), 0, st, R, L, S, 0, 1, min_eig, 0);
                 APMF_CHECK_LAUNCH();
                 ChJobs J;
                 memset(&J, 0, sizeof(J));
@@ -1759,7 +1768,7 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
             }
             // bracket: the ladder of shifts, one batched factorisation
             LpList S = list_of(todo);
-            hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, S.n * (LP_NS - 1)), dim3(256), 0, st, R, L, S, 1, LP_NS - 1, min_eig, 0);
+            APMF_LAUNCH(lp_shift, dim3(g_mat.x, S.n * (LP_NS - 1)), dim3(256), 0, st, R, L, S, 1, LP_NS - 1, min_eig, 0);
             APMF_CHECK_LAUNCH();
             {
                 ChJobs J;
@@ -1789,8 +1798,8 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
             }
             APMF_CHECK_HIP(hipMemcpyAsync(e.lp_sel, sel_h, (size_t)S.n * sizeof(int), hipMemcpyHostToDevice, st));
             for (int k = 0; k + 1 < R.nbk; k++)
-                hipLaunchKernelGGL(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), S.n), dim3(256), 0, st, R2, e.lp_sel, k);
-            hipLaunchKernelGGL(lp_init, dim3((N + 255) / 256, S.n), dim3(256), 0, st, L, S);
+                APMF_LAUNCH(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), S.n), dim3(256), 0, st, R2, e.lp_sel, k);
+            APMF_LAUNCH(lp_init, dim3((N + 255) / 256, S.n), dim3(256), 0, st, L, S);
             APMF_CHECK_LAUNCH();
             // inverse iteration, the Rayleigh pair and its residual looked at every few steps
             std::vector<int> run = todo;
@@ -1803,11 +1812,11 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
                 for (int q = 0; q < T.n; q++) T.a[q] = rung[T.y[q]];
                 const int its = chk == 0 ? 12 : 6;
                 for (int it = 0; it < its; it++) {
-                    hipLaunchKernelGGL(lp_fwd, dim3(g_rows.x, T.n), dim3(256), xs_bytes, st, L, T);
-                    hipLaunchKernelGGL(lp_bwd, dim3(R.nbk * LP_RS, T.n), dim3(256), 0, st, L, T);
+                    APMF_LAUNCH(lp_fwd, dim3(g_rows.x, T.n), dim3(256), xs_bytes, st, L, T);
+                    APMF_LAUNCH(lp_bwd, dim3(R.nbk * LP_RS, T.n), dim3(256), 0, st, L, T);
                 }
-                hipLaunchKernelGGL(lp_resid, dim3(g_rows.x, T.n), dim3(256), xs_bytes, st, R, L, T);
-                hipLaunchKernelGGL(lp_final, dim3(T.n), dim3(256), 0, st, L, T);
+                APMF_LAUNCH(lp_resid, dim3(g_rows.x, T.n), dim3(256), xs_bytes, st, R, L, T);
+                APMF_LAUNCH(lp_final, dim3(T.n), dim3(256), 0, st, L, T);
                 APMF_CHECK_LAUNCH();
                 APMF_TRY(sync_read(out_h, L.out, 2 * (size_t)cap * sizeof(double)));
                 std::vector<int> more, closer;
@@ -1836,7 +1845,7 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
                 if (!closer.empty()) {
                     // ladder of shifts below the Rayleigh pair, one batched factorisation, the closest rung that factors
                     LpList C = list_of(closer);
-                    hipLaunchKernelGGL(lp_shift, dim3(g_mat.x, C.n * (LP_NS - 2)), dim3(256), 0, st, R, L, C, 1, LP_NS - 2, min_eig, 1);
+                    APMF_LAUNCH(lp_shift, dim3(g_mat.x, C.n * (LP_NS - 2)), dim3(256), 0, st, R, L, C, 1, LP_NS - 2, min_eig, 1);
                     APMF_CHECK_LAUNCH();
                     ChJobs J;
                     memset(&J, 0, sizeof(J));
@@ -1860,7 +1869,7 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
                     if (!ok.empty()) {
                         APMF_CHECK_HIP(hipMemcpyAsync(e.lp_sel, sel_h, ok.size() * sizeof(int), hipMemcpyHostToDevice, st));
                         for (int k = 0; k + 1 < R.nbk; k++)
-                            hipLaunchKernelGGL(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), (int)ok.size()), dim3(256), 0, st, R2,
+                            APMF_LAUNCH(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), (int)ok.size()), dim3(256), 0, st, R2,
                                                e.lp_sel, k);
                         APMF_CHECK_LAUNCH();
                         for (int y : ok) prev[y] = 1e300;        // the rate of the old shift says nothing about the new one
@@ -1877,7 +1886,7 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
             if (!keep.empty()) {
                 LpList K = list_of(keep);
                 for (int q = 0; q < K.n; q++) K.a[q] = npairs[keep[q]]++;
-                hipLaunchKernelGGL(lp_commit, dim3(g_mat.x, K.n), dim3(256), 0, st, R, L, K);
+                APMF_LAUNCH(lp_commit, dim3(g_mat.x, K.n), dim3(256), 0, st, R, L, K);
                 APMF_CHECK_LAUNCH();
             }
             todo.swap(keep);
@@ -1890,7 +1899,7 @@ int low_project(const Refs &R, const EigSet &e, hipStream_t st, const std::vecto
         if (!app.empty()) {
             LpList A = list_of(app);
             for (int q = 0; q < A.n; q++) A.a[q] = npairs[app[q]];
-            hipLaunchKernelGGL(lp_apply, dim3(g_mat.x, A.n), dim3(256), 0, st, R, L, A, min_eig);
+            APMF_LAUNCH(lp_apply, dim3(g_mat.x, A.n), dim3(256), 0, st, R, L, A, min_eig);
             APMF_CHECK_LAUNCH();
         }
         APMF_CHECK_HIP(hipStreamSynchronize(st));     // the next chunk reuses the buffers the host reads
@@ -1925,8 +1934,8 @@ int slow_S_pre(apmf_mn_batch *b, EigSet &e, void *handle, const std::vector<int>
     const int np = (int)w.proj.size();
     const int *dsel;
     APMF_TRY(upload_sel(b, e.slot0, w.proj, &dsel));
-    hipLaunchKernelGGL(kb_copy, g2(nn, np, 256), dim3(256), 0, st, R, dsel, (int)T_S_CAND, (int)T_S_W, nn);
-    if (!w.low) hipLaunchKernelGGL(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
+    APMF_LAUNCH(kb_copy, g2(nn, np, 256), dim3(256), 0, st, R, dsel, (int)T_S_CAND, (int)T_S_W, nn);
+    if (!w.low) APMF_LAUNCH(kb_ptrs, dim3((np + 63) / 64), dim3(64), 0, st, R, dsel, np, (int)T_S_W);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -1946,8 +1955,8 @@ rocblas_status slow_S_solve(const Refs &R, SlowS &w)
         if (hipMemcpyAsync(w.dsel, w.full.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess)      // (w.full is pageable: the copy is staged before the call returns anyway)
             return rocblas_status_internal_error;
-        hipLaunchKernelGGL(kb_copy, g2(nn, nf, 256), dim3(256), 0, st, R, w.dsel, (int)T_S_CAND, (int)T_S_W, nn);
-        hipLaunchKernelGGL(kb_ptrs, dim3((nf + 63) / 64), dim3(64), 0, st, R, w.dsel, nf, (int)T_S_W);
+        APMF_LAUNCH(kb_copy, g2(nn, nf, 256), dim3(256), 0, st, R, w.dsel, (int)T_S_CAND, (int)T_S_W, nn);
+        APMF_LAUNCH(kb_ptrs, dim3((nf + 63) / 64), dim3(64), 0, st, R, w.dsel, nf, (int)T_S_W);
         if (hipGetLastError() != hipSuccess) return rocblas_status_internal_error;
     } else {
         w.full = w.proj;
@@ -1973,7 +1982,7 @@ int slow_S_post(apmf_mn_batch *b, EigSet &e, const SlowS &w, rocblas_status rs, 
     b->st_proj_low += (long)(w.proj.size() - w.full.size());
     if (!w.full.empty()) {
         const int *dsel = b->sel_dev + (size_t)e.slot0 * R.H;      // uploaded by slow_S_pre / slow_S_solve
-        hipLaunchKernelGGL(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, (int)w.full.size()), dim3(256), 0, st, R, dsel,
+        APMF_LAUNCH(kb_rebuild, dim3(R.nbk * (R.nbk + 1) / 2, (int)w.full.size()), dim3(256), 0, st, R, dsel,
                            min_eig);
         APMF_CHECK_LAUNCH();
     }
@@ -1981,7 +1990,7 @@ int slow_S_post(apmf_mn_batch *b, EigSet &e, const SlowS &w, rocblas_status rs, 
         const int nr = (int)w.refac.size();
         const int *dsel;
         APMF_TRY(upload_sel(b, e.slot0 + 1, w.refac, &dsel));
-        hipLaunchKernelGGL(kb_copy, g2(nn, nr, 256), dim3(256), 0, st, R, dsel, tS, (int)T_S_F, nn);
+        APMF_LAUNCH(kb_copy, g2(nn, nr, 256), dim3(256), 0, st, R, dsel, tS, (int)T_S_F, nn);
         APMF_CHECK_LAUNCH();
         APMF_TRY(launch_factor(b, dsel, nr, 1, e.jobs));
     }
@@ -2104,7 +2113,7 @@ int launch_gradient(apmf_mn_batch *b, const std::vector<int> &grad, double sigma
         for (int h : slow) {
             double *S = b->tab_host[(size_t)T_S_CUR * R.H + h], *G = b->tab_host[(size_t)T_S_GRAD * R.H + h];
             APMF_TRY(apmf_dense_inv_logdet(b->ctx, S, R.N, G, nullptr));
-            hipLaunchKernelGGL(kb_entropy_scale, dim3((unsigned)(((size_t)R.N * R.N + 255) / 256)), dim3(256), 0, st, G,
+            APMF_LAUNCH(kb_entropy_scale, dim3((unsigned)(((size_t)R.N * R.N + 255) / 256)), dim3(256), 0, st, G,
                                R.N, half_mult);
         }
         APMF_CHECK_LAUNCH();
@@ -2114,21 +2123,21 @@ int launch_gradient(apmf_mn_batch *b, const std::vector<int> &grad, double sigma
         else APMF_TRY(upload_sel(b, 2, fast, &dfast));
         const int nf = (int)fast.size();
         for (int k = 0; k + 1 < R.nbk; k++)
-            hipLaunchKernelGGL(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), nf), dim3(256), 0, st, R, dfast, k);
-        hipLaunchKernelGGL(kb_lauum, dim3(R.nbk * (R.nbk + 1) / 2, nf), dim3(256), 0, st, R, dfast, half_mult);
+            APMF_LAUNCH(kb_trinv_step, dim3((R.nbk - k - 1) * (k + 1), nf), dim3(256), 0, st, R, dfast, k);
+        APMF_LAUNCH(kb_lauum, dim3(R.nbk * (R.nbk + 1) / 2, nf), dim3(256), 0, st, R, dfast, half_mult);
         APMF_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(kb_rowconst, dim3((R.N + 255) / 256, ng), dim3(256), 0, st, R, dgrad, (int)T_M_CUR,
+    APMF_LAUNCH(kb_rowconst, dim3((R.N + 255) / 256, ng), dim3(256), 0, st, R, dgrad, (int)T_M_CUR,
                        (int)T_S_CUR, (int)T_O_CUR);
     const double inv_sig = 1. / sigma_sq;
     const int dp = dp6_for(R.d);
     const int nbu = (R.n + 3) / 4, nbv = (R.m + 3) / 4;
-    DISPATCH_DP6(dp, hipLaunchKernelGGL((kb_kl_rows<DP>), dim3(nbu + nbv, ng), dim3(256), 0, st, R, dgrad, nbu,
+    DISPATCH_DP6(dp, APMF_LAUNCH((kb_kl_rows<DP>), dim3(nbu + nbv, ng), dim3(256), 0, st, R, dgrad, nbu,
                                         b->r->ptr[0], b->r->idx[0], b->r->val[0], b->r->ptr[1], b->r->idx[1],
                                         b->r->val[1], inv_sig));
-    hipLaunchKernelGGL(kb_finish_rows, dim3((R.N + 255) / 256, ng), dim3(256), 0, st, R, dgrad, inv_sig, sigma_u_sq,
+    APMF_LAUNCH(kb_finish_rows, dim3((R.N + 255) / 256, ng), dim3(256), 0, st, R, dgrad, inv_sig, sigma_u_sq,
                        sigma_v_sq);
-    hipLaunchKernelGGL(kb_omega, dim3(R.d * R.d, ng), dim3(256), 0, st, R, dgrad, inv_sig, sigma_u_sq, sigma_v_sq);
+    APMF_LAUNCH(kb_omega, dim3(R.d * R.d, ng), dim3(256), 0, st, R, dgrad, inv_sig, sigma_u_sq, sigma_v_sq);
     APMF_CHECK_LAUNCH();
     return APMF_OK;
 }
@@ -2287,14 +2296,22 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
 }
 
 int apmf_mn_batch_fit_stats(const apmf_mn_batch *b, int64_t *iterations, int64_t *trials, int64_t *proj_low,
-                            int64_t *proj_full, int64_t *cert_by_bound)
+                            int64_t *proj_full, int64_t *cert_by_bound, int64_t *gradients)
 {
     APMF_REQUIRE(b, "NULL batch");
+    if (gradients) *gradients = b->st_grads;
     if (cert_by_bound) *cert_by_bound = b->st_cert_skipped;
     if (iterations) *iterations = b->st_iters;
     if (trials) *trials = b->st_trials;
     if (proj_low) *proj_low = b->st_proj_low;
     if (proj_full) *proj_full = b->st_proj_full;
+    return APMF_OK;
+}
+
+int apmf_mn_batch_launch_count(int64_t *launches)
+{
+    APMF_REQUIRE(launches, "NULL operand");
+    *launches = (int64_t)g_k6_launches.load(std::memory_order_relaxed);
     return APMF_OK;
 }
 
@@ -2317,14 +2334,14 @@ int apmf_mn_batch_set_state(apmf_ctx *ctx, apmf_mn_batch *b, const double *d_mea
     hipStream_t st = b->ctx->stream;
     const int p = per_hypothesis;
     if (d_mean)
-        hipLaunchKernelGGL(kb_fill, g2(nd, R.H, 64), dim3(256), 0, st, R, (int)T_M_CUR, d_mean, (p & 1) ? nd : 0, nd);
+        APMF_LAUNCH(kb_fill, g2(nd, R.H, 64), dim3(256), 0, st, R, (int)T_M_CUR, d_mean, (p & 1) ? nd : 0, nd);
     if (d_cov_useritems) {
-        hipLaunchKernelGGL(kb_fill, g2(nn, R.H, 256), dim3(256), 0, st, R, (int)T_S_CUR, d_cov_useritems,
+        APMF_LAUNCH(kb_fill, g2(nn, R.H, 256), dim3(256), 0, st, R, (int)T_S_CUR, d_cov_useritems,
                            (p & 2) ? nn : 0, nn);
         std::fill(b->fvalid.begin(), b->fvalid.end(), 0);
     }
     if (d_cov_latents) {
-        hipLaunchKernelGGL(kb_fill, g2(dd, R.H, 4), dim3(256), 0, st, R, (int)T_O_CUR, d_cov_latents,
+        APMF_LAUNCH(kb_fill, g2(dd, R.H, 4), dim3(256), 0, st, R, (int)T_O_CUR, d_cov_latents,
                            (p & 4) ? dd : 0, dd);
         std::fill(b->oivalid.begin(), b->oivalid.end(), 0);
     }
@@ -2410,10 +2427,10 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         const int *dsel;
         const int ni = (int)init.size();
         APMF_TRY(upload_sel(b, 0, init, &dsel));
-        hipLaunchKernelGGL(kb_copy, g2((size_t)R.N * R.N, ni, 256), dim3(256), 0, st, R, dsel, (int)T_S_CUR,
+        APMF_LAUNCH(kb_copy, g2((size_t)R.N * R.N, ni, 256), dim3(256), 0, st, R, dsel, (int)T_S_CUR,
                            (int)T_S_F, (size_t)R.N * R.N);
         APMF_TRY(launch_factor(b, dsel, ni, 1));
-        hipLaunchKernelGGL(kb_small_spd, dim3(ni), dim3(64), small_smem(R.d), st, R, dsel, (int)T_O_CUR, (int)T_OI_CUR,
+        APMF_LAUNCH(kb_small_spd, dim3(ni), dim3(64), small_smem(R.d), st, R, dsel, (int)T_O_CUR, (int)T_OI_CUR,
                            0, min_eig);
         APMF_TRY(launch_value(b, dsel, ni, T_M_CUR, T_S_CUR, T_O_CUR, 1, 0, sigma_sq, sigma_u_sq));
         APMF_TRY(read_status(b));
@@ -2532,8 +2549,8 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             const int *dsel;
             APMF_TRY(upload_sel(b, 0, active, &dsel));
             const int nt32 = (R.N + 31) / 32;
-            hipLaunchKernelGGL(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig);
-            hipLaunchKernelGGL(kb_trial_small, dim3((unsigned)(((size_t)R.N * R.d + (size_t)R.d * R.d + 255) / 256), na),
+            APMF_LAUNCH(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig);
+            APMF_LAUNCH(kb_trial_small, dim3((unsigned)(((size_t)R.N * R.d + (size_t)R.d * R.d + 255) / 256), na),
                                dim3(256), 0, st, R, dsel, R.jobs, nt32 * (nt32 + 1) / 2, bound_eig);
             APMF_CHECK_LAUNCH();
             {
@@ -2542,7 +2559,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
                 J.list = R.jobs;
                 APMF_TRY(chol_lower_jobs(ctx, J, 2 * na, R.N));
             }
-            hipLaunchKernelGGL(kb_post, dim3(2 + (R.N + 63) / 64, na), dim3(64), small_smem(R.d), st, R, dsel,
+            APMF_LAUNCH(kb_post, dim3(2 + (R.N + 63) / 64, na), dim3(64), small_smem(R.d), st, R, dsel,
                                (int)T_M_CAND, (int)T_S_CAND, (int)T_O_CAND, (int)T_O_CAND, (int)T_OI_CAND, 1, min_eig);
             APMF_TRY(launch_value(b, dsel, na, T_M_CAND, T_S_CAND, T_O_CAND, 0, 0, sigma_sq, sigma_u_sq, false));
             APMF_TRY(read_status(b));
@@ -2721,13 +2738,13 @@ int apmf_mn_batch_score_grid(apmf_ctx *ctx, apmf_mn_batch *b, int h0, int B, int
     void *omega = (char *)diag + (size_t)B * R.N * isz;
     if (rc == APMF_OK) {
         if (use_f32) {
-            hipLaunchKernelGGL((kb_extract<float>), g2(per, B, 512), dim3(256), 0, ctx->stream, R, dsel, ld,
+            APMF_LAUNCH((kb_extract<float>), g2(per, B, 512), dim3(256), 0, ctx->stream, R, dsel, ld,
                                (float *)mean, (float *)cross, (float *)diag, (float *)omega);
             rc = apmf_mn_score_grid_f32(ctx, B, R.n, R.m, R.d, ld, (const float *)mean, (const float *)cross,
                                         (const float *)diag, (const float *)omega, d_mask, (float *)d_var,
                                         (float *)d_pmean, d_sum, want, (float *)d_best_val, d_best_idx);
         } else {
-            hipLaunchKernelGGL((kb_extract<double>), g2(per, B, 512), dim3(256), 0, ctx->stream, R, dsel, ld,
+            APMF_LAUNCH((kb_extract<double>), g2(per, B, 512), dim3(256), 0, ctx->stream, R, dsel, ld,
                                (double *)mean, (double *)cross, (double *)diag, (double *)omega);
             rc = apmf_mn_score_grid_f64(ctx, B, R.n, R.m, R.d, ld, (const double *)mean, (const double *)cross,
                                         (const double *)diag, (const double *)omega, d_mask, (double *)d_var,
@@ -2749,7 +2766,7 @@ int apmf_mn_batch_score_pool(apmf_ctx *ctx, apmf_mn_batch *b, int h, const int32
     if (P == 0) return APMF_OK;
     APMF_REQUIRE(d_pi && d_pj, "NULL operand");
     const int blocks = (int)(cdiv64(P, 256) < 2048 ? cdiv64(P, 256) : 2048);
-    hipLaunchKernelGGL(kb_pool, dim3(blocks), dim3(256), (size_t)R.d * R.d * sizeof(double), ctx->stream, R, h, d_pi,
+    APMF_LAUNCH(kb_pool, dim3(blocks), dim3(256), (size_t)R.d * R.d * sizeof(double), ctx->stream, R, h, d_pi,
                        d_pj, P, d_pmean, d_var);
     APMF_CHECK_LAUNCH();
     return APMF_OK;

@@ -52,6 +52,10 @@ def lookahead_budget_bytes():
     return int(float(os.environ.get('APMF_LOOKAHEAD_GB', '96')) * (1 << 30))
 
 
+# counters of the most recent batched lookahead (summed over its chunks): MNBatch.fit_stats() keys
+LAST_BATCH_STATS = {}
+
+
 class MNActivePMF(_ActiveBase):
     def __init__(self, rating_tuples, latent_d=1, rating_values=None,
                  discrete_expectations=False, refit_lookahead=False, knowable=None,
@@ -367,6 +371,7 @@ class MNActivePMF(_ActiveBase):
         ctx, rt = self._device_ratings()
         out = []
         batch = None
+        LAST_BATCH_STATS.clear()
         for lo in range(0, len(hyps), chunk):
             part = hyps[lo:lo + chunk]
             H = len(part)
@@ -403,6 +408,8 @@ class MNActivePMF(_ActiveBase):
                 batch.set_state(*base)
             batch.set_extra([h[0] for h in part], [h[1] for h in part], [h[2] for h in part])
             batch.fit(sig[0], sig[1], sig[2], self.min_eig, self.normal_learning_rate, None, max_steps=-1)
+            for k, v in batch.fit_stats().items():
+                LAST_BATCH_STATS[k] = LAST_BATCH_STATS.get(k, 0) + v
             if special == 'tv':
                 out.extend(batch.total_variance().tolist())
             elif special == 'ent':

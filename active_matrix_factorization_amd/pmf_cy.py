@@ -51,6 +51,15 @@ class _PairsRecipe(object):
         self.n_rated = int(self.rated_mask.sum())
         self.n_unrated = int(self.cand_mask.sum())
 
+    def clone(self):
+        """Independent copy (the construction inputs are never modified and stay shared)."""
+        c = _PairsRecipe.__new__(_PairsRecipe)
+        c.pairs0, c.knowable = self.pairs0, self.knowable
+        c.adds = [set(a) for a in self.adds]
+        c.rated_mask, c.cand_mask = self.rated_mask.copy(), self.cand_mask.copy()
+        c.n_rated, c.n_unrated = self.n_rated, self.n_unrated
+        return c
+
     def build(self, n, m):
         rated = set(map(tuple, self.pairs0))
         if self.knowable is None:
@@ -195,9 +204,17 @@ class ProbabilisticMatrixFactorization(object):
         return res
 
     def __deepcopy__(self, memodict):
-        res = type(self)(self.ratings.copy())
-        res.__setstate__(deepcopy(self.__getstate__(), memodict))
+        rec = self._recipe_clone()
+        res = type(self)(self.ratings.copy(), **({} if rec is None else {'knowable': rec}))
+        res.__setstate__(deepcopy(self.__getstate__(_pairs=rec is None), memodict))
         return res
+
+    def _recipe_clone(self):
+        """A model built by from_dense() whose rated / unrated sets nobody has asked for yet is copied
+        WITHOUT building them (10^6 tuples at 943 x 1682, per lookahead hypothesis): the copy gets its
+        own recipe and masks."""
+        rec = self.__dict__.get('_pairs_recipe')
+        return rec.clone() if rec is not None else None
 
     def __setstate__(self, state):
         if state is None:
@@ -210,13 +227,18 @@ class ProbabilisticMatrixFactorization(object):
             else:
                 setattr(self, k, v)
 
-    def __getstate__(self):
-        return {k: getattr(self, k) for k in _PUBLIC_STATE}
+    def __getstate__(self, _pairs=True):
+        # _pairs=False (deep copies of a model whose sets are still a recipe): everything but the sets
+        return {k: getattr(self, k) for k in _PUBLIC_STATE if _pairs or k not in ('rated', 'unrated')}
+
+    # the storage behind the rated / unrated properties: state carries only 'rated' / 'unrated', like
+    # the reference's (pmf_cy.pyx:90-126)
+    _private_attrs = frozenset(('_dev', '_rated_set', '_unrated_set', '_pairs_recipe'))
 
     def _extra_dict(self):
         """What a Python subclass of the reference's cdef class keeps in its __dict__."""
         return {k: v for k, v in self.__dict__.items()
-                if k not in self._base_attrs and k != '_dev'}
+                if k not in self._base_attrs and k not in self._private_attrs}
 
     # ------------------------------------------------------------------ device plumbing
     def _device(self):

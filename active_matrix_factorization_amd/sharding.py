@@ -12,9 +12,12 @@ What shards, and what is exchanged:
     results are all-gathered (bench.py's weak-scaling step).
   * PMF fit (K1): rank g owns a block of user rows and a block of item rows.  It computes
     grad_u for its users and grad_v for its items (each from the full ratings container,
-    no reduction needed), updates its blocks of the trial point ON THE DEVICE, and the trial
-    U, V are all-gathered device to device; the three sums of the log-likelihood are
-    all-reduced, so every rank takes the same accept / reject decision of fit_lls.
+    no reduction needed) and its blocks of the next trial point ON THE DEVICE.  ONE grouped
+    all-gather per trial carries, device to device, this rank's three partial sums of the trial's
+    log-likelihood together with its blocks of BOTH possible next trial points (the one that follows
+    an accepted trial and the one that follows a rejected one: the decision lags, as in the
+    single-GPU k_fit_iter); every rank adds the partial sums in rank order - the same bits, hence
+    the same accept / reject decision everywhere, no all-reduce - and keeps the branch that applies.
   * Gibbs (K3): a half-sweep is split by row block, then the freshly sampled side is
     all-gathered before the other side's half-sweep (which needs the NEW values).
 The functions here are engine-agnostic: `engine` is any object with the block methods of
@@ -27,6 +30,7 @@ its workers (active_pmf.py:739-770, bayes_pmf.py:385-422).
 import os
 import socket
 import struct
+import sys
 import time
 
 import numpy as np
@@ -67,8 +71,13 @@ def _recv_exact(sock, count):
     return bytes(buf)
 
 
-def _recv_msg(sock):
+_MAX_MSG = 1 << 34       # 16 GiB: far above any block this path exchanges, far below a garbage length
+
+
+def _recv_msg(sock, limit=_MAX_MSG):
     (count,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    if count > limit:
+        raise ConnectionError('message length %d exceeds the limit %d' % (count, limit))
     return _recv_exact(sock, count)
 
 
@@ -137,33 +146,38 @@ class Comm(object):
                 conn, _ = srv.accept()
                 conn.settimeout(timeout)
                 try:
-                    msg = _recv_msg(conn)
+                    msg = _recv_msg(conn, limit=4096)         # anybody can connect to this port
                     if not msg.startswith(hello + b':'):
                         conn.close()
                         continue
                     r = int(msg[len(hello) + 1:])
+                    if not (1 <= r < self.world) or r in peers:
+                        conn.close()                          # not a rank of this run, or a duplicate
+                        continue
                     _send_msg(conn, hello)
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     peers[r] = conn
-                except (OSError, ValueError):
+                except (OSError, ValueError, ConnectionError, struct.error):
                     conn.close()
             self._peers = [peers[r] for r in range(1, self.world)]
         else:
             deadline = time.time() + timeout
             while True:
                 for p in range(port, port + span):
+                    s = None
                     try:
                         s = socket.create_connection((addr, p), timeout=2.)
                         s.settimeout(5.)
                         _send_msg(s, hello + b':%d' % self.rank)
-                        if _recv_msg(s) == hello:
+                        if _recv_msg(s, limit=4096) == hello:
                             s.settimeout(timeout)
                             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                             self._root = s
                             return
                         s.close()
                     except (OSError, ConnectionError, struct.error):
-                        pass
+                        if s is not None:
+                            s.close()
                 if time.time() > deadline:
                     raise TimeoutError('rank %d: no rank 0 on %s:[%d, %d)' % (self.rank, addr, port, port + span))
                 time.sleep(.05)
@@ -235,6 +249,39 @@ class Comm(object):
         parts = self.allgather_bytes(block.tobytes())
         return np.frombuffer(b''.join(parts), block.dtype).reshape((self.world,) + block.shape).copy()
 
+    def all_gather_multi(self, blocks):
+        """Several equal-sized-per-rank blocks exchanged as ONE step: a list of (world,) + block.shape arrays.
+        DeviceArrays go through one RCCL group (a single launch on the context's stream); NumPy arrays - and
+        DeviceArrays in a rehearsal without RCCL - through one message of the socket transport."""
+        blocks = list(blocks)
+        if not blocks:
+            return []
+        if isinstance(blocks[0], _lib.DeviceArray):
+            outs = [self.ctx.empty((self.world,) + b.shape, b.dtype) for b in blocks]
+            if self._nccl is not None:
+                import ctypes as C
+                k = len(blocks)
+                send = (C.c_void_p * k)(*[b.ptr for b in blocks])
+                recv = (C.c_void_p * k)(*[o.ptr for o in outs])
+                size = (C.c_size_t * k)(*[b.nbytes for b in blocks])
+                _lib._check(self._libc.apmf_comm_allgather_multi(self.ctx._h, self._nccl, k, send, recv, size))
+            elif self.world == 1:
+                for o, b in zip(outs, blocks):
+                    self.ctx.copy(o, b, b.nbytes)
+            else:
+                for o, h in zip(outs, self.all_gather_multi([b.to_host() for b in blocks])):
+                    o.upload(h)
+            return outs
+        blocks = [np.ascontiguousarray(b) for b in blocks]
+        if self.world == 1:
+            return [b[None].copy() for b in blocks]
+        parts = self.allgather_bytes(b''.join(b.tobytes() for b in blocks))
+        outs, off = [], 0
+        for b in blocks:
+            outs.append(np.stack([np.frombuffer(p, b.dtype, b.size, off).reshape(b.shape) for p in parts]))
+            off += b.nbytes
+        return outs
+
     def all_gather_rows(self, block, n):
         """Row blocks (block_range layout, each padded to block_size rows) of an (n, ...) array ->
         the array on every rank: NumPy (n, ...) / DeviceArray (world * block_size, ...)."""
@@ -282,7 +329,26 @@ def comm_from_env(ctx=None, port_offset=1):
     addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(os.environ.get('MASTER_PORT', '29500')) + port_offset
     tag = os.environ.get('TORCHELASTIC_RUN_ID', '') + ':' + os.environ.get('MASTER_PORT', '')
-    return Comm(rank, world, addr, port, ctx=ctx, tag=tag)
+    t0 = time.time()
+    try:
+        comm = Comm(rank, world, addr, port, ctx=ctx, tag=tag)
+    except Exception as e:
+        sys.stderr.write('[apmf comm] rank %d/%d device %s: communicator set-up FAILED after %.1f s (%s:%d+): %s\n'
+                         % (rank, world, getattr(ctx, 'device', None), time.time() - t0, addr, port, e))
+        sys.stderr.flush()
+        raise
+    # one line per rank, so that a first multi-GPU run that goes wrong can be read from the launcher's tail
+    version = None
+    if comm.has_rccl:
+        import ctypes as C
+        v = C.c_int(0)
+        if comm._libc.apmf_comm_version(C.byref(v)) == 0:
+            version = v.value
+    sys.stderr.write('[apmf comm] rank %d/%d device %s: %s up in %.2f s (rendezvous %s:%d+, RCCL version %s)\n'
+                     % (rank, world, getattr(ctx, 'device', None), 'RCCL communicator' if comm.has_rccl else
+                        'socket transport', time.time() - t0, addr, port, version))
+    sys.stderr.flush()
+    return comm
 
 
 # ---------------------------------------------------------------------------- the product's engine
@@ -311,14 +377,15 @@ class HipEngine(object):
         return arr.to_host()[:n]
 
     # -- K1
-    def grad_rows(self, side, lo, hi, U, V):
-        """Rows [lo, hi) of grad_u (side 0) / grad_v (side 1) in a full-size device array."""
+    def grad_rows(self, side, lo, hi, U, V, slot=0):
+        """Rows [lo, hi) of grad_u (side 0) / grad_v (side 1) in a full-size device array; two slots,
+        so that the gradient at the current point and the speculative one at the trial point coexist."""
         ctx, d = self.ctx, self.d
         sig, su, sv, sub, mr = self.hyper
         rows = self.n if side == 0 else self.m
-        g = self._grad.get(side)
+        g = self._grad.get((side, slot))
         if g is None:
-            g = self._grad[side] = ctx.empty((rows, d))
+            g = self._grad[(side, slot)] = ctx.empty((rows, d))
         ctx.pmf_gradient_rows(self.rt, side, lo, hi, U, V, d, sig, su, sv, sub, mr, g)
         return g
 
@@ -333,6 +400,22 @@ class HipEngine(object):
     def ll_terms(self, U, V, u_lo, u_hi, v_lo, v_hi):
         _, _, _, sub, mr = self.hyper
         return self.ctx.pmf_ll_terms(self.rt, U, V, self.d, sub, mr, u_lo, u_hi, v_lo, v_hi)
+
+    def ll_partial(self, U, V, u_lo, u_hi, v_lo, v_hi):
+        """This rank's three partial sums of the log-likelihood as a 4-double DEVICE record (no host
+        synchronisation): it travels inside the trial's collective."""
+        _, _, _, sub, mr = self.hyper
+        rec = self.ctx.zeros(4)
+        self.ctx.pmf_ll_terms_dev(self.rt, U, V, self.d, sub, mr, u_lo, u_hi, v_lo, v_hi, rec)
+        return rec
+
+    def small_to_host(self, arr):
+        return arr.to_host()
+
+    def as_rows(self, gathered):
+        """(world, bs, d) gathered blocks -> the (world * bs, d) array they are, without a copy."""
+        gathered.shape = (gathered.shape[0] * gathered.shape[1],) + tuple(gathered.shape[2:])
+        return gathered
 
     # -- K3
     def gibbs_rows(self, side, lo, hi, oth, alpha, mu, beta, mean_sub, z, bs):
@@ -363,7 +446,92 @@ class HipEngine(object):
         return float(dsum.to_host()[0]), float(bv.to_host()[0]), int(bi.to_host()[0])
 
 
+    # -- K2 with this rank's rows of the state resident on the device (ShardedGrid)
+    def hold_grid(self, rows_2d, dtype=np.float64):
+        """(rows, m) host block -> resident zero-padded device grid (rows, ld)"""
+        rows_2d = np.asarray(rows_2d)
+        if rows_2d.shape[0] == 0:
+            return None
+        return self.ctx.upload_grid(rows_2d.astype(dtype, copy=False), dtype)
+
+    def hold(self, host):
+        return self.ctx.array(np.ascontiguousarray(host, np.float64))
+
+    def score_resident(self, cross, mask, mean_u_rows, mean_items, diag_u_rows, diag_items, omega, m, want):
+        """The sweep of this rank's resident rows: everything stays on the device; returns the device record
+        [sum f64, best value f64, best local flat index i64 (-1: none), 0]."""
+        ctx, d = self.ctx, self.d
+        rec = ctx.zeros(4)
+        if cross is None:
+            ctx.write_bytes(rec, 16, np.array([-1], np.int64))
+            return rec
+        nl, ld = cross.shape
+        mean = ctx.empty((nl + m, d))
+        diag = ctx.empty(nl + m)
+        ctx.copy(mean, mean_u_rows, nl * d * 8)
+        ctx.copy(mean, mean_items, m * d * 8, dst_off=nl * d * 8)
+        ctx.copy(diag, diag_u_rows, nl * 8)
+        ctx.copy(diag, diag_items, m * 8, dst_off=nl * 8)
+        ctx.mn_score_grid(np.float64, 1, nl, m, d, ld, mean, cross, diag, omega, mask=mask, dsum=rec.ptr, want=want,
+                          best_val=rec.ptr + 8, best_idx=rec.ptr + 16)
+        return rec
+
+
 # ---------------------------------------------------------------------------- K2
+class ShardedGrid(object):
+    """One posterior state's candidate grid, user rows sharded, RESIDENT where it is consumed (SURVEY.md
+    8(e) rows 1 and 4): rank g keeps its rows of the Sigma cross block (and of the candidate mask) in the
+    engine's memory for the life of the object - the (n+m)^2 covariance never moves - and a selection step
+    exchanges only what the other ranks cannot know: the item factors and the item entries of diag(Sigma),
+    which are sharded by ITEM block (each rank owns and updates its block), in one grouped all-gather;
+    cov_latents (d x d) is replicated.  After the sweep one (sum, value, flat index) record per rank is
+    all-gathered and merged with the single-device tie rule."""
+
+    def __init__(self, engine, comm, n, m, cross_rows, mask_rows=None):
+        self.engine, self.comm, self.n, self.m = engine, comm, n, m
+        self.lo, self.hi = block_range(n, comm.rank, comm.world)
+        self.v_lo, self.v_hi = block_range(m, comm.rank, comm.world)
+        nl = self.hi - self.lo
+        if cross_rows.shape[0] != nl:
+            raise ValueError('cross_rows must be this rank\'s %d rows' % nl)
+        self.cross = engine.hold_grid(cross_rows)
+        self.mask = None if mask_rows is None else engine.hold_grid(np.asarray(mask_rows).astype(np.uint8), np.uint8)
+
+    def select(self, mean_u_rows, mean_v_block, diag_u_rows, diag_v_block, omega, want=1):
+        """mean_u_rows (nl, d), diag_u_rows (nl,): this rank's user rows; mean_v_block / diag_v_block: its ITEM
+        block (block_range(m) rows, host arrays).  -> (total, best value, (i, j)), identical on every rank."""
+        eng, comm, n, m = self.engine, self.comm, self.n, self.m
+        bs_v = block_size(m, comm.world)
+        d = np.asarray(omega).shape[0]
+        vb = np.zeros((bs_v, d))
+        vb[:self.v_hi - self.v_lo] = mean_v_block
+        db = np.zeros(bs_v)
+        db[:self.v_hi - self.v_lo] = diag_v_block
+        gv, gd = comm.all_gather_multi([eng.hold(vb), eng.hold(db)])          # the step's one exchange
+        rec = eng.score_resident(self.cross, self.mask, eng.hold(mean_u_rows), eng.as_rows(gv), eng.hold(diag_u_rows),
+                                 eng.as_rows(gd), eng.hold(omega), m, want)
+        (recs,) = comm.all_gather_multi([rec])
+        return _merge_select(eng.small_to_host(recs), self.lo_of_rank(), m, want)
+
+    def lo_of_rank(self):
+        return [block_range(self.n, r, self.comm.world)[0] for r in range(self.comm.world)]
+
+
+def _merge_select(rows, los, m, want):
+    rows = np.ascontiguousarray(rows, np.float64).reshape(len(los), -1)
+    idx = np.ascontiguousarray(rows[:, 2]).view(np.int64)      # the index travels as its 8 bytes
+    total = float(sum(float(r[0]) for r in rows))
+    best_val, best_idx = 0., -1
+    for v, i, lo in zip(rows[:, 1], idx, los):      # rank order = ascending row blocks; ties -> lowest flat index
+        i = int(i)
+        if i < 0:
+            continue
+        i = (i // m + lo) * m + i % m
+        if best_idx < 0 or (v > best_val if want > 0 else v < best_val) or (v == best_val and i < best_idx):
+            best_val, best_idx = float(v), i
+    return total, best_val, (best_idx // m, best_idx % m) if best_idx >= 0 else None
+
+
 def sharded_select(engine, comm, n, m, mean, cross, diag, omega, mask=None, want=1):
     """Arg-extremum and total of Var[U_i.V_j] over the (masked) n x m grid, user rows sharded.
     cross / mask may be the full (n, m) arrays or just this rank's row block.
@@ -386,11 +554,20 @@ def sharded_select(engine, comm, n, m, mean, cross, diag, omega, mask=None, want
 
 
 # ---------------------------------------------------------------------------- K1
+def _ll_from_partials(parts, sigma_sq, sigma_u_sq, sigma_v_sq):
+    """log-likelihood from the (world, >= 3) per-rank partial sums, added in RANK ORDER: every rank computes
+    the same bits, so every rank takes the same accept / reject decision without an all-reduce."""
+    t = np.zeros(3)
+    for row in np.asarray(parts, np.float64).reshape(len(parts), -1):
+        t += row[:3]
+    return -t[0] / (2. * sigma_sq) - t[1] / (2. * sigma_u_sq) - t[2] / (2. * sigma_v_sq)
+
+
 def _ll(engine, comm, U, V, n, m, sigma_sq, sigma_u_sq, sigma_v_sq):
     u_lo, u_hi = block_range(n, comm.rank, comm.world)
     v_lo, v_hi = block_range(m, comm.rank, comm.world)
-    t = comm.all_reduce_sum(engine.ll_terms(U, V, u_lo, u_hi, v_lo, v_hi))
-    return -t[0] / (2. * sigma_sq) - t[1] / (2. * sigma_u_sq) - t[2] / (2. * sigma_v_sq)
+    (parts,) = comm.all_gather_multi([engine.ll_partial(U, V, u_lo, u_hi, v_lo, v_hi)])
+    return _ll_from_partials(engine.small_to_host(parts), sigma_sq, sigma_u_sq, sigma_v_sq)
 
 
 def sharded_log_likelihood(engine, comm, U, V, n, m, sigma_sq, sigma_u_sq, sigma_v_sq):
@@ -400,38 +577,54 @@ def sharded_log_likelihood(engine, comm, U, V, n, m, sigma_sq, sigma_u_sq, sigma
 
 def sharded_fit_lls(engine, comm, U, V, n, m, sigma_sq=1., sigma_u_sq=10., sigma_v_sq=10.,
                     learning_rate=1e-4, min_learning_rate=1e-10, stop_thresh=1e-2, max_steps=-1):
-    """fit_lls (pmf_cy.pyx:257-291) with users and items row-sharded over the ranks.  Every
-    rank runs the same control flow on the same all-reduced LL; the factors live in the engine's
-    arrays (device-resident for HipEngine) for the whole fit and each trial's exchange is two
-    all-gathers of row blocks plus one 3-element all-reduce.  Returns (U, V, ll_trace)."""
+    """fit_lls (pmf_cy.pyx:257-291) with users and items row-sharded over the ranks, ONE collective per
+    trial.  A trial point X is evaluated by every rank on its own rows: the three partial sums of LL(X) and -
+    speculatively, as the single-GPU k_fit_iter does - the gradient at X.  Whether X is accepted is only known
+    once all partial sums are in, so each rank forms its blocks of BOTH possible next trial points,
+        A = X + 1.25 lr g(X)        (X accepted)            R = cur + 0.5 lr g(cur)       (X rejected),
+    and a single grouped all-gather carries [partials | A_u | A_v | R_u | R_v]; every rank then adds the partials
+    in rank order, decides, and continues with the gathered A or R.  The factors stay in the engine's arrays
+    (device-resident for HipEngine) for the whole fit.  Returns (U, V, ll_trace)."""
     world = comm.world
     u_lo, u_hi = block_range(n, comm.rank, world)
     v_lo, v_hi = block_range(m, comm.rank, world)
     bs_u, bs_v = block_size(n, world), block_size(m, world)
-    ll = lambda A, B: _ll(engine, comm, A, B, n, m, sigma_sq, sigma_u_sq, sigma_v_sq)
-    hU, hV = engine.put(U, bs_u * world), engine.put(V, bs_v * world)
-    lr, old_ll, trace, converged = learning_rate, ll(hU, hV), [], False
-    while not converged and (max_steps < 0 or len(trace) < max_steps):
-        gU = engine.grad_rows(0, u_lo, u_hi, hU, hV)
-        gV = engine.grad_rows(1, v_lo, v_hi, hU, hV)
-        while True:
-            # each rank updates its own blocks of the trial point; the exchange step
-            nU = comm.all_gather_rows(engine.trial_block(hU, gU, u_lo, u_hi, lr, bs_u), n)
-            nV = comm.all_gather_rows(engine.trial_block(hV, gV, v_lo, v_hi, lr, bs_v), m)
-            new_ll = ll(nU, nV)
-            if new_ll > old_ll:
-                hU, hV = nU, nV
-                lr *= 1.25
-                if new_ll - old_ll < stop_thresh:
-                    converged = True
-                trace.append(new_ll)
-                old_ll = new_ll
+    sig = (sigma_sq, sigma_u_sq, sigma_v_sq)
+
+    def grads(A, B, slot):
+        return (engine.grad_rows(0, u_lo, u_hi, A, B, slot), engine.grad_rows(1, v_lo, v_hi, A, B, slot))
+
+    def blocks(A, B, g, rate):
+        return [engine.trial_block(A, g[0], u_lo, u_hi, rate, bs_u), engine.trial_block(B, g[1], v_lo, v_hi, rate, bs_v)]
+
+    cU, cV = engine.put(U, bs_u * world), engine.put(V, bs_v * world)
+    lr, trace = learning_rate, []
+    g_cur = grads(cU, cV, 0)
+    # the starting LL and the first trial point (no decision pending yet): one exchange
+    got = comm.all_gather_multi([engine.ll_partial(cU, cV, u_lo, u_hi, v_lo, v_hi)] + blocks(cU, cV, g_cur, lr))
+    old_ll = _ll_from_partials(engine.small_to_host(got[0]), *sig)
+    xU, xV = engine.as_rows(got[1]), engine.as_rows(got[2])
+    slot = 1
+    while max_steps < 0 or len(trace) < max_steps:
+        part = engine.ll_partial(xU, xV, u_lo, u_hi, v_lo, v_hi)
+        g_x = grads(xU, xV, slot)
+        got = comm.all_gather_multi([part] + blocks(xU, xV, g_x, lr * 1.25) + blocks(cU, cV, g_cur, lr * .5))
+        new_ll = _ll_from_partials(engine.small_to_host(got[0]), *sig)
+        if new_ll > old_ll:
+            cU, cV, g_cur, slot = xU, xV, g_x, slot ^ 1
+            lr *= 1.25
+            trace.append(new_ll)
+            done = new_ll - old_ll < stop_thresh
+            old_ll = new_ll
+            if done:
                 break
+            xU, xV = engine.as_rows(got[1]), engine.as_rows(got[2])
+        else:
             lr *= .5
             if lr < min_learning_rate:
-                converged = True
                 break
-    return engine.get(hU, n), engine.get(hV, m), np.array(trace)
+            xU, xV = engine.as_rows(got[3]), engine.as_rows(got[4])
+    return engine.get(cU, n), engine.get(cV, m), np.array(trace)
 
 
 # ---------------------------------------------------------------------------- K3

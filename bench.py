@@ -84,6 +84,9 @@ def main():
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-class-level', action='store_true')
+    ap.add_argument('--no-f64', action='store_true', help='skip the float64 sweep legs (roofline_f64)')
+    ap.add_argument('--no-lookahead', action='store_true', help='skip the configs[3] batched-lookahead leg')
+    ap.add_argument('--lookahead-candidates', type=int, default=100, help='pool size of the lookahead leg (x 5 rating values)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -268,11 +271,20 @@ def main():
                            'algorithmic_GBs': gs_bytes * grad_steps_per_s / (1 if strong else world) / 1e9,
                            'workload': grad_note},
         }
+    if world == 1 and not args.no_f64:
+        # the product's precision on the same workload (every class computes in float64)
+        print('bench.py: float64 sweep legs ...', file=sys.stderr, flush=True)
+        out['roofline_f64'] = f64_sweeps(ctx, B, ld, d_mean, d_cross, d_diag, d_omega, d_mask, min(K, 200), min(W, 5))
+    d_cross = d_var = None
     if world == 1 and not args.no_class_level:
         print('bench.py: kernel regions done; class-level selection ...', file=sys.stderr, flush=True)
         cl = class_level(ctx, ratings, rs)
         if out is not None:
             out['class_level'] = cl
+    if world == 1 and not args.no_lookahead:
+        # the product's real hot loop: the batched one-step lookahead (K6) at configs[3]'s shape
+        print('bench.py: batched lookahead at configs[3] (about 15 s) ...', file=sys.stderr, flush=True)
+        out['lookahead'] = lookahead_leg(args.lookahead_candidates)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             print('bench.py: CPU baseline (about 30 s) ...', file=sys.stderr, flush=True)
@@ -281,6 +293,114 @@ def main():
     comm.barrier()
     comm.close()
     ctx.close()
+
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X float64 matrix peak (vendor figure; the guide lists none for f64)
+
+
+def f64_sweeps(ctx, B, ld, d_mean, d_cross, d_diag, d_omega, d_mask, K, W):
+    """The SAME 943x1682-d10-B256 workload through apmf_mn_score_grid_f64 - the sweep every class of the
+    package actually calls: (a) scores written + per-state sum + arg-max, 8 B read + 8 B written = 16 B per
+    candidate (what get_key_evals / pick_query_point run), (b) reduction only (per-state sum + arg-max, no grid
+    written: 8 B per candidate) - how the batched lookahead reduces its H hypothesis states (_total_variance).
+    HIP events around the kernel, in-library, on the launch stream."""
+    n, m, d = N_USERS, N_ITEMS, LATENT_D
+    m64, c64, g64, o64 = (ctx.cast(x, np.float64) for x in (d_mean, d_cross, d_diag, d_omega))
+    var = ctx.empty((B, n, ld), np.float64)
+    dsum, bv, bi = ctx.empty(B), ctx.empty(B), ctx.empty(B, np.int64)
+    out = {'workload': '943x1682-d10-B%d' % B, 'dtype': 'f64', 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
+    for name, v, bpc in (('written', var, 16.), ('reduce_only', None, 8.)):
+        def step():
+            ctx.mn_score_grid(np.float64, B, n, m, d, ld, m64, c64, g64, o64, mask=d_mask, var=v, dsum=dsum, want=1,
+                              best_val=bv, best_idx=bi)
+        for _ in range(W):
+            step()
+        ctx.sync()
+        ctx.profile_begin(min(K, 1024))
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ms = ctx.profile_end()
+        ms = ms[ms > 0]
+        avg = float(ms.mean()) if ms.size else None
+        algo = bpc * B * n * m
+        ach = algo / (avg * 1e-3) / 1e9 if avg else None
+        out[name] = {'achieved': ach, 'frac': ach / HBM_PEAK_GBS if ach else None, 'avg_kernel_ms': avg,
+                     'algorithmic_bytes_per_launch': algo, 'bytes_per_candidate': bpc, 'launches_timed': int(ms.size),
+                     'candidates_per_s': B * n * m * K / dt, 'ms_per_step': 1e3 * dt / K}
+    sums = dsum.to_host()
+    if not (np.isfinite(sums).all() and (sums > 0).all()):
+        sys.exit('bench.py: the float64 sweep produced invalid sums')
+    return out
+
+
+def lookahead_leg(n_cand):
+    """BASELINE.json configs[3]'s shape (94 x 425 rank 5, 500 known ratings, five rating values): the
+    'total-variance' lookahead criterion (mn_active_pmf.py:627-696) over a pool of `n_cand` unrated entries =
+    5 n_cand hypotheses, each a variational re-fit to convergence - one K6 batch (csrc/k6_batch.hip) - reduced by one
+    float64 sweep with B = H.  Reports hypotheses/s, kernel launches per hypothesis and the matrix-core rate:
+    float64 MFMA flops per second against the 78.6 TFLOP/s peak, from the instruction count of a committed
+    rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 pass of this same leg when one is on file (profiles/pmc_lookahead_latest.json),
+    and from the operation count of the factorisations otherwise."""
+    import io
+    import random
+    from contextlib import redirect_stdout
+    from active_matrix_factorization_amd import mn_active_pmf as mn, _lib
+    state = np.random.get_state(), random.getstate()
+    np.random.seed(0)
+    random.seed(0)
+    n, m, d, known = 94, 425, 5, 500
+    u, v = np.random.normal(0, 1, (n, d)), np.random.normal(0, 1, (m, d))
+    x = u @ v.T
+    real = np.clip(np.round(3 + x / x.std() * 1.2), 1, 5)
+    flat = np.random.choice(n * m, known, replace=False)
+    ratings = np.c_[flat // m, flat % m, real[flat // m, flat % m]].astype(float)
+    a = mn.MNActivePMF(ratings, latent_d=d, rating_values=range(1, 6), discrete_expectations=True)
+    key = mn.KEY_FUNCS['total-variance']
+    log = io.StringIO()
+    with redirect_stdout(log):
+        a.do_fit()
+        a.initialize_approx()
+        t0 = time.perf_counter()
+        a.fit_normal()
+        t_fit = time.perf_counter() - t0
+        pool = sorted(a.unrated)[:n_cand]
+        a._get_key_vals(pool[:1], key)                   # warm: code objects, workspaces
+        l0 = _lib.batch_launch_count()
+        t0 = time.perf_counter()
+        vals = a._get_key_vals(pool, key)
+        dt = time.perf_counter() - t0
+        launches = _lib.batch_launch_count() - l0
+    np.random.set_state(state[0])
+    random.setstate(state[1])
+    H = 5 * len(pool)
+    N = n + m
+    stats = dict(mn.LAST_BATCH_STATS) if getattr(mn, 'LAST_BATCH_STATS', None) else {}
+    out = {'workload': 'configs[3] shape 94x425-d5, %d known, pool %d x 5 rating values' % (known, len(pool)),
+           'hypotheses': H, 'seconds': dt, 'hypotheses_per_s': H / dt, 'launches': launches,
+           'launches_per_hypothesis': launches / float(H), 'fit_stats': stats,
+           'base_fit_normal_s': t_fit, 'argmin': [int(q) for q in pool[int(np.argmin(vals))]],
+           'full_grid_estimate_s': len(a.unrated) * 5 / (H / dt), 'dtype': 'f64',
+           'matrix_dim': N, 'bytes_per_hypothesis_state': 5 * N * N * 8}
+    # matrix-core work: two Cholesky factorisations per trial point (the second skipped when the eigenvalue bound
+    # certifies the trial) and one inverse-from-factor per gradient, N^3/3 multiply-adds each way (lower bound:
+    # the tile kernels also run the zero padding of 519 -> 576)
+    if stats:
+        fact = 2 * stats.get('trials', 0) - stats.get('cert_by_bound', 0)
+        flops = (fact + 2 * stats.get('gradients', 0)) * (2. * N ** 3 / 3.)
+        out['mfma_model'] = {'flops': flops, 'tflops': flops / dt / 1e12, 'frac_of_peak': flops / dt / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                             'peak_tflops': F64_MFMA_PEAK_TFLOPS, 'note': 'operation count of the factorisations / inverses'}
+    pmc = os.path.join(ROOT, 'profiles', 'pmc_lookahead_latest.json')
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            if rec.get('hypotheses') == H:
+                out['pmc'] = rec
+        except Exception:
+            pass
+    return out
 
 
 def class_level(ctx, ratings, rs):

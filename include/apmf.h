@@ -122,6 +122,11 @@ int apmf_pmf_gradient_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int r
 int apmf_pmf_ll_terms(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V, int d,
                       int subtract_mean, double mean_rating, int user_lo, int user_hi, int item_lo,
                       int item_hi, double *h_terms3);
+/* apmf_pmf_ll_terms with the three sums left ON THE DEVICE (d_terms3, three doubles) and no host
+ * synchronisation: the partial sums of a rank travel to the others inside the trial's collective. */
+int apmf_pmf_ll_terms_dev(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U, const double *d_V, int d,
+                          int subtract_mean, double mean_rating, int user_lo, int user_hi, int item_lo,
+                          int item_hi, double *d_terms3);
 /* log_likelihood(), pmf_cy.pyx:170-193 (h_ll) and the bare sum of squared errors that
  * update_sigma() needs, pmf_cy.pyx:225-234 (h_sq_error; either may be NULL). */
 int apmf_pmf_log_likelihood(apmf_ctx *ctx, const apmf_ratings *r, const double *d_U,
@@ -341,10 +346,15 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
 /* Counters of the last apmf_mn_batch_fit (each nullable): iterations of the search loop, trial points
  * evaluated, the project_psd calls (mn_active_pmf.py:42-67) that really clipped eigenvalues - how many
  * were finished through the few eigenpairs below min_eig, how many through the full eigendecomposition -
- * and the trial points whose "nothing to clip" was certified by an eigenvalue bound (Weyl, from the inverse
- * the gradient computes) without factoring the shifted matrix. */
+ * the trial points whose "nothing to clip" was certified by an eigenvalue bound (Weyl, from the inverse
+ * the gradient computes) without factoring the shifted matrix, and the gradients evaluated (one per accepted
+ * step plus the first). */
 int apmf_mn_batch_fit_stats(const apmf_mn_batch *b, int64_t *iterations, int64_t *trials, int64_t *proj_low,
-                            int64_t *proj_full, int64_t *cert_by_bound);
+                            int64_t *proj_full, int64_t *cert_by_bound, int64_t *gradients);
+/* Kernel launches the batch engine has enqueued so far in this process (all batches, all streams): the
+ * difference around a call is its launch count.  A hypothesis of the reference's lookahead
+ * (mn_active_pmf.py:660-668) is a chain of dependent launches here; launches per hypothesis is tracked. */
+int apmf_mn_batch_launch_count(int64_t *launches);
 /* kl_divergence() of every current point (mn_kl_divergence, matrix_normal_exps_cy.pyx:159-213). */
 int apmf_mn_batch_kl(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double sigma_u_sq,
                      double sigma_v_sq, double *h_kl);
@@ -406,6 +416,13 @@ int apmf_comm_rank(const apmf_comm *c, int *rank, int *world);
  * of the freshly sampled Gibbs side, of diag(Sigma); the per-rank (sum, value, index) records */
 int apmf_comm_allgather(apmf_ctx *ctx, apmf_comm *c, const void *d_send, void *d_recv,
                         size_t bytes_per_rank);
+/* `count` (<= 16) all-gathers enqueued as one RCCL group - one launch: d_recv[k] (world x bytes_per_rank[k]) <-
+ * every rank's d_send[k].  The exchange of one sharded fit_lls trial (pmf_cy.pyx:266-291 row-sharded): the
+ * U / V row blocks of both speculative next trial points and the three partial sums of the log-likelihood. */
+int apmf_comm_allgather_multi(apmf_ctx *ctx, apmf_comm *c, int count, const void *const *d_send,
+                              void *const *d_recv, const size_t *bytes_per_rank);
+/* RCCL's version code, for the diagnostic line a rank prints when its communicator comes up */
+int apmf_comm_version(int *version);
 /* element-wise sum over the ranks (the three sums of log_likelihood, pmf_cy.pyx:191-193) */
 int apmf_comm_allreduce_f64(apmf_ctx *ctx, apmf_comm *c, const double *d_send, double *d_recv,
                             size_t count);

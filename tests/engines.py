@@ -23,7 +23,7 @@ class OracleEngine(object):
     def get(self, arr, n):
         return np.array(arr[:n])
 
-    def grad_rows(self, side, lo, hi, U, V):
+    def grad_rows(self, side, lo, hi, U, V, slot=0):
         gU, gV = orc.pmf_gradient(self.ratings, U[:self.n], V[:self.m], **self.kw)
         return gU if side == 0 else gV
 
@@ -38,6 +38,32 @@ class OracleEngine(object):
         sel = r[(r[:, 0] >= u_lo) & (r[:, 0] < u_hi)]
         sq = orc.pmf_sq_error(sel, U, V, self.kw['subtract_mean'], self.kw['mean_rating']) if len(sel) else 0.
         return np.array([sq, (U[u_lo:u_hi] ** 2).sum(), (V[v_lo:v_hi] ** 2).sum()])
+
+    def ll_partial(self, U, V, u_lo, u_hi, v_lo, v_hi):
+        return np.concatenate([self.ll_terms(U, V, u_lo, u_hi, v_lo, v_hi), [0.]])
+
+    def small_to_host(self, arr):
+        return np.asarray(arr)
+
+    def as_rows(self, gathered):
+        return gathered.reshape((gathered.shape[0] * gathered.shape[1],) + gathered.shape[2:])
+
+    def hold_grid(self, rows_2d, dtype=np.float64):
+        rows_2d = np.asarray(rows_2d)
+        return None if rows_2d.shape[0] == 0 else rows_2d.astype(dtype)
+
+    def hold(self, host):
+        return np.array(host, np.float64)
+
+    def score_resident(self, cross, mask, mean_u_rows, mean_items, diag_u_rows, diag_items, omega, m, want):
+        rec = np.zeros(4)
+        idx = rec[2:3].view(np.int64)
+        idx[0] = -1
+        if cross is not None:
+            tot, bv, bi = self.score_rows(mean_u_rows, mean_items[:m], cross, diag_u_rows, diag_items[:m], omega,
+                                          mask, want)
+            rec[0], rec[1], idx[0] = tot, bv, bi
+        return rec
 
     def gibbs_rows(self, side, lo, hi, oth, alpha, mu, beta, mean_sub, z, bs):
         rows = self.n if side == 0 else self.m

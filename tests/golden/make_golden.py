@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a', 'r3b': sections V, W (round 3)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -157,6 +157,12 @@ def main():
         return
     if args.only == 'r2n':
         round2n(np, active_pmf, save, seed, _print)
+        return
+    if args.only == 'r3a':
+        round3a(np, active_pmf, save, seed, _print)
+        return
+    if args.only == 'r3b':
+        round3b(np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -798,6 +804,176 @@ def round2n(np, active_pmf, save, seed, _print):
     save('trace_c1_full_lookahead', real=real, ratings=ratings, seed=49, n_rated=np.array([s[0] for s in steps]),
          rmse=np.array([s[1] for s in steps], dtype=np.float64), pick=np.array(steps[1][2]),
          vals=np.array(steps[1][3], dtype=np.float64))
+
+
+def _hyp_trace_full(args):
+    """One hypothesis of the full-covariance lookahead, as calculate_fn runs it (active_pmf.py:660-668):
+    deepcopy + add_rating + fit_normal_kls to convergence; the KL after every accepted step, the first accepted
+    steps' states and the total variance at the end.  Module level so that a process pool can map it."""
+    from copy import deepcopy
+    import numpy as np
+    a, i, j, v, keep, cut = args
+    b = deepcopy(a)
+    b.add_rating(i, j, v)
+    kl0 = b.kl_divergence()
+    kls, states, tv_cut = [], [], None
+    for kl in b.fit_normal_kls():
+        kls.append(kl)
+        if len(kls) <= keep:
+            states.append(np.concatenate([b.mean, b.cov.reshape(-1)]))
+        if len(kls) == cut:
+            tv_cut = b._total_variance()
+    tv = b._total_variance()
+    return kl0, np.array(kls), np.array(states), tv, tv if tv_cut is None else tv_cut
+
+
+def round3a(np, active_pmf, save, seed, _print):
+    """V. Section U step by step.  What compare(['total-variance'], do_threading=False) does under seed 49 up to
+    its first pick (active_pmf.py:1012-1090, 795-832), with the intermediate quantities written down: the
+    approximation full_test() starts from (its second initialize_approx), its KL, its first gradient, the KL after
+    every accepted fit_normal_kls step and the state every 10 steps; then, for every one of the 450 hypotheses of
+    the selection step, the number of accepted steps, the final KL and the total variance - and for fifteen of them
+    (three candidates x five rating values) the whole KL trace and the first three accepted states."""
+    import multiprocessing as mp
+    from copy import deepcopy
+    g = np.load(os.path.join(HERE, 'trace_c1_mn.npz'))
+    u = np.load(os.path.join(HERE, 'trace_c1_full_lookahead.npz'))
+    real, ratings = g['real'], g['ratings']
+    t0 = time.perf_counter()
+    seed(49)
+    A = active_pmf.ActivePMF
+    apmf = A(ratings.copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5), discrete_expectations=True)
+    apmf.sig_u_mean, apmf.sig_u_var, apmf.sig_v_mean, apmf.sig_v_var = 0, -1, 0, -1
+    apmf.do_fit()
+    apmf.initialize_approx()
+    apmf.fit_normal()
+    _init = deepcopy(apmf)                 # results['_initial_apmf']
+    b = deepcopy(apmf)                     # the copy full_test() works on
+    b.do_fit()
+    out = dict(users=b.users.copy(), items=b.items.copy(), ratings=ratings)
+    rng_state = np.random.get_state()
+    b.initialize_approx()
+    np.random.set_state(rng_state)
+    out['init_draw'] = np.random.normal(0, 2, (b.approx_dim, b.approx_dim))      # what initialize_approx projected
+    out['init_mean'], out['init_cov'] = b.mean.copy(), b.cov.copy()
+    out['init_kl'] = b.kl_divergence()
+    gm, gc = active_pmf.normal_gradient(b)
+    out['init_grad_mean'], out['init_grad_cov'] = np.array(gm), np.array(gc)
+    kls, snaps = [], []
+    for kl in b.fit_normal_kls():
+        kls.append(kl)
+        if len(kls) <= 3 or len(kls) % 10 == 0:
+            snaps.append(np.concatenate([[len(kls)], b.mean, b.cov.reshape(-1)]))
+    out['base_kls'], out['base_snaps'] = np.array(kls), np.array(snaps)
+    out['base_mean'], out['base_cov'] = b.mean.copy(), b.cov.copy()
+    out['base_total_variance'] = b._total_variance()
+    out['base_rmse'] = b.rmse(real)
+    assert abs(out['base_rmse'] - u['rmse'][0]) < 1e-12, (out['base_rmse'], u['rmse'][0])
+    _print('full-cov base fit: %d steps, KL %r, %.0f s' % (len(kls), kls[-1], time.perf_counter() - t0))
+    pool = list(b.unrated)                 # the order full_test() evaluates in; section U's values are in it
+    vals = b.rating_values
+    ref_grid = np.asarray(u['vals'], float)
+    pick = tuple(int(x) for x in u['pick'])
+    assert ref_grid.shape == (len(pool),) and pool[int(np.argmin(ref_grid))] == pick
+    order = np.argsort(ref_grid)
+    traced = [pick, pool[int(order[3])], pool[int(order[-1])]]      # the reference's pick, its 4th best, its worst
+    cut = 40          # accepted steps after which every hypothesis is ALSO evaluated (see below)
+    jobs = [(b, i, j, float(v), 3 if (i, j) in traced else 0, cut) for i, j in pool for v in vals]
+    with mp.Pool(7) as workers:
+        got = workers.map(_hyp_trace_full, jobs, chunksize=1)
+    H = len(jobs)
+    out['hyp_ijv'] = np.array([(i, j, v) for _, i, j, v, _, _ in jobs])
+    out['hyp_kl0'] = np.array([r[0] for r in got])
+    out['hyp_steps'] = np.array([len(r[1]) for r in got])
+    out['hyp_final_kl'] = np.array([r[1][-1] if len(r[1]) else np.nan for r in got])
+    out['hyp_tv'] = np.array([r[3] for r in got])
+    out['traced'] = np.array(traced)
+    for (i, j) in traced:
+        for v in vals:
+            k = jobs.index((b, i, j, float(v), 3, cut))
+            out['trace_%d_%d_%d' % (i, j, int(v))] = got[k][1]
+            out['states_%d_%d_%d' % (i, j, int(v))] = got[k][2]
+    # the criterion values recomputed from these hypotheses must be the grid section U recorded
+    import math
+    from scipy import stats
+    est = np.full(len(pool), np.nan)
+    tv = out['hyp_tv'].reshape(len(pool), len(vals))
+    for k, (i, j) in enumerate(pool):
+        mean = np.dot(b.users[i, :], b.items[j, :])
+        cdfs = stats.norm.cdf(b.rating_bounds, loc=mean, scale=math.sqrt(b.sigma_sq))
+        est[k] = (tv[k] * np.diff(cdfs)).sum()
+    out['pool'], out['vals'] = np.array(pool), est
+    # The same selection with every hypothesis stopped after `cut` accepted steps (or at its convergence, if
+    # earlier): up to there the searches have not yet amplified rounding differences, so values AND pick are
+    # determined - what an implementation with different summation orders can be held to exactly.
+    head = np.full((H, 60), np.nan)
+    for k, r in enumerate(got):
+        head[k, :min(60, len(r[1]))] = r[1][:60]
+    out['cut'], out['hyp_kl_head'], out['hyp_tv_cut'] = cut, head, np.array([r[4] for r in got])
+    est_cut = np.full(len(pool), np.nan)
+    tvc = out['hyp_tv_cut'].reshape(len(pool), len(vals))
+    for k, (i, j) in enumerate(pool):
+        mean = np.dot(b.users[i, :], b.items[j, :])
+        cdfs = stats.norm.cdf(b.rating_bounds, loc=mean, scale=math.sqrt(b.sigma_sq))
+        est_cut[k] = (tvc[k] * np.diff(cdfs)).sum()
+    out['vals_cut'], out['pick_cut'] = est_cut, np.array(pool[int(np.argmin(est_cut))])
+    srt = np.sort(est_cut)
+    _print('cut at %d steps: pick %s, margin to the runner-up %.3g (relative %.3g)' % (
+        cut, pool[int(np.argmin(est_cut))], srt[1] - srt[0], (srt[1] - srt[0]) / srt[0]))
+    dev = np.abs(est - ref_grid).max()
+    _print('full-cov hypotheses: %d, recomputed grid vs section U: max |diff| %.3g, %.0f s' % (H, dev, time.perf_counter() - t0))
+    assert dev == 0, dev
+    save('trace_c1_full_lookahead_steps', **out)
+
+
+def _hyp_trunc_mn(args):
+    """One matrix-normal hypothesis (mn_active_pmf.py:660-668) stopped after `steps` accepted fit_normal_kls
+    steps: the KL trace and the total variance there."""
+    import itertools
+    from copy import deepcopy
+    import numpy as np
+    a, i, j, v, steps = args
+    b = deepcopy(a)
+    b.add_rating(i, j, v)
+    kls = np.array(list(itertools.islice(b.fit_normal_kls(), steps)))
+    return kls, b._total_variance()
+
+
+def round3b(np, mn_active_pmf, save, seed, _print):
+    """W. configs[3] (DrugBank 94 x 425 rank 5): the RANKING of a realistic pool under the lookahead criterion.
+    24 unrated entries x 2 rating values from the converged approximation of section G, every hypothesis
+    (deepcopy + add_rating + fit_normal_kls, mn_active_pmf.py:660-668) advanced by exactly 100 accepted steps -
+    where the search has not yet amplified rounding differences - then _total_variance and the expectation over the
+    rating values exactly as _exp_with_rij forms it (:676-681): 48 KL traces, 48 totals, 24 criterion values."""
+    import math
+    import multiprocessing as mp
+    from scipy import stats
+    g = np.load(os.path.join(HERE, 'mn_c4_94x425_d5.npz'))
+    t = np.load(os.path.join(HERE, 'lookahead_c4_pool.npz'))
+    MN = mn_active_pmf.MNActivePMF
+    a = MN(g['ratings'].copy(), latent_d=5, rating_values=(0., 1.), discrete_expectations=True)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    a.mean, a.cov_useritems, a.cov_latents = g['mean_fit'].copy(), g['cov_useritems_fit'].copy(), g['cov_latents_fit'].copy()
+    unrated = sorted(a.unrated)
+    idx = sorted(set([11, 12, 20011] + [int(x) for x in np.linspace(100, len(unrated) - 100, 21)]))
+    pool = [unrated[k] for k in idx]
+    assert [tuple(int(x) for x in r) for r in t['pool']] == [unrated[11], unrated[12], unrated[20011]]
+    steps = 100
+    t0 = time.perf_counter()
+    jobs = [(a, i, j, v, steps) for i, j in pool for v in a.rating_values]
+    with mp.Pool(7) as workers:
+        got = workers.map(_hyp_trunc_mn, jobs, chunksize=1)
+    _print('c4 truncated pool: %d hypotheses x %d steps, %.0f s' % (len(jobs), steps, time.perf_counter() - t0))
+    assert all(len(r[0]) == steps for r in got)
+    tv = np.array([r[1] for r in got]).reshape(len(pool), 2)
+    est = []
+    for (i, j), evals in zip(pool, tv):
+        mean = np.dot(a.users[i, :], a.items[j, :])
+        cdfs = stats.norm.cdf(a.rating_bounds, loc=mean, scale=math.sqrt(a.sigma_sq))
+        est.append((evals * np.diff(cdfs)).sum())
+    save('lookahead_c4_pool_ranked', pool=np.array(pool), steps=steps, kls=np.array([r[0] for r in got]),
+         tv=tv, vals=np.array(est), order=np.argsort(est, kind='stable'))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -17,8 +17,8 @@ def problem(seed=0, n=23, m=31, d=5, N=260):
     return rs, ratings, U, V, n, m, d
 
 
-def check_all(make_engine, comm, tol=1e-10):
-    rs, ratings, U, V, n, m, d = problem()
+def check_all(make_engine, comm, tol=1e-10, dims=None):
+    rs, ratings, U, V, n, m, d = problem(**(dims or {}))
     eng = make_engine(ratings, n, m, d)
     # --- K1: sharded fit == single-process fit
     U1, V1, tr1 = orc.pmf_fit_lls(ratings, U, V, max_steps=12)
@@ -56,15 +56,31 @@ def check_all(make_engine, comm, tol=1e-10):
         assert abs(tot - pvar[mask].sum()) <= 1e-11 * abs(pvar[mask].sum())
         assert abs(pvar[ij] - cand.ravel()[k]) <= 1e-12 * abs(cand.ravel()[k])
         assert ij == (k // m, k % m)
+    # the same selection with this rank's rows RESIDENT and only the item-side blocks exchanged (ShardedGrid):
+    # the state changes between steps (here: twice), the cross block and the mask stay where they are
+    lo, hi = sh.block_range(n, comm.rank, comm.world)
+    v_lo, v_hi = sh.block_range(m, comm.rank, comm.world)
+    grid = sh.ShardedGrid(eng, comm, n, m, R[:n, n:][lo:hi], mask[lo:hi])
+    diag = np.diag(R).copy()
+    for scale in (1., .5):
+        mean_s = mean * scale
+        _, pv_s = orc.mn_pred_means_vars(n, m, mean_s, R, Om)
+        for want in (1, -1):
+            tot, bv, ij = grid.select(mean_s[lo:hi], mean_s[n + v_lo:n + v_hi], diag[lo:hi], diag[n + v_lo:n + v_hi],
+                                      Om, want)
+            cand = np.where(mask, pv_s, -np.inf if want > 0 else np.inf)
+            k = int(np.argmax(cand)) if want > 0 else int(np.argmin(cand))
+            assert abs(tot - pv_s[mask].sum()) <= 1e-11 * abs(pv_s[mask].sum())
+            assert ij == (k // m, k % m) and abs(bv - cand.ravel()[k]) <= 1e-12 * abs(cand.ravel()[k])
     # exact ties across the shard boundary resolve to the lowest flat index
     mean_t = np.tile(mean[:1], (n + m, 1))
     R_t = np.eye(n + m)
     tot, bv, ij = sh.sharded_select(eng, comm, n, m, mean_t, R_t[:n, n:], np.diag(R_t).copy(), Om, None, 1)
     assert ij == (0, 0)
     m2 = np.zeros((n, m), bool)
-    m2[n - 1, 3] = m2[n - 2, 7] = True          # both in the last block
+    m2[n - 1, 3] = m2[n - 2, m - 1] = True      # both near the end of the grid
     tot, bv, ij = sh.sharded_select(eng, comm, n, m, mean_t, R_t[:n, n:], np.diag(R_t).copy(), Om, m2, 1)
-    assert ij == (n - 2, 7)
+    assert ij == (n - 2, m - 1)
     # block layout
     los = [sh.block_range(n, r, comm.world) for r in range(comm.world)]
     assert los[0][0] == 0 and los[-1][1] == n and all(a[1] == b[0] for a, b in zip(los, los[1:]))

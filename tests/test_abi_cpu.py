@@ -131,6 +131,94 @@ def test_cli_refuses_arbitrary_pickles(tmp_path):
     with pytest.raises(pickle.UnpicklingError):
         _cli._load_data(str(bad))
     assert not (tmp_path / 'pwned').exists()
+    # a protocol-4 pickle can name 'os.getcwd' THROUGH one of the package's own modules (dotted
+    # names are resolved attribute by attribute), or a function of such a module instead of a class
+    import io
+    import pickletools
+    for module, name in (('active_matrix_factorization_amd._active_base', 'os.getcwd'),
+                         ('active_matrix_factorization_amd.pmf_cy', 'np.load'),
+                         ('active_matrix_factorization_amd.bayes_pmf', 'os.system'),
+                         ('active_matrix_factorization_amd.pmf_cy', 'fake_ratings'),
+                         ('pmf_cy', 'deepcopy'), ('os', 'getcwd')):
+        payload = (b'\x80\x04' + b'\x8c' + bytes([len(module)]) + module.encode() +
+                   b'\x8c' + bytes([len(name)]) + name.encode() + b'\x93' + b')R.')      # STACK_GLOBAL, (), REDUCE
+        pickletools.dis(payload, out=io.StringIO())       # well-formed
+        with pytest.raises(pickle.UnpicklingError):
+            _cli.restricted_load(io.BytesIO(payload))
+    # the classes themselves load, under the package's name and under the reference's bare module name
+    for module in ('active_matrix_factorization_amd.mn_active_pmf', 'mn_active_pmf'):
+        payload = (b'\x80\x04' + b'\x8c' + bytes([len(module)]) + module.encode() + b'\x8c\x0bMNActivePMF\x93.')
+        cls = _cli.restricted_load(io.BytesIO(payload))
+        assert cls.__module__ == 'active_matrix_factorization_amd.mn_active_pmf' and cls.__name__ == 'MNActivePMF'
     npz = tmp_path / 'data.npz'
     np.savez(npz, _real=np.eye(2), _ratings=np.zeros((1, 3)))
     assert set(_cli._load_data(str(npz))) == {'_real', '_ratings'}
+
+
+def test_lazy_pairs_state_and_deepcopy():
+    """the storage behind the rated / unrated properties ('_rated_set', '_unrated_set',
+    '_pairs_recipe') is not model state - a pickle carries 'rated' / 'unrated' only, like the reference's
+    (pmf_cy.pyx:90-126) - and a deep copy of a model whose sets are still a recipe (from_dense) does not build
+    the 10^6-tuple sets: it gets its own recipe and masks."""
+    import copy
+    import pickle
+    import numpy as np
+    from active_matrix_factorization_amd import pmf_cy, mn_active_pmf, bayes_pmf
+    rs = np.random.RandomState(3)
+    n, m = 7, 9
+    known = rs.rand(n, m) < .4
+    known[np.arange(n), np.arange(n)] = True
+    known[n - 1, m - 1] = True
+    real = rs.randint(1, 6, (n, m)).astype(float)
+    ii, jj = known.nonzero()
+    ratings = np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+    for cls, kw in ((pmf_cy.ProbabilisticMatrixFactorization, {}), (mn_active_pmf.MNActivePMF, {}),
+                    (bayes_pmf.BayesianPMF, {})):
+        eager = cls(ratings.copy(), latent_d=2, **kw)
+        lazy = cls(ratings.copy(), latent_d=2, knowable=pmf_cy._PairsRecipe(ratings[:, :2].copy(), None, n, m), **kw)
+        free = sorted(eager.unrated)[:2]
+        lazy.add_rating(free[0][0], free[0][1], 3.)
+        eager.add_rating(free[0][0], free[0][1], 3.)
+        dup = copy.deepcopy(lazy)
+        assert lazy.__dict__['_pairs_recipe'] is not None and dup.__dict__['_pairs_recipe'] is not None
+        assert dup.__dict__['_pairs_recipe'] is not lazy.__dict__['_pairs_recipe']
+        dup.add_rating(free[1][0], free[1][1], 4.)            # the copy's masks are its own
+        assert lazy._n_rated() == eager._n_rated() == dup._n_rated() - 1
+        assert lazy.__dict__['_pairs_recipe'] is not None
+        with pytest.raises(ValueError):
+            dup.add_rating(free[1][0], free[1][1], 4.)
+        state = lazy.__getstate__()
+        flat = dict(state)
+        flat.update(flat.pop('__dict__', {}))
+        assert not {'_rated_set', '_unrated_set', '_pairs_recipe', '_dev'} & set(flat)
+        assert state['rated'] == eager.rated and state['unrated'] == eager.unrated
+        assert list(state['unrated']) == list(eager.unrated)        # same construction sequence: same iteration order
+        back = pickle.loads(pickle.dumps(lazy))
+        assert back.rated == eager.rated and back.unrated == eager.unrated
+        assert dup.rated == eager.rated | {free[1]}
+
+
+def test_late_torch_guard_lets_probes_through():
+    """once libapmf_dense.so is loaded, `import torch` must fail with an explanation (the SONAME clash
+    would crash the process) - but importlib.util.find_spec('torch'), the usual availability probe, must not."""
+    import subprocess
+    import sys
+    code = (
+        "import importlib.util, sys\n"
+        "from active_matrix_factorization_amd import _lib\n"
+        "_lib.load_dense()\n"
+        "assert 'torch' not in sys.modules\n"
+        "spec = importlib.util.find_spec('torch')\n"
+        "assert spec is not None and spec.name == 'torch'\n"
+        "assert importlib.util.find_spec('no_such_module_xyz') is None\n"
+        "try:\n"
+        "    import torch\n"
+        "except ImportError as e:\n"
+        "    assert 'libapmf_dense' in str(e), e\n"
+        "else:\n"
+        "    raise SystemExit('late import torch was not refused')\n"
+        "assert 'torch' not in sys.modules\n"
+        "print('ok')\n")
+    out = subprocess.run([sys.executable, '-c', code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == 'ok', out.stderr[-2000:]

@@ -378,13 +378,14 @@ def test_config1_full_lookahead_selection_step(pkg):
     """One selection step of the full-covariance loop under the LOOKAHEAD criterion 'total-variance'
     (active_pmf.py:560-640 under compare(): 90 unrated entries x 5 rating values, each a deepcopy + add_rating +
     fit_normal of the 40 x 40 approximation to convergence) on config 1 under seed 49, against the REAL
-    reference's evaluation grid.  Statistical agreement, not a reproduced pick: each of the 450 hypotheses is a
-    chaotic search that stops on the first accepted step improving the KL by less than its threshold (DESIGN.md
-    section 2), started from an initial approximation that agrees with the reference's to 1e-4 - the 90 values
-    scatter around the reference's by a few per cent with no bias, and the best ten of them lie within a few per
-    cent of each other, so the arg-min is not determined at that level: the entry picked here must be among the
-    reference's best few.  (The same step of the matrix-normal class, whose searches are far better conditioned,
-    reproduces the reference's picks exactly: test_config1_lookahead_selection_step.)"""
+    reference's evaluation grid, END TO END: parity of the converged values is UNPINNED here, and
+    test_config1_full_lookahead_pinned (below) shows why and what is pinned instead - the initial approximation,
+    the base fit and the first 40 accepted steps of all 450 hypotheses agree with the reference's own recorded
+    quantities to rounding and select the reference's entry exactly; past accepted step 46 ... 98 the searches
+    amplify last-place differences and stop at different steps.  What this test keeps is the statistical check
+    of the values at convergence: the 90 values scatter around the reference's by a few per cent with no bias,
+    the best ten lie within a few per cent of each other, and the entry picked here must be among the
+    reference's best few."""
     g = load_golden('trace_c1_full_lookahead')
     seed(int(g['seed']))
     res = pkg.full.compare(['total-variance'], latent_d=2, do_threading=False, steps=2, discrete_exp=True,
@@ -400,6 +401,95 @@ def test_config1_full_lookahead_selection_step(pkg):
         (np.median(np.abs(rel)), np.abs(rel).max(), rel.mean())
     # (the grid of this class is a list over the pool, in the pool's order - the same order on both sides)
     assert ref[ok][int(np.argmin(got[ok]))] <= 1.05 * ref[ok].min()      # by the reference's own values, a near-optimal query
+
+
+def test_config1_full_lookahead_pinned(pkg):
+    """The selection step of test_config1_full_lookahead_selection_step taken apart, against the REAL reference's own
+    intermediate quantities (make_golden.py section V; active_pmf.py:189-200, 250-288, 635-704): where the device
+    path agrees with the reference to rounding, and from which step on the two searches are different searches.
+
+      1. initialize_approx: the projection of the seeded draw - 1e-14 of the matrix scale (NOT the 1e-4 the
+         end-to-end trace test allows), KL there to 1e-12, its gradient to 1e-9 (the inverse of a matrix whose
+         lower half of the spectrum sits at min_eig = 1e-5).
+      2. the base fit_normal from there: the reference's 42 accepted steps, KL trace to 1e-8, state to 1e-7.
+      3. all 450 hypotheses started from the REFERENCE's base state: identical KL at the start (1e-13), KL traces
+         equal to 1e-7 over the first 40 accepted steps, and with every hypothesis evaluated there the 90 criterion
+         values agree to 1e-7 and the SELECTED ENTRY IS THE REFERENCE'S (arg-min exact, as are the ten best in
+         order).
+      4. run to their own convergence, the traces of the fifteen hypotheses the fixture holds in full part from the
+         reference's beyond 1e-9 between accepted step 40 and 110 (measured: 46 ... 98) - the learning-rate search
+         runs at the edge of stability (x1.25 per accepted step until a trial fails), where a difference in the last
+         place grows by about 1.4x per step - and only after that do accept / reject decisions and the stopping step
+         (an accepted step that improves the KL by < 0.005) differ: 396 of 450 hypotheses still stop at the reference's
+         step and 348 reproduce its total variance to 1e-6; the others stop elsewhere on a trajectory that is no
+         longer the reference's.  This is what the statistical band of the end-to-end test stands for: beyond the
+         cut the arg-min is parity-UNPINNED by construction, up to it it is exact."""
+    g = load_golden('trace_c1_full_lookahead_steps')
+    A = pkg.full.ActivePMF
+    a = A(g['ratings'].copy(), latent_d=2, rating_values=(1, 2, 3, 4, 5), discrete_expectations=True)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    # 1
+    cov0 = pkg.full.project_psd(g['init_draw'], min_eig=a.min_eig)
+    assert np.abs(cov0 - g['init_cov']).max() <= 1e-13 * np.abs(g['init_cov']).max()
+    a.mean, a.cov = g['init_mean'].copy(), g['init_cov'].copy()
+    np.testing.assert_allclose(a.kl_divergence(), float(g['init_kl']), rtol=1e-12)
+    gm, gc = pkg.full.normal_gradient(a)
+    np.testing.assert_allclose(gm, g['init_grad_mean'], rtol=1e-12, atol=1e-13)
+    assert np.abs(gc - g['init_grad_cov']).max() <= 1e-9 * np.abs(g['init_grad_cov']).max()
+    # 2
+    a.cov = cov0
+    kls = list(a.fit_normal_kls())
+    assert len(kls) == len(g['base_kls']) == 42
+    np.testing.assert_allclose(kls, g['base_kls'], rtol=1e-8)
+    np.testing.assert_allclose(a.cov, g['base_cov'], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(a.mean, g['base_mean'], rtol=0, atol=1e-7)
+    # 3 + 4
+    a.mean, a.cov = g['base_mean'].copy(), g['base_cov'].copy()
+    cut = int(g['cut'])
+    ijv = g['hyp_ijv']
+    H = len(ijv)
+    steps, tv, tv_cut, kl0 = np.zeros(H, int), np.zeros(H), np.zeros(H), np.zeros(H)
+    traced = {tuple(int(x) for x in t) for t in g['traced']}
+    parts = []
+    for k, (i, j, v) in enumerate(ijv):
+        i, j = int(i), int(j)
+        b = copy.deepcopy(a)
+        b.add_rating(i, j, float(v))
+        kl0[k] = b.kl_divergence()
+        trace, cut_tv = [], None
+        for kl in b.fit_normal_kls():
+            trace.append(kl)
+            if len(trace) == cut:
+                cut_tv = b._total_variance()
+        steps[k], tv[k] = len(trace), b._total_variance()
+        tv_cut[k] = tv[k] if cut_tv is None else cut_tv
+        head = g['hyp_kl_head'][k]
+        nh = min(cut, len(trace), int(np.isfinite(head).sum()))
+        np.testing.assert_allclose(trace[:nh], head[:nh], rtol=1e-7, err_msg=str((i, j, v)))
+        if (i, j) in traced:
+            ref = g['trace_%d_%d_%d' % (i, j, int(v))]
+            nn = min(len(ref), len(trace))
+            rel = np.abs(np.array(trace[:nn]) - ref[:nn]) / np.abs(ref[:nn])
+            bad = np.nonzero(rel > 1e-9)[0]
+            parts.append((int(bad[0]) if bad.size else None, len(trace), len(ref)))
+    np.testing.assert_allclose(kl0, g['hyp_kl0'], rtol=1e-13)
+    np.testing.assert_allclose(tv_cut, g['hyp_tv_cut'], rtol=1e-7)
+    from scipy import stats
+    pool = [tuple(int(x) for x in ij) for ij in g['pool']]
+    est = np.empty(len(pool))
+    for k, (i, j) in enumerate(pool):
+        cdfs = stats.norm.cdf(a.rating_bounds, loc=np.dot(a.users[i], a.items[j]), scale=np.sqrt(a.sigma_sq))
+        est[k] = (tv_cut.reshape(len(pool), -1)[k] * np.diff(cdfs)).sum()
+    np.testing.assert_allclose(est, g['vals_cut'], rtol=1e-7)
+    assert pool[int(np.argmin(est))] == tuple(int(x) for x in g['pick_cut'])           # selected entry: exact
+    assert np.array_equal(np.argsort(est, kind='stable')[:10], np.argsort(g['vals_cut'], kind='stable')[:10])
+    # 4: where the full searches part, and that nothing parts earlier
+    for first, n_here, n_ref in parts:
+        assert first is None or 40 <= first <= 110, parts
+        assert first is not None or n_here == n_ref, parts            # never parted: same stopping step
+    same = int((steps == g['hyp_steps']).sum())
+    close = int((np.abs(tv / g['hyp_tv'] - 1) < 1e-6).sum())
+    assert same >= 360 and close >= 315, (same, close)               # measured 396 / 348 of 450
 
 
 def test_mn_lookahead_total_variance(pkg):

@@ -796,6 +796,23 @@ def test_config5_shard_scale(ctx):
     assert ok, out
 
 
+def test_config5_full_scale(ctx):
+    """BASELINE.json configs[4] at its FULL size on one MI355X - 100 000 x 20 000, rank 64, 5e7 observed ratings,
+    2e9 candidates: the whole 8-GPU configuration fits a single 288 GB device (ratings CSR x 2 1.2 GB, one f32
+    cross block 8 GB in + 8 GB out).  Same size-independent properties as the shard-sized case above
+    (tools/c5_scale.py): sampled gradient rows and the log-likelihood against NumPy, sampled grid rows against the
+    float64 closed form, fused sum / arg-max against the written grid, an increasing fit_lls trace."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'c5_scale.py')
+    spec = importlib.util.spec_from_file_location('c5_scale', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out, ok = mod.run(n=100000, m=20000, d=64, N=50000000, ctx=ctx)
+    assert ok, out
+    assert out['k2_candidates_per_s'] > 1e11 and out['k1_grad_steps_per_s'] > 10, out      # seconds, not minutes
+
+
 @pytest.mark.parametrize('shape', [(4, 3, 1, 5), (6, 5, 3, 12), (9, 14, 5, 40), (7, 6, 8, 20), (5, 4, 17, 9)])
 def test_full_kl_gradient_vs_numpy(ctx, shape):
     """K5-full (apmf_full_kl_gradient) against the NumPy restatement of normal_exps_cy.pyx:217-303

@@ -30,6 +30,11 @@ def test_hip_engine_single_rank_rccl():
     assert g.shape == (1, 3, 4) and np.array_equal(g.to_host()[0], a.to_host())
     r = comm.all_reduce_sum(ctx.array(np.array([1.5, -2., 7.])))
     assert np.array_equal(r.to_host(), [1.5, -2., 7.])
+    # the grouped exchange of a fit_lls trial (apmf_comm_allgather_multi: one RCCL group, one launch)
+    b3 = [ctx.array(np.arange(6.).reshape(2, 3)), ctx.array(np.array([7., 8., 9., 10.])), ctx.array(np.zeros((0, 3)))]
+    g3 = comm.all_gather_multi(b3)
+    assert [x.shape for x in g3] == [(1, 2, 3), (1, 4), (1, 0, 3)]
+    assert np.array_equal(g3[0].to_host()[0], np.arange(6.).reshape(2, 3)) and np.array_equal(g3[1].to_host()[0], [7., 8., 9., 10.])
     comm.barrier()
     sharding_cases.check_all(_make_engine_factory(ctx), comm)
     comm.close()

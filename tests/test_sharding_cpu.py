@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, dims=None):
     try:
         from active_matrix_factorization_amd import sharding as sh
         from engines import OracleEngine
@@ -35,7 +35,12 @@ def _worker(rank, world, port, q):
         rows = comm.all_gather_rows(np.full((sh.block_range(7, rank, world)[1] - sh.block_range(7, rank, world)[0], 2),
                                             float(rank)), 7)
         assert rows.shape == (7, 2) and rows[0, 0] == 0. and rows[-1, 0] == (7 - 1) // sh.block_size(7, world)
-        sharding_cases.check_all(lambda r, n, m, d: OracleEngine(r, n, m, d), comm)
+        sharding_cases.check_all(lambda r, n, m, d: OracleEngine(r, n, m, d), comm, dims=dims)
+        # the grouped exchange of a fit_lls trial: several blocks, one message
+        a, b = np.full((2, 3), float(rank)), np.arange(4.) + 10 * rank
+        ga, gb = comm.all_gather_multi([a, b])
+        assert ga.shape == (world, 2, 3) and gb.shape == (world, 4)
+        assert all((ga[r] == r).all() and gb[r][0] == 10 * r for r in range(world))
         comm.barrier()
         comm.close()
         assert 'torch' not in sys.modules       # the multi-process path needs no PyTorch
@@ -57,6 +62,69 @@ def test_sharded_path_sockets(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(msg == 'ok' for _, msg in res), '\n'.join(str(x) for x in res)
+
+
+def _run_world(world, dims=None, timeout=400):
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, dims)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(msg == 'ok' for _, msg in res), '\n'.join(str(x) for x in res)
+
+
+def test_sharded_path_world8():
+    """The driver's scaling run is 8 ranks: every sharded algorithm at world 8 over the socket transport
+    (23 users / 31 items: blocks of 3 and 4 rows, the last ones short)."""
+    _run_world(8)
+
+
+def test_sharded_path_fewer_rows_than_ranks():
+    """n < world and m < world: most ranks own an EMPTY row block of one side or both (zero-sized blocks in
+    every exchange, empty sweeps, partial sums of zero)."""
+    _run_world(8, dims=dict(n=5, m=6, d=3, N=40))
+
+
+def test_rendezvous_rejects_strangers():
+    """Rank 0's accept loop: a connection that does not speak the handshake, announces a rank outside
+    1..world-1 or a rank that is already connected is dropped, and the run still comes up."""
+    import multiprocessing as mp
+    import struct
+    import threading
+    import time
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(0, 2, port, q))]
+    procs[0].start()
+
+    def send(payload):
+        for _ in range(200):
+            try:
+                s = socket.create_connection(('127.0.0.1', port), timeout=1.)
+                s.sendall(payload)
+                time.sleep(.1)
+                s.close()
+                return
+            except OSError:
+                time.sleep(.05)
+    hello = b'APMFCOMM1t'
+    send(b'\xff' * 8)                                                   # a garbage length
+    send(struct.pack('<Q', 5) + b'hello')                               # not the handshake
+    for bad in (b':0', b':2', b':-1', b':x'):
+        msg = hello + bad
+        send(struct.pack('<Q', len(msg)) + msg)                         # rank out of range / not a number
+    procs.append(ctx.Process(target=_worker, args=(1, 2, port, q)))
+    procs[1].start()
     res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(30)
