@@ -54,6 +54,7 @@ _SIGS = {
     'apmf_d2d': (_i, [_vp, _vp, _vp, _sz]),
     'apmf_h2d_2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     'apmf_d2h_2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    'apmf_d2d_2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     'apmf_axpy_f64': (_i, [_vp, _vp, _vp, _dbl, _vp, _sz]),
     'apmf_cast_f64_f32': (_i, [_vp, _vp, _vp, _sz]),
     'apmf_cast_f32_f64': (_i, [_vp, _vp, _vp, _sz]),
@@ -70,6 +71,8 @@ _SIGS = {
     'apmf_pmf_fit_lls': (_i, [_vp, _vp, _vp, _vp, _i, _dbl, _dbl, _dbl, _i, _dbl, C.POINTER(_dbl),
                               C.POINTER(_dbl), _dbl, _dbl, _i64, _vp, _i64, C.POINTER(_i64),
                               C.POINTER(_i)]),
+    'apmf_pmf_batch_fit_lls': (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _i, _vp, _dbl, _dbl,
+                                    _dbl, _i64, _vp, _vp, _vp]),
     'apmf_pmf_minibatch_epoch': (_i, [_vp, _vp, _i64, _i, _i, _i64, _dbl, _dbl, _vp, _vp, _vp, _vp,
                                       _i, _dbl, _dbl, _dbl, _i, _dbl]),
     'apmf_pmf_predicted_matrix': (_i, [_vp, _vp, _vp, _i, _i, _i, _dbl, _vp, _i]),
@@ -647,6 +650,23 @@ class Context(object):
                                           trace.ctypes.data, max_trace, C.byref(steps), C.byref(conv)))
         res = (trace[:min(steps.value, max_trace)].copy(), steps.value, lr_io.value, bool(conv.value))
         return res + (ll_io.value,) if return_ll else res
+
+    def pmf_batch_fit_lls(self, rt, dU, dV, d, H, ei, ej, ev, sig, sig_u, sig_v, subtract_mean, mean_ratings, lr,
+                          min_lr, stop_thresh, max_steps=-1):
+        """H fit_lls searches over the shared container `rt`, hypothesis h with the extra rating (ei[h], ej[h],
+        ev[h]); dU (H, n, d) / dV (H, m, d) updated in place.  -> (final LL (H), accepted steps (H), converged (H))"""
+        ei = np.ascontiguousarray(ei, np.int32)
+        ej = np.ascontiguousarray(ej, np.int32)
+        ev = np.ascontiguousarray(ev, np.float64)
+        if not (ei.size == ej.size == ev.size == H):
+            raise ValueError('one extra rating per hypothesis expected')
+        mr = None if mean_ratings is None else np.ascontiguousarray(mean_ratings, np.float64)
+        ll, steps, conv = np.empty(H), np.zeros(H, np.int64), np.zeros(H, np.int32)
+        _check(self._lib.apmf_pmf_batch_fit_lls(self._h, rt._h, d, H, ei.ctypes.data, ej.ctypes.data, ev.ctypes.data,
+                                                _ptr(dU), _ptr(dV), sig, sig_u, sig_v, int(bool(subtract_mean)),
+                                                None if mr is None else mr.ctypes.data, lr, min_lr, stop_thresh,
+                                                max_steps, ll.ctypes.data, steps.ctypes.data, conv.ctypes.data))
+        return ll, steps, conv.astype(bool)
 
     def pmf_minibatch_epoch(self, shuffled, n, m, batch_size, lr, momentum, dU, dV, duinc, dvinc, d,
                             sig, sig_u, sig_v, subtract_mean, mean_rating):

@@ -67,6 +67,7 @@ struct apmf_ratings {
     int max_len;       // longest row of either side
     int has_empty[2];  // some row on that side has no rating
     void *block;       // single allocation backing everything above
+    void *h_desc;      // host copy of desc (malloc): the batched re-fits derive per-hypothesis row orders from it
 };
 
 void apmf_set_error(const char *fmt, ...);

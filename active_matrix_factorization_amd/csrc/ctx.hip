@@ -324,6 +324,17 @@ int apmf_d2h_2d(apmf_ctx *ctx, void *h_dst, size_t dpitch, const void *d_src, si
     return APMF_OK;
 }
 
+int apmf_d2d_2d(apmf_ctx *ctx, void *d_dst, size_t dpitch, const void *d_src, size_t spitch, size_t width,
+                size_t height)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    if (width == 0 || height == 0) return APMF_OK;
+    APMF_REQUIRE(d_dst && d_src && dpitch >= width && spitch >= width, "bad 2-D copy");
+    APMF_CHECK_HIP(hipMemcpy2DAsync(d_dst, dpitch, d_src, spitch, width, height, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+    return APMF_OK;
+}
+
 } // extern "C"
 
 int apmf_ws(apmf_ctx *ctx, int slot, size_t bytes, void **out)

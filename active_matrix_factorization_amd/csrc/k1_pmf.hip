@@ -103,17 +103,63 @@ struct RowDesc {
 };
 static_assert(sizeof(RowDesc) == 16, "RowDesc is one 16-byte load");
 
+// Batched re-fits (apmf_pmf_batch_fit_lls): hypothesis h is the SHARED ratings container plus ONE extra
+// rating (i, j, v), which the row kernels take as the last entry of user row i / item row j - exactly where
+// add_rating() + a rebuilt container puts it (the new rating is the last row of the ratings array and the
+// CSR build is a stable counting sort) - so that a batched fit is bit-identical to the same fit run alone
+// on a rebuilt container.  The row's extended length (len + 1) is what the caller passes as `end`.
+struct RowExtra {
+    int64_t at;     // position of the extra entry: end - 1 of the extended row; -1 = this row has none
+    int32_t c;      // its index on the other side
+    double r;       // its value
+};
+
+struct FitBatch {
+    const int *sel;            // blockIdx.y -> hypothesis
+    const int32_t *ei, *ej;    // the extra rating of every hypothesis
+    const double *ev;
+    const double *mean_add;    // per-hypothesis mean offset (subtract_mean), or NULL: PmfParams'
+    size_t nu, nv;             // strides of the per-hypothesis factor / gradient arrays (n d, m d)
+    int nrows;                 // n + m: stride of the per-hypothesis row descriptors
+};
+
+template <bool EX>
+__device__ __forceinline__ RowExtra row_extra(const FitBatch &B, int h, bool is_user, int row, int64_t end)
+{
+    RowExtra x;
+    x.at = -1; x.c = 0; x.r = 0.;
+    if (EX) {
+        const int i = B.ei[h], j = B.ej[h];
+        if (is_user ? row == i : row == j) {
+            x.at = end - 1;
+            x.c = is_user ? j : i;
+            x.r = B.ev[h];
+        }
+    }
+    return x;
+}
+
+// entry `tc` of a row for the loads: the extra entry is not in memory - its neighbour is read instead
+// (an address inside the array: the row before it, or entry 0) and replaced afterwards
+template <bool EX>
+__device__ __forceinline__ int64_t mem_entry(int64_t tc, const RowExtra &ex)
+{
+    if (!EX) return tc;
+    const int64_t tm = tc == ex.at ? tc - 1 : tc;
+    return tm < 0 ? 0 : tm;
+}
+
 // One pass over (a share of) one CSR row.  The row's own vector is xk (lane k of every
 // group); for each rating the other side's row y is gathered and the prediction formed with a
 // DP-lane reduce.
 //   GRAD : returns this wave's share of  sum_t y_t * (r_t - pred_t) / sigma^2   (lane k)
 //   !GRAD: returns this wave's share of  sum_t (r_t - pred_t)^2                 (lanes k == 0)
 // WPR waves share a row: wave `sub` takes ratings sub*G + g, + WPR*G, ...
-template <int DP, int WPR, bool GRAD>
+template <int DP, int WPR, bool GRAD, bool EX = false>
 __device__ __forceinline__ double row_pass(const PmfParams &p, int lane, int sub, int64_t beg, int64_t end,
                                            const int32_t *__restrict__ idx,
                                            const double *__restrict__ val, double xk,
-                                           const double *__restrict__ Y)
+                                           const double *__restrict__ Y, const RowExtra ex = RowExtra{-1, 0, 0.})
 {
     constexpr int G = 64 / DP;
     constexpr int STRIDE = WPR * G;
@@ -137,8 +183,10 @@ __device__ __forceinline__ double row_pass(const PmfParams &p, int lane, int sub
             const int64_t t = t0 + (int64_t)u * STRIDE;
             ok[u] = t < end;
             const int64_t tc = ok[u] ? t : last;
-            c[u] = idx[tc];
-            r[u] = val[tc];
+            const int64_t tm = mem_entry<EX>(tc, ex);
+            c[u] = idx[tm];
+            r[u] = val[tm];
+            if (EX && tc == ex.at) { c[u] = ex.c; r[u] = ex.r; }
         }
 #pragma unroll
         for (int u = 0; u < UN; u++) y[u] = Y[(size_t)c[u] * d + kc];
@@ -266,6 +314,111 @@ __global__ __launch_bounds__(256) void k_sqerr(const PmfParams p, int u_lo, int 
     }
 }
 
+// gradient() of hypothesis blockIdx.y at its own factors, the extra rating included (the starting gradient
+// of a batched re-fit): the arithmetic of k_grad row by row
+template <int DP, int WPR>
+__global__ __launch_bounds__(256) void k_grad_batch(const PmfParams p_in, const FitBatch B,
+                                                    const int64_t *__restrict__ ptr_u,
+                                                    const int32_t *__restrict__ idx_u,
+                                                    const double *__restrict__ val_u,
+                                                    const int64_t *__restrict__ ptr_v,
+                                                    const int32_t *__restrict__ idx_v,
+                                                    const double *__restrict__ val_v,
+                                                    const double *__restrict__ U, const double *__restrict__ V,
+                                                    double *__restrict__ gU, double *__restrict__ gV)
+{
+    __shared__ double sh[4][64];
+    constexpr int RPB = 4 / WPR;
+    PmfParams p = p_in;
+    const int hyp = B.sel[blockIdx.y];
+    if (B.mean_add) p.mean_add = B.mean_add[hyp];
+    U += hyp * B.nu; gU += hyp * B.nu;
+    V += hyp * B.nv; gV += hyp * B.nv;
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const int slot = blockIdx.x * RPB + wave / WPR;
+    const int sub = wave % WPR;
+    const bool valid = slot < B.nrows;
+    const int d = p.d;
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    int row = 0;
+    bool is_user = true;
+    double xk = 0., acc = 0.;
+    if (valid) {
+        is_user = slot < p.n;
+        row = is_user ? slot : slot - p.n;
+        const int64_t *ptr = is_user ? ptr_u : ptr_v;
+        const double *X = is_user ? U : V;
+        xk = kok ? X[(size_t)row * d + k] : 0.;
+        int64_t end = ptr[row + 1];
+        const int xi = B.ei[hyp], xj = B.ej[hyp];
+        if (is_user ? row == xi : row == xj) end += 1;
+        const RowExtra ex = row_extra<true>(B, hyp, is_user, row, end);
+        acc = row_pass<DP, WPR, true, true>(p, lane, sub, ptr[row], end, is_user ? idx_u : idx_v,
+                                            is_user ? val_u : val_v, xk, is_user ? V : U, ex);
+        acc = cross_group_sum<DP>(acc);
+    }
+    if (WPR > 1) {
+        sh[wave][lane] = acc;
+        __syncthreads();
+        if (valid && sub == 0)
+#pragma unroll
+            for (int w = 1; w < WPR; w++) acc += sh[wave + w][lane];
+    }
+    if (valid && sub == 0 && g == 0 && kok)
+        (is_user ? gU : gV)[(size_t)row * d + k] = -xk / (is_user ? p.sig_u : p.sig_v) + acc;
+}
+
+// the per-wave partials of k_sqerr for hypothesis blockIdx.y (whole model), the extra rating included
+template <int DP, int WPR>
+__global__ __launch_bounds__(256) void k_sqerr_batch(const PmfParams p_in, const FitBatch B,
+                                                     const int64_t *__restrict__ ptr_u,
+                                                     const int32_t *__restrict__ idx_u,
+                                                     const double *__restrict__ val_u,
+                                                     const double *__restrict__ U, const double *__restrict__ V,
+                                                     double *__restrict__ part /* (H, nslots * WPR, 3) */, int nslots)
+{
+    constexpr int RPB = 4 / WPR;
+    PmfParams p = p_in;
+    const int hyp = B.sel[blockIdx.y];
+    if (B.mean_add) p.mean_add = B.mean_add[hyp];
+    U += hyp * B.nu;
+    V += hyp * B.nv;
+    part += (size_t)hyp * nslots * WPR * 3;
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_id_uniform();
+    const int slot = blockIdx.x * RPB + wave / WPR;
+    const int sub = wave % WPR;
+    if (slot >= nslots) return;
+    const int d = p.d;
+    const int k = lane % DP, g = lane / DP;
+    const bool kok = k < d;
+    double sq = 0., un = 0., vn = 0.;
+    if (slot < p.n) {
+        const int urow = slot;
+        const double xk = kok ? U[(size_t)urow * d + k] : 0.;
+        if (sub == 0 && g == 0 && kok) un = xk * xk;
+        int64_t end = ptr_u[urow + 1];
+        if (urow == B.ei[hyp]) end += 1;
+        const RowExtra ex = row_extra<true>(B, hyp, true, urow, end);
+        sq = row_pass<DP, WPR, false, true>(p, lane, sub, ptr_u[urow], end, idx_u, val_u, xk, V, ex);
+    }
+    if (sub == 0 && slot < p.m && g == 0 && kok) {
+        const double vk = V[(size_t)slot * d + k];
+        vn = vk * vk;
+    }
+    sq = wave_sum(sq);
+    un = wave_sum(un);
+    vn = wave_sum(vn);
+    if (lane == 0) {
+        const size_t e = ((size_t)slot * WPR + sub) * 3;
+        part[e + 0] = sq;
+        part[e + 1] = un;
+        part[e + 2] = vn;
+    }
+}
+
 // fixed-order combine of the per-wave partials (one 256-thread block) -> sums[3]
 __device__ __forceinline__ void combine_parts(int nparts, const double *__restrict__ part, double (*sh)[256],
                                               double (&sums)[3])
@@ -299,6 +452,18 @@ __global__ __launch_bounds__(256) void k_ll_finish(int nparts, const double *__r
         out[2] = s[1];
         out[3] = s[2];
     }
+}
+
+// k_ll_finish for hypothesis blockIdx.x: out[h] = LL
+__global__ __launch_bounds__(256) void k_ll_finish_batch(int nparts, const double *__restrict__ part, double sig,
+                                                         double sig_u, double sig_v, const int *__restrict__ sel,
+                                                         double *__restrict__ out)
+{
+    __shared__ double sh[3][256];
+    double s[3];
+    const int hyp = sel[blockIdx.x];
+    combine_parts(nparts, part + (size_t)hyp * nparts * 3, sh, s);
+    if (threadIdx.x == 0) out[hyp] = -s[0] / (2. * sig) - s[1] / (2. * sig_u) - s[2] / (2. * sig_v);
 }
 
 // ---- one search iteration in ONE launch ------------------------------------------------------
@@ -338,29 +503,32 @@ __device__ __forceinline__ void trip_compute(const PmfParams &p, bool kok, int k
 // entries t0 + u*STRIDE of a row; past the end they are read at the last entry and masked (a
 // predicated load is a branch around the instruction, and a trip of those is a chain of waits
 // instead of UNT loads in flight)
-template <int STRIDE, int UNT>
+template <int STRIDE, int UNT, bool EX = false>
 __device__ __forceinline__ void load_entries(int64_t t0, int64_t end, const int32_t *__restrict__ idx,
                                              const double *__restrict__ val, int32_t (&c)[UNT],
-                                             double (&r)[UNT], bool (&ok)[UNT])
+                                             double (&r)[UNT], bool (&ok)[UNT], const RowExtra ex = RowExtra{-1, 0, 0.})
 {
 #pragma unroll
     for (int u = 0; u < UNT; u++) {
         const int64_t t = t0 + (int64_t)u * STRIDE;
         ok[u] = t < end;
         const int64_t tc = ok[u] ? t : end - 1;
-        c[u] = idx[tc];
-        r[u] = val[tc];
+        const int64_t tm = mem_entry<EX>(tc, ex);
+        c[u] = idx[tm];
+        r[u] = val[tm];
+        if (EX && tc == ex.at) { c[u] = ex.c; r[u] = ex.r; }
     }
 }
 
 // The rest of a row whose first trip's entries (c, r, ok) and gathers (y, gy) are in registers.
-template <int DP, int WPR, int UNT>
+template <int DP, int WPR, int UNT, bool EX = false>
 __device__ __forceinline__ void row_pass_trial(const PmfParams &p, int lane, int sub, int64_t beg,
                                                int64_t end, const int32_t *__restrict__ idx,
                                                const double *__restrict__ val, double xk, const double *Y,
                                                const double *gY, double lr, int32_t (&c)[UNT],
                                                double (&r)[UNT], bool (&ok)[UNT], double (&y)[UNT],
-                                               double (&gy)[UNT], double &acc_g, double &acc_sq)
+                                               double (&gy)[UNT], double &acc_g, double &acc_sq,
+                                               const RowExtra ex = RowExtra{-1, 0, 0.})
 {
     constexpr int G = 64 / DP;
     constexpr int STRIDE = WPR * G;
@@ -378,7 +546,7 @@ __device__ __forceinline__ void row_pass_trial(const PmfParams &p, int lane, int
         double rn[UNT];
         bool okn[UNT];
         t0 += (int64_t)STRIDE * UNT;
-        load_entries<STRIDE, UNT>(t0, end, idx, val, cn, rn, okn);
+        load_entries<STRIDE, UNT, EX>(t0, end, idx, val, cn, rn, okn, ex);
         trip_compute<DP, WPR, UNT>(p, kok, k, xk, lr, y, gy, r, ok, acc_g, acc_sq);
         if (done + (int64_t)STRIDE * UNT < span) {
 #pragma unroll
@@ -414,8 +582,10 @@ __device__ unsigned long long g_k1_stamps[8 * 16384];
 #endif
 
 // A block is RPB rows x WPR waves.
-template <int DP, int WPR, int RPB, int UNT>
-__global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, const FitState *__restrict__ st_in,
+// EX (apmf_pmf_batch_fit_lls): gridDim.y hypotheses, each with its own state, partial sums, row descriptors
+// (the order a rebuilt container would have), factor / gradient arrays and one extra rating (FitBatch).
+template <int DP, int WPR, int RPB, int UNT, bool EX = false>
+__global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p_in, const FitState *__restrict__ st_in,
                                                   FitState *__restrict__ st_out, int nparts_in,
                                                   const double *__restrict__ part_in,
                                                   double *__restrict__ part_out,
@@ -426,8 +596,21 @@ __global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, 
                                                   const double *__restrict__ val_v, double *U0, double *V0,
                                                   double *U1, double *V1, double *gU0, double *gV0,
                                                   double *gU1, double *gV1, double sig,
-                                                  double *__restrict__ trace)
+                                                  double *__restrict__ trace, const FitBatch B = FitBatch{})
 {
+    PmfParams p = p_in;
+    int hyp = 0;
+    if (EX) {
+        hyp = B.sel[blockIdx.y];
+        if (B.mean_add) p.mean_add = B.mean_add[hyp];
+        st_in += hyp;
+        st_out += hyp;
+        part_in += (size_t)hyp * 3 * FIT_GRID_MAX;
+        part_out += (size_t)hyp * 3 * FIT_GRID_MAX;
+        desc += (size_t)hyp * B.nrows;
+        U0 += hyp * B.nu; U1 += hyp * B.nu; gU0 += hyp * B.nu; gU1 += hyp * B.nu;
+        V0 += hyp * B.nv; V1 += hyp * B.nv; gV0 += hyp * B.nv; gV1 += hyp * B.nv;
+    }
     constexpr int NW = RPB * WPR;
     __shared__ double sh_g[NW][64];
     __shared__ double sh_p[NW][3];
@@ -481,6 +664,7 @@ __global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, 
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)rd.beg);
     int64_t end = beg + __builtin_amdgcn_readfirstlane(rd.len);
     bool has = valid && end - (beg + sub * G) > 0;      // wave-uniform
+    RowExtra ex = row_extra<EX>(B, hyp, is_user, row, end);
     int32_t c[UNT];
     double r[UNT], y[UNT], gy[UNT], y1[UNT], gy1[UNT];
     bool ok[UNT];
@@ -495,8 +679,8 @@ __global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, 
         gx1 = (is_user ? gU1 : gV1)[o];
     }
     if (has) {
-        load_entries<STRIDE, UNT>(beg + sub * G + g, end, is_user ? idx_u : idx_v, is_user ? val_u : val_v, c, r,
-                                  ok);
+        load_entries<STRIDE, UNT, EX>(beg + sub * G + g, end, is_user ? idx_u : idx_v, is_user ? val_u : val_v, c, r,
+                                      ok, ex);
 #pragma unroll
         for (int u = 0; u < UNT; u++) {
             const size_t oy = (size_t)c[u] * d + kc;
@@ -565,9 +749,9 @@ __global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, 
             }
             K1_STAMP(2);
             if (has)
-                row_pass_trial<DP, WPR, UNT>(p, lane, sub, beg, end, is_user ? idx_u : idx_v,
-                                             is_user ? val_u : val_v, xk, is_user ? cV : cU,
-                                             is_user ? gV : gU, lr, c, r, ok, y, gy, acc, sq_row);
+                row_pass_trial<DP, WPR, UNT, EX>(p, lane, sub, beg, end, is_user ? idx_u : idx_v,
+                                                 is_user ? val_u : val_v, xk, is_user ? cV : cU,
+                                                 is_user ? gV : gU, lr, c, r, ok, y, gy, acc, sq_row, ex);
             K1_STAMP(3);
             acc = cross_group_sum<DP>(acc);
             if (is_user) sq += sq_row;
@@ -595,14 +779,15 @@ __global__ __launch_bounds__(64 * RPB * WPR) void k_fit_iter(const PmfParams p, 
               (uint32_t)__builtin_amdgcn_readfirstlane((int)rd.beg);
         end = beg + __builtin_amdgcn_readfirstlane(rd.len);
         has = valid && end - (beg + sub * G) > 0;
+        ex = row_extra<EX>(B, hyp, is_user, row, end);
         if (valid) {
             const size_t o = (size_t)row * d + kc;
             xc = (is_user ? cU : cV)[o];
             gxc = (is_user ? gU : gV)[o];
         }
         if (has) {
-            load_entries<STRIDE, UNT>(beg + sub * G + g, end, is_user ? idx_u : idx_v, is_user ? val_u : val_v, c,
-                                      r, ok);
+            load_entries<STRIDE, UNT, EX>(beg + sub * G + g, end, is_user ? idx_u : idx_v, is_user ? val_u : val_v, c,
+                                          r, ok, ex);
 #pragma unroll
             for (int u = 0; u < UNT; u++) {
                 const size_t oy = (size_t)c[u] * d + kc;
@@ -875,6 +1060,9 @@ int upload_desc(apmf_ctx *ctx, apmf_ratings *r, const std::vector<int32_t> &orde
         r->max_len = std::max(r->max_len, desc[t].len);
     }
     if (desc.empty()) return APMF_OK;
+    r->h_desc = malloc(desc.size() * sizeof(RowDesc));
+    if (!r->h_desc) { apmf_set_error("out of host memory"); return APMF_ENOMEM; }
+    memcpy(r->h_desc, desc.data(), desc.size() * sizeof(RowDesc));
     return apmf_h2d(ctx, r->desc, desc.data(), desc.size() * sizeof(RowDesc));
 }
 
@@ -959,7 +1147,7 @@ int apmf_ratings_create(apmf_ctx *ctx, const double *h_ratings, int64_t N, int n
     }
     if (rc == APMF_OK) rc = apmf_h2d(ctx, r->order, order.data(), order.size() * 4);
     if (rc == APMF_OK) rc = upload_desc(ctx, r, order, ptr[0], ptr[1]);
-    if (rc != APMF_OK) { (void)hipFree(r->block); delete r; return rc; }
+    if (rc != APMF_OK) { (void)hipFree(r->block); free(r->h_desc); delete r; return rc; }
     *out = r;
     return APMF_OK;
 }
@@ -1027,7 +1215,7 @@ int apmf_ratings_create_dense(apmf_ctx *ctx, const double *d_real, int ld_real, 
         if (hipGetLastError() != hipSuccess) { apmf_set_error("kernel launch failed"); rc = APMF_EHIP; }
         if (rc == APMF_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { apmf_set_error("sync failed"); rc = APMF_EHIP; }
     }
-    if (rc != APMF_OK) { (void)hipFree(r->block); delete r; return rc; }
+    if (rc != APMF_OK) { (void)hipFree(r->block); free(r->h_desc); delete r; return rc; }
     *out = r;
     return APMF_OK;
 }
@@ -1037,6 +1225,7 @@ int apmf_ratings_destroy(apmf_ctx *ctx, apmf_ratings *r)
     if (!r) return APMF_OK;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (r->block) (void)hipFree(r->block);
+    free(r->h_desc);
     delete r;
     return APMF_OK;
 }
@@ -1285,6 +1474,213 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
     if (h_old_ll) *h_old_ll = fin.old_ll;
     *h_steps = fin.steps;
     if (h_converged) *h_converged = fin.converged ? 1 : 0;
+    return APMF_OK;
+}
+
+namespace {
+
+// per hypothesis: the factors of the accepted point live in the second buffer pair -> copy them back
+__global__ __launch_bounds__(256) void k_fit_batch_collect(const int *__restrict__ cur, size_t nu, size_t nv,
+                                                           double *__restrict__ U, const double *__restrict__ tU,
+                                                           double *__restrict__ V, const double *__restrict__ tV)
+{
+    const int h = blockIdx.y;
+    if (!cur[h]) return;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nu + nv; e += (size_t)gridDim.x * 256) {
+        if (e < nu) U[h * nu + e] = tU[h * nu + e];
+        else V[h * nv + (e - nu)] = tV[h * nv + (e - nu)];
+    }
+}
+
+struct DevBlocks {            // device blocks of one call, released together
+    apmf_ctx *ctx;
+    std::vector<void *> p;
+    explicit DevBlocks(apmf_ctx *c) : ctx(c) {}
+    ~DevBlocks() { for (void *q : p) (void)apmf_free(ctx, q); }
+    int get(size_t bytes, void **out)
+    {
+        int rc = apmf_malloc(ctx, bytes ? bytes : 8, out);
+        if (rc == APMF_OK) p.push_back(*out);
+        return rc;
+    }
+};
+
+} // namespace
+
+// H fit_lls searches in one chain of launches: hypothesis h = the shared container + the rating
+// (h_ei[h], h_ej[h], h_ev[h]) appended where add_rating() would put it, started from its own factors
+// d_U[h], d_V[h] (updated in place).  The lookahead with refit_lookahead re-fits the MAP estimate of every
+// hypothesis first (mn_active_pmf.py:662-665: apmf.do_fit() on the deep copy).  Every hypothesis runs the
+// arithmetic of apmf_pmf_fit_lls on a container rebuilt with its rating - same row order, same partial
+// sums, same decisions: bit-identical - with its own accept / reject state on the device.
+int apmf_pmf_batch_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, const int32_t *h_ei,
+                           const int32_t *h_ej, const double *h_ev, double *d_U, double *d_V, double sigma_sq,
+                           double sigma_u_sq, double sigma_v_sq, int subtract_mean, const double *h_mean_rating,
+                           double learning_rate, double min_learning_rate, double stop_thresh, int64_t max_steps,
+                           double *h_ll, int64_t *h_steps, int *h_converged)
+{
+    APMF_TRY(check_common(ctx, r, d, sigma_sq, sigma_u_sq, sigma_v_sq));
+    APMF_REQUIRE(H >= 1 && h_ei && h_ej && h_ev && d_U && d_V, "NULL operand / empty batch");
+    APMF_REQUIRE(!subtract_mean || h_mean_rating, "subtract_mean needs the mean rating of every hypothesis");
+    APMF_REQUIRE(r->N >= 1 && r->h_desc, "the ratings container is empty");
+    const int n = r->n, m = r->m, R = n + m;
+    for (int h = 0; h < H; h++)
+        APMF_REQUIRE(h_ei[h] >= 0 && h_ei[h] < n && h_ej[h] >= 0 && h_ej[h] < m, "hypothesis %d: entry (%d, %d) outside %d x %d",
+                     h, h_ei[h], h_ej[h], n, m);
+    const PmfParams p = make_params(r, d, sigma_sq, sigma_u_sq, sigma_v_sq, 0, 0.);
+    const size_t nu = (size_t)n * d, nv = (size_t)m * d;
+    // what a container rebuilt with one more rating would choose (wpr_for, fit block shape)
+    const int64_t rows_min = std::max(1, std::min(n, m));
+    const int wpr = ((r->N + 1) / rows_min) >= 48 ? 4 : 1;
+    const int nslots = std::max(n, m);
+    const int nparts_ll = nslots * wpr;
+    const RowDesc *base = (const RowDesc *)r->h_desc;
+    std::vector<int32_t> len_of((size_t)R);
+    std::vector<int64_t> beg_of((size_t)R);
+    for (int t = 0; t < R; t++) { len_of[base[t].row_all] = base[t].len; beg_of[base[t].row_all] = base[t].beg; }
+    // per-hypothesis row descriptors: the stable descending-nnz order of the rebuilt container
+    std::vector<RowDesc> desc((size_t)H * R);
+    std::vector<int> fwpr_of((size_t)H);
+    const int fit_wpr = getenv("APMF_K1_WPR") ? atoi(getenv("APMF_K1_WPR")) : 0;
+    auto before = [](const RowDesc &a, const RowDesc &b) { return a.len != b.len ? a.len > b.len : a.row_all < b.row_all; };
+    for (int h = 0; h < H; h++) {
+        const int a = h_ei[h], b = n + h_ej[h];
+        RowDesc ins[2] = {{a, len_of[a] + 1, beg_of[a]}, {b, len_of[b] + 1, beg_of[b]}};
+        if (before(ins[1], ins[0])) std::swap(ins[0], ins[1]);
+        RowDesc *out = desc.data() + (size_t)h * R;
+        int q = 0, w = 0;
+        for (int t = 0; t < R; t++) {
+            const RowDesc &e = base[t];
+            if (e.row_all == a || e.row_all == b) continue;
+            while (q < 2 && before(ins[q], e)) out[w++] = ins[q++];
+            out[w++] = e;
+        }
+        while (q < 2) out[w++] = ins[q++];
+        const int max_len = std::max(r->max_len, std::max(len_of[a], len_of[b]) + 1);
+        fwpr_of[h] = (fit_wpr == 1 || fit_wpr == 4) ? fit_wpr : (max_len > 192 ? 4 : 1);
+    }
+    DevBlocks dev(ctx);
+    RowDesc *d_desc;
+    int32_t *d_ei, *d_ej;
+    double *d_ev, *d_mean = nullptr, *d_work, *d_part, *d_part_ll, *d_ll0;
+    FitState *d_state;
+    int *d_sel, *d_cur;
+    APMF_TRY(dev.get(desc.size() * sizeof(RowDesc), (void **)&d_desc));
+    APMF_TRY(dev.get((size_t)H * 4, (void **)&d_ei));
+    APMF_TRY(dev.get((size_t)H * 4, (void **)&d_ej));
+    APMF_TRY(dev.get((size_t)H * 8, (void **)&d_ev));
+    if (subtract_mean) APMF_TRY(dev.get((size_t)H * 8, (void **)&d_mean));
+    APMF_TRY(dev.get((size_t)H * 6 * (nu + nv) / 2 * 8 + 64, (void **)&d_work));       // gU0 gV0 gU1 gV1 tU tV
+    APMF_TRY(dev.get((size_t)2 * H * 3 * FIT_GRID_MAX * 8, (void **)&d_part));
+    APMF_TRY(dev.get((size_t)H * nparts_ll * 24, (void **)&d_part_ll));
+    APMF_TRY(dev.get((size_t)H * 8, (void **)&d_ll0));
+    APMF_TRY(dev.get((size_t)2 * H * sizeof(FitState), (void **)&d_state));
+    APMF_TRY(dev.get((size_t)H * 4, (void **)&d_sel));
+    APMF_TRY(dev.get((size_t)H * 4, (void **)&d_cur));
+    double *gU0 = d_work, *gV0 = gU0 + H * nu, *gU1 = gV0 + H * nv, *gV1 = gU1 + H * nu, *tU = gV1 + H * nv,
+           *tV = tU + H * nu;
+    APMF_TRY(apmf_h2d(ctx, d_desc, desc.data(), desc.size() * sizeof(RowDesc)));
+    APMF_TRY(apmf_h2d(ctx, d_ei, h_ei, (size_t)H * 4));
+    APMF_TRY(apmf_h2d(ctx, d_ej, h_ej, (size_t)H * 4));
+    APMF_TRY(apmf_h2d(ctx, d_ev, h_ev, (size_t)H * 8));
+    if (subtract_mean) APMF_TRY(apmf_h2d(ctx, d_mean, h_mean_rating, (size_t)H * 8));
+    FitBatch B;
+    B.sel = d_sel; B.ei = d_ei; B.ej = d_ej; B.ev = d_ev; B.mean_add = d_mean; B.nu = nu; B.nv = nv; B.nrows = R;
+    std::vector<int> sel((size_t)H);
+    for (int h = 0; h < H; h++) sel[h] = h;
+    APMF_TRY(apmf_h2d(ctx, d_sel, sel.data(), (size_t)H * 4));
+    const int dp = dp_for(d);
+    // LL of every starting point (launch_ll's arithmetic) and the gradient there (launch_grad's)
+    APMF_CHECK_HIP(hipMemsetAsync(d_part_ll, 0, (size_t)H * nparts_ll * 24, ctx->stream));
+    {
+        const int blocks = (nslots + (4 / wpr) - 1) / (4 / wpr);
+        DISPATCH_DP_WPR(dp, wpr,
+                        hipLaunchKernelGGL((k_sqerr_batch<DP, WPR>), dim3(blocks, H), dim3(256), 0, ctx->stream, p, B,
+                                           r->ptr[0], r->idx[0], r->val[0], d_U, d_V, d_part_ll, nslots));
+        hipLaunchKernelGGL(k_ll_finish_batch, dim3(H), dim3(256), 0, ctx->stream, nparts_ll, d_part_ll, sigma_sq,
+                           p.sig_u, p.sig_v, d_sel, d_ll0);
+        APMF_CHECK_LAUNCH();
+    }
+    std::vector<double> ll0((size_t)H);
+    APMF_TRY(apmf_d2h(ctx, ll0.data(), d_ll0, (size_t)H * 8));
+    std::vector<FitState> st((size_t)H), fin((size_t)H);
+    for (int h = 0; h < H; h++) {
+        memset(&st[h], 0, sizeof(FitState));
+        st[h].lr = learning_rate;
+        st[h].old_ll = ll0[h];
+        st[h].min_lr = min_learning_rate;
+        st[h].stop_thresh = stop_thresh;
+        st[h].max_steps = max_steps;
+        st[h].max_trace = 0;
+        fin[h] = st[h];
+    }
+    APMF_TRY(apmf_h2d(ctx, d_state, st.data(), (size_t)H * sizeof(FitState)));
+    APMF_CHECK_HIP(hipMemsetAsync(d_part, 0, (size_t)2 * H * 3 * FIT_GRID_MAX * 8, ctx->stream));
+    if (max_steps != 0) {
+        const int blocks = (R + (4 / wpr) - 1) / (4 / wpr);
+        DISPATCH_DP_WPR(dp, wpr,
+                        hipLaunchKernelGGL((k_grad_batch<DP, WPR>), dim3(blocks, H), dim3(256), 0, ctx->stream, p, B,
+                                           r->ptr[0], r->idx[0], r->val[0], r->ptr[1], r->idx[1], r->val[1], d_U, d_V,
+                                           gU0, gV0));
+        APMF_CHECK_LAUNCH();
+    }
+    // the search: all live hypotheses advance by one trial per launch; the list of live ones is compacted
+    // whenever the states are read (a finished hypothesis' state is final: its launches pass it through)
+    std::vector<char> live((size_t)H, max_steps != 0 ? 1 : 0);
+    long long it = 0;
+    for (;;) {
+        int done_all = 1;
+        for (int pass = 0; pass < 2; pass++) {            // the two block shapes a batch may need
+            const int fwpr = pass ? 4 : 1;
+            sel.clear();
+            for (int h = 0; h < H; h++) if (live[h] && fwpr_of[h] == fwpr) sel.push_back(h);
+            if (sel.empty()) continue;
+            done_all = 0;
+            int *d_sel_p = d_sel + (pass ? H - (int)sel.size() : 0);     // the two lists share the array
+            APMF_TRY(apmf_h2d(ctx, d_sel_p, sel.data(), sel.size() * 4));
+            FitBatch Bp = B;
+            Bp.sel = d_sel_p;
+            const int frpb = 4 / fwpr;
+            const int g_blocks = std::min((R + frpb - 1) / frpb, FIT_GRID_MAX);
+            long long jt = it;
+            for (int c = 0; c < 16; c++, jt++) {
+                FitState *s_in = d_state + (size_t)(jt & 1) * H, *s_out = d_state + (size_t)((jt + 1) & 1) * H;
+                double *p_in = d_part + (size_t)(jt & 1) * H * 3 * FIT_GRID_MAX,
+                       *p_out = d_part + (size_t)((jt + 1) & 1) * H * 3 * FIT_GRID_MAX;
+#define FIT_ITER_B(WPR_, RPB_)                                                                                   \
+    DISPATCH_DP(dp, hipLaunchKernelGGL((k_fit_iter<DP, WPR_, RPB_, 2, true>), dim3(g_blocks, (unsigned)sel.size()), \
+                                       dim3(256), 0, ctx->stream, p, s_in, s_out, g_blocks, p_in, p_out, d_desc,  \
+                                       r->idx[0], r->val[0], r->idx[1], r->val[1], d_U, d_V, tU, tV, gU0, gV0,   \
+                                       gU1, gV1, sigma_sq, (double *)nullptr, Bp))
+                if (fwpr == 4) { FIT_ITER_B(4, 1); } else { FIT_ITER_B(1, 4); }
+#undef FIT_ITER_B
+            }
+            APMF_CHECK_LAUNCH();
+        }
+        if (done_all) break;
+        it += 16;                                         // an even number: the parity of the buffers is that of `it`
+        APMF_TRY(apmf_d2h(ctx, st.data(), d_state + (size_t)(it & 1) * H, (size_t)H * sizeof(FitState)));
+        for (int h = 0; h < H; h++) {
+            if (!live[h]) continue;
+            fin[h] = st[h];
+            if (st[h].converged || (max_steps >= 0 && st[h].steps >= max_steps)) live[h] = 0;
+        }
+    }
+    std::vector<int> cur((size_t)H);
+    int any = 0;
+    for (int h = 0; h < H; h++) { cur[h] = fin[h].cur; any |= cur[h]; }
+    if (any) {
+        APMF_TRY(apmf_h2d(ctx, d_cur, cur.data(), (size_t)H * 4));
+        const unsigned gx = (unsigned)std::min<size_t>((nu + nv + 255) / 256, 64);
+        hipLaunchKernelGGL(k_fit_batch_collect, dim3(gx, H), dim3(256), 0, ctx->stream, d_cur, nu, nv, d_U, tU, d_V, tV);
+        APMF_CHECK_LAUNCH();
+    }
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int h = 0; h < H; h++) {
+        if (h_ll) h_ll[h] = fin[h].old_ll;
+        if (h_steps) h_steps[h] = fin[h].steps;
+        if (h_converged) h_converged[h] = fin[h].converged ? 1 : 0;
+    }
     return APMF_OK;
 }
 

@@ -10,6 +10,7 @@ loop through exp_dotprod_sq in the reference - is one batched HIP launch here (K
 csrc/k2_score.hip), in float64 so that the selected indices match the reference.
 """
 import os
+import time
 
 import numpy as np
 
@@ -380,30 +381,40 @@ class MNActivePMF(_ActiveBase):
                     batch.free()
                 batch = ctx.mn_batch(rt, d, H)
             models = None
+            t_refit = time.perf_counter()
             if self.refit_lookahead:
                 # MAP re-fit per hypothesis (do_fit), then initialize_approx(): mean = MAP, identity
                 # covariances.  The batch fit needs no model objects: fit_lls runs straight on a
                 # container with the hypothesis' rating appended (other fit types, or a criterion
                 # that wants the models, take the deep copies the reference makes)
                 if self.fit_type == ('batch',) and special is not None:
-                    means = np.empty((H, n_all, d))
+                    # all H re-fits as one chain of launches over the SHARED container (apmf_pmf_batch_fit_lls:
+                    # bit-identical to H fits on rebuilt containers); the fitted factors never leave the device
                     dd_, s_, su_, sv_, sub_, _mr = self._hyper()
-                    for k, (i, j, v) in enumerate(part):
-                        plus = np.vstack([self.ratings, [i, j, v]])
-                        rth = ctx.ratings(plus, self.num_users, self.num_items)
-                        dU, dV = ctx.array(self.users, np.float64), ctx.array(self.items, np.float64)
-                        ctx.pmf_fit_lls(rth, dU, dV, d, s_, su_, sv_, sub_, float(np.mean(plus[:, 2])),
-                                        float(self.learning_rate), float(self.min_learning_rate),
-                                        float(self.stop_thresh), max_steps=-1, max_trace=0)
-                        means[k, :self.num_users], means[k, self.num_users:] = dU.to_host(), dV.to_host()
-                        rth.free()
+                    n_u = self.num_users
+                    dU = ctx.array(np.broadcast_to(self.users, (H,) + self.users.shape), np.float64)
+                    dV = ctx.array(np.broadcast_to(self.items, (H,) + self.items.shape), np.float64)
+                    hv = np.array([h[2] for h in part], np.float64)
+                    # the mean add_rating() would leave behind (pmf_cy.pyx:152-153): np.mean of the extended column
+                    means_r = [float(np.mean(np.append(self.ratings[:, 2], v))) for v in hv] if sub_ else None
+                    ctx.pmf_batch_fit_lls(rt, dU, dV, d, H, [h[0] for h in part], [h[1] for h in part], hv, s_, su_,
+                                          sv_, sub_, means_r, float(self.learning_rate), float(self.min_learning_rate),
+                                          float(self.stop_thresh))
+                    d_means = ctx.empty((H, n_all, d))
+                    _lib._check(ctx._lib.apmf_d2d_2d(ctx._h, d_means.ptr, n_all * d * 8, dU.ptr, n_u * d * 8,
+                                                     n_u * d * 8, H))
+                    _lib._check(ctx._lib.apmf_d2d_2d(ctx._h, d_means.ptr + n_u * d * 8, n_all * d * 8, dV.ptr,
+                                                     (n_all - n_u) * d * 8, (n_all - n_u) * d * 8, H))
+                    means = d_means
                 else:
                     models = [self._hypothesis_model(i, j, v) for i, j, v in part]
                     for apmf in models:
                         apmf.do_fit()
                     means = np.stack([np.vstack((apmf.users, apmf.items)) for apmf in models])
-                batch.set_state(ctx.array(means), ctx.array(np.eye(n_all)), ctx.array(np.eye(d)),
-                                per_hypothesis=1)
+                batch.set_state(means if isinstance(means, _lib.DeviceArray) else ctx.array(means),
+                                ctx.array(np.eye(n_all)), ctx.array(np.eye(d)), per_hypothesis=1)
+                ctx.sync()
+                LAST_BATCH_STATS['refit_s'] = LAST_BATCH_STATS.get('refit_s', 0.) + time.perf_counter() - t_refit
             else:
                 batch.set_state(*base)
             batch.set_extra([h[0] for h in part], [h[1] for h in part], [h[2] for h in part])

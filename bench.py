@@ -19,8 +19,9 @@ Workload (config.workload = "943x1682-d10-B256", BASELINE.json configs[1] shape)
 --scaling weak (default): every rank owns B states and its own PMF refit (the lookahead's
 hypotheses and the per-key refits are independent units: SURVEY.md 8(e)); the sweep has no
 data-path collective.  --scaling strong: the B states are split over the ranks (B / N each) and
-the PMF fit is ONE fit row-sharded over the ranks (sharding.sharded_fit_lls: per trial two
-device-to-device all-gathers of the U / V row blocks and a 3-element all-reduce).
+the PMF fit is ONE fit row-sharded over the ranks (sharding.sharded_fit_lls: per trial ONE grouped
+device-to-device all-gather carrying the log-likelihood partial sums and the U / V row blocks of both
+speculative next trial points).
 A communicator that cannot be set up is fatal (non-zero exit): no number is printed.
 """
 import argparse
@@ -196,8 +197,9 @@ def main():
         t_grad = max_over_ranks(time.perf_counter() - t0)
         done = int(tr.size)
         grad_steps_per_s = done / t_grad
-        grad_note = ('ONE fit_lls row-sharded over %d ranks (device-to-device all-gather of the U, V row '
-                     'blocks + 3-element all-reduce per trial), N=100000 ratings' % world)
+        grad_note = ('ONE fit_lls row-sharded over %d ranks (one grouped device-to-device all-gather per trial: '
+                     'log-likelihood partial sums + the U, V row blocks of both speculative next trial points), '
+                     'N=100000 ratings' % world)
         per_gpu_steps = done
     else:
         rt = ctx.ratings(ratings, n, m)
@@ -385,11 +387,11 @@ def lookahead_leg(n_cand):
            'full_grid_estimate_s': len(a.unrated) * 5 / (H / dt), 'dtype': 'f64',
            'matrix_dim': N, 'bytes_per_hypothesis_state': 5 * N * N * 8}
     # matrix-core work: two Cholesky factorisations per trial point (the second skipped when the eigenvalue bound
-    # certifies the trial) and one inverse-from-factor per gradient, N^3/3 multiply-adds each way (lower bound:
-    # the tile kernels also run the zero padding of 519 -> 576)
+    # certifies the trial), N^3/3 flops each, and one inverse-from-factor per gradient (triangular inverse + W'W:
+    # 2 N^3/3 flops).  A lower bound: the tile kernels also run the zero padding of 519 -> 576.
     if stats:
         fact = 2 * stats.get('trials', 0) - stats.get('cert_by_bound', 0)
-        flops = (fact + 2 * stats.get('gradients', 0)) * (2. * N ** 3 / 3.)
+        flops = (fact + 2 * stats.get('gradients', 0)) * (N ** 3 / 3.)
         out['mfma_model'] = {'flops': flops, 'tflops': flops / dt / 1e12, 'frac_of_peak': flops / dt / 1e12 / F64_MFMA_PEAK_TFLOPS,
                              'peak_tflops': F64_MFMA_PEAK_TFLOPS, 'note': 'operation count of the factorisations / inverses'}
     pmc = os.path.join(ROOT, 'profiles', 'pmc_lookahead_latest.json')

@@ -79,6 +79,10 @@ int apmf_h2d_2d(apmf_ctx *ctx, void *d_dst, size_t dpitch, const void *h_src, si
                 size_t width, size_t height);
 int apmf_d2h_2d(apmf_ctx *ctx, void *h_dst, size_t dpitch, const void *d_src, size_t spitch,
                 size_t width, size_t height);
+/* device to device, on the stream, no host synchronisation (e.g. H fitted (n, d) / (m, d) factor pairs
+ * stacked into the H (n+m, d) means of a batch of approximations) */
+int apmf_d2d_2d(apmf_ctx *ctx, void *d_dst, size_t dpitch, const void *d_src, size_t spitch,
+                size_t width, size_t height);
 /* d_out = d_x + alpha * d_y, product and sum rounded separately like NumPy's `x + alpha * y`
  * (the trial points of the learning-rate searches, pmf_cy.pyx:271-272); in place allowed */
 int apmf_axpy_f64(apmf_ctx *ctx, double *d_out, const double *d_x, double alpha, const double *d_y,
@@ -148,6 +152,19 @@ int apmf_pmf_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, double *d_U, double *
                      double mean_rating, double *h_lr, double *h_old_ll,
                      double min_learning_rate, double stop_thresh, int64_t max_steps,
                      double *h_ll_trace, int64_t max_trace, int64_t *h_steps, int *h_converged);
+/* H fit_lls searches as ONE chain of launches - the MAP re-fits of a lookahead with refit_lookahead
+ * (mn_active_pmf.py:660-665 / active_pmf.py:660-665: deepcopy, add_rating(i, j, v), do_fit() per hypothesis;
+ * bayes_pmf.py:457-468 with fit_first).  Hypothesis h is the shared container `r` plus the rating
+ * (h_ei[h], h_ej[h], h_ev[h]) taken as the last entry of user row i / item row j - where add_rating() and a
+ * rebuilt container put it - and starts from its own factors d_U (H, n, d), d_V (H, m, d), updated in place.
+ * Row order, partial sums and decisions are those of apmf_pmf_fit_lls on the rebuilt container: results are
+ * bit-identical to H separate calls.  h_mean_rating (H; only read with subtract_mean): mean of the H extended
+ * rating lists.  Outputs (each nullable): final log-likelihood, accepted steps, converged flag per hypothesis. */
+int apmf_pmf_batch_fit_lls(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, const int32_t *h_ei,
+                           const int32_t *h_ej, const double *h_ev, double *d_U, double *d_V, double sigma_sq,
+                           double sigma_u_sq, double sigma_v_sq, int subtract_mean, const double *h_mean_rating,
+                           double learning_rate, double min_learning_rate, double stop_thresh, int64_t max_steps,
+                           double *h_ll, int64_t *h_steps, int *h_converged);
 /* One epoch of fit_minibatches(), pmf_cy.pyx:324-344, on ALREADY SHUFFLED ratings
  * (the host keeps np.random.shuffle so the RNG stream matches): for each consecutive
  * batch  inc = momentum*inc + grad*(lr/len(batch)); params += inc.  d_U, d_V, d_uinc,

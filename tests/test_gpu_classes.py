@@ -981,6 +981,31 @@ def test_lookahead_batched_refit_equals_per_hypothesis(pkg, monkeypatch):
     assert batched == alone
 
 
+def test_lookahead_refit_configs3_makefile_setting(pkg, monkeypatch):
+    """configs[3] as the reference's own Makefile runs it (results/drugbank-94x425/Makefile:31,71): LATENT_D = 20
+    and --refit-lookahead, on the reference's DrugBank subset (the ratings of fixture mn_c4_94x425_d5).  Every
+    hypothesis re-fits the MAP estimate (mn_active_pmf.py:662-665) - all of them as ONE batch of fit_lls searches
+    over the shared container (apmf_pmf_batch_fit_lls) - restarts the approximation from it and fits that (K6, the
+    d in (16, 32] template of its row kernels): batched == per-hypothesis (deep copy, rebuilt container, do_fit,
+    fit_normal) bit for bit."""
+    g = load_golden('mn_c4_94x425_d5')
+    seed(11)
+    a = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=20, rating_values=(0., 1.), discrete_expectations=True,
+                           refit_lookahead=True)
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    a.do_fit()
+    a.initialize_approx()
+    unrated = sorted(a.unrated)
+    pool = [unrated[11], unrated[20011]]
+    k = pkg.mn.KEY_FUNCS['total-variance']
+    batched = a._get_key_vals(pool, k)
+    stats = dict(pkg.mn.LAST_BATCH_STATS)
+    monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', '0')
+    alone = a._get_key_vals(pool, k, procs=1)
+    assert batched == alone
+    assert all(np.isfinite(batched)) and stats['trials'] > 0
+
+
 def test_lookahead_configs3_shape(pkg, monkeypatch):
     """BASELINE.json configs[3]'s shape (94 x 425, rank 5, 500 known): E[total variance] of two
     candidates, batched == per-hypothesis bit for bit, from a partly fitted approximation."""

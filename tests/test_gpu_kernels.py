@@ -780,6 +780,85 @@ def test_rank64_paths(ctx):
     np.testing.assert_allclose(out.to_host()[:50], ref, rtol=1e-8, atol=1e-10)
 
 
+def _batch_fit_case(ctx, ratings, n, m, d, hyps, subtract_mean=False, max_steps=40, seed=0):
+    """H batched re-fits (apmf_pmf_batch_fit_lls) against H separate apmf_pmf_fit_lls calls on containers REBUILT
+    with the hypothesis' rating appended: factors, log-likelihood and step counts must agree bit for bit."""
+    rs = np.random.RandomState(seed)
+    H = len(hyps)
+    U0, V0 = rs.random_sample((n, d)), rs.random_sample((m, d))
+    rt = ctx.ratings(ratings, n, m)
+    dU = ctx.array(np.broadcast_to(U0, (H, n, d)).copy())
+    dV = ctx.array(np.broadcast_to(V0, (H, m, d)).copy())
+    ei, ej, ev = [h[0] for h in hyps], [h[1] for h in hyps], [float(h[2]) for h in hyps]
+    means = [float(np.mean(np.append(ratings[:, 2], v))) for v in ev] if subtract_mean else None
+    ll, steps, conv = ctx.pmf_batch_fit_lls(rt, dU, dV, d, H, ei, ej, ev, 1., 10., 10., subtract_mean, means, 1e-4,
+                                            1e-10, 1e-2, max_steps=max_steps)
+    bU, bV = dU.to_host(), dV.to_host()
+    for h, (i, j, v) in enumerate(hyps):
+        plus = np.vstack([ratings, [i, j, v]])
+        rth = ctx.ratings(plus, n, m)
+        aU, aV = ctx.array(U0), ctx.array(V0)
+        mr = float(np.mean(plus[:, 2])) if subtract_mean else 0.
+        _, st, lr, cv, ll1 = ctx.pmf_fit_lls(rth, aU, aV, d, 1., 10., 10., subtract_mean, mr, 1e-4, 1e-10, 1e-2,
+                                             max_steps=max_steps, max_trace=0, return_ll=True)
+        assert st == steps[h] and cv == conv[h], (h, st, steps[h])
+        assert ll1 == ll[h], (h, ll1, ll[h])
+        assert np.array_equal(aU.to_host(), bU[h]) and np.array_equal(aV.to_host(), bV[h]), h
+        rth.free()
+    rt.free()
+    return steps
+
+
+@pytest.mark.parametrize('d', [2, 5, 10, 20])
+def test_pmf_batch_fit_lls_equals_rebuilt(ctx, d):
+    """The MAP re-fits of a lookahead with refit_lookahead (mn_active_pmf.py:662-665) as one batch: hypotheses whose
+    rating lands in an empty-ish row, in the heaviest row (it moves up in the descending-nnz row order the partial
+    sums follow), in rows tied with others, twice the same entry with different values; with and without
+    subtract_mean."""
+    rs = np.random.RandomState(40 + d)
+    n, m, N = 23, 31, 180
+    flat = rs.choice(n * m, N, replace=False)
+    ratings = np.column_stack([flat // m, flat % m, rs.randint(1, 6, N)]).astype(float)
+    rated = set(zip(ratings[:, 0].astype(int), ratings[:, 1].astype(int)))
+    cnt_u = np.bincount(ratings[:, 0].astype(int), minlength=n)
+    cnt_v = np.bincount(ratings[:, 1].astype(int), minlength=m)
+    free = [(i, j) for i in range(n) for j in range(m) if (i, j) not in rated]
+    heavy_u, light_u = int(np.argmax(cnt_u)), int(np.argmin(cnt_u))
+    heavy_v, light_v = int(np.argmax(cnt_v)), int(np.argmin(cnt_v))
+    pick = lambda i=None, j=None: next(e for e in free if (i is None or e[0] == i) and (j is None or e[1] == j))
+    cand = [pick(heavy_u), pick(light_u), pick(j=heavy_v), pick(j=light_v), free[0], free[-1], free[len(free) // 2]]
+    hyps = [(i, j, float(1 + (k % 5))) for k, (i, j) in enumerate(cand)] + [(cand[0][0], cand[0][1], 5.), (cand[0][0], cand[0][1], 1.)]
+    steps = _batch_fit_case(ctx, ratings, n, m, d, hyps, max_steps=60)
+    assert steps.min() > 3
+    _batch_fit_case(ctx, ratings, n, m, d, hyps[:4], subtract_mean=True, max_steps=25, seed=1)
+
+
+def test_pmf_batch_fit_lls_block_shapes(ctx):
+    """A hypothesis can change the block shape its re-fit runs with - a row growing past 192 ratings (4 waves per
+    row in k_fit_iter), N + 1 reaching 48 ratings per row (4 waves per row in the gradient / log-likelihood
+    kernels) - and a batch may hold both kinds: each hypothesis must get what its rebuilt container would."""
+    rs = np.random.RandomState(9)
+    n, m, d = 5, 260, 4
+    cols = rs.choice(m, 192, replace=False)
+    rows = [np.column_stack([np.zeros(192), cols, rs.randint(1, 6, 192)])]
+    for i in range(1, n):
+        c = rs.choice(m, 9, replace=False)
+        rows.append(np.column_stack([np.full(9, i), c, rs.randint(1, 6, 9)]))
+    ratings = np.vstack(rows).astype(float)
+    free0 = [j for j in range(m) if j not in set(cols)]
+    rated1 = set(ratings[ratings[:, 0] == 1][:, 1].astype(int))
+    free1 = [j for j in range(m) if j not in rated1]
+    hyps = [(0, free0[0], 3.), (1, free1[0], 2.), (0, free0[1], 5.), (2, 7 if (2, 7) not in set(map(tuple, ratings[:, :2].astype(int))) else 8, 1.)]
+    _batch_fit_case(ctx, ratings, n, m, d, hyps, max_steps=12)
+    # N = 191 over min(n, m) = 4 rows: the rebuilt containers have 192 / 4 = 48 ratings per row
+    n, m, N = 4, 70, 191
+    flat = rs.choice(n * m, N, replace=False)
+    ratings = np.column_stack([flat // m, flat % m, rs.randint(1, 6, N)]).astype(float)
+    rated = set(zip(ratings[:, 0].astype(int), ratings[:, 1].astype(int)))
+    free = [(i, j) for i in range(n) for j in range(m) if (i, j) not in rated]
+    _batch_fit_case(ctx, ratings, n, m, 3, [(i, j, 4.) for i, j in free[:3]], max_steps=12)
+
+
 def test_config5_shard_scale(ctx):
     """BASELINE.json configs[4] (100 000 x 20 000, rank 64, 5e7 observed) at the size ONE of its
     8 row shards has: 12 500 user rows x 20 000 items, 6.25e6 ratings.  Size-independent
