@@ -73,24 +73,33 @@ enum { MM_NT = 0, MM_NN = 1, MM_TN = 2 };
 
 // acc += A op B over k in [0, K) (K a multiple of 4, tiles zero-padded):
 //   MM_NT: C[i][j] += A[i][k] B[j][k]     MM_NN: C[i][j] += A[i][k] B[k][j]     MM_TN: C[i][j] += A[k][i] B[k][j]
+// rmax / cmax: rows / columns of the 64 x 64 output the caller keeps (a short last block of the matrix: 519 =
+// 8 x 64 + 7 leaves 7-row and 7-column strips of tiles, 30 % of all tile products of a factorisation).  A 16 x 16
+// accumulator wholly outside them is skipped - its values would be dropped anyway - and the others are
+// computed exactly as before: the kept results are the same bits.
 template <int FORM>
-__device__ __forceinline__ void tile_mfma(f64x4 (&acc)[2][2], const double (*A)[TP], const double (*B)[TP], int K)
+__device__ __forceinline__ void tile_mfma(f64x4 (&acc)[2][2], const double (*A)[TP], const double (*B)[TP], int K,
+                                          int rmax = 64, int cmax = 64)
 {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane & 15, g = lane >> 4;
     const int r0 = 32 * (w >> 1) + li, c0 = 32 * (w & 1) + li;
+    const bool ru[2] = {32 * (w >> 1) < rmax, 32 * (w >> 1) + 16 < rmax};      // wave-uniform
+    const bool cv[2] = {32 * (w & 1) < cmax, 32 * (w & 1) + 16 < cmax};
+    if (!ru[0] || !cv[0]) return;
     for (int k0 = 0; k0 < K; k0 += 4) {
         const int k = k0 + g;
         double a[2], b[2];
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            a[u] = FORM == MM_TN ? A[k][r0 + 16 * u] : A[r0 + 16 * u][k];
-            b[u] = FORM == MM_NT ? B[c0 + 16 * u][k] : B[k][c0 + 16 * u];
+            a[u] = ru[u] ? (FORM == MM_TN ? A[k][r0 + 16 * u] : A[r0 + 16 * u][k]) : 0.;
+            b[u] = cv[u] ? (FORM == MM_NT ? B[c0 + 16 * u][k] : B[k][c0 + 16 * u]) : 0.;
         }
 #pragma unroll
         for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int v = 0; v < 2; v++) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+            for (int v = 0; v < 2; v++)
+                if (ru[u] && cv[v]) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
     }
 }
 
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k
     }
     __syncthreads();
     f64x4 acc[2][2] = {};
-    tile_mfma<MM_NT>(acc, P, X, CH_NB);
+    tile_mfma<MM_NT>(acc, P, X, CH_NB, rows, nb);
     TILE_FOR_EACH(u, v, r) {
         const int i = tile_row(u, r), j = tile_col(v);
         if (i < rows && j < nb) A[(size_t)(r0 + i) * N + k + j] = acc[u][v][r];
@@ -360,9 +369,13 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
     pj.load(A, N, j0, k, N, N);
     if (*job.info != 0) return;
     f64x4 acc[2][2] = {};
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane & 15, g = lane >> 4;
     const int r0 = 32 * (w >> 1) + li, c0 = 32 * (w & 1) + li;
+    // 16 x 16 accumulators wholly outside the matrix (a short last block) are skipped: see tile_mfma
+    const int rmax = N - i0, cmax = N - j0;
+    const bool ru[2] = {32 * (w >> 1) < rmax, 32 * (w >> 1) + 16 < rmax};
+    const bool cv[2] = {32 * (w & 1) < cmax, 32 * (w & 1) + 16 < cmax};
     for (int ks = 0; ks < nb; ks += KS) {
         __syncthreads();
 #pragma unroll
@@ -376,17 +389,18 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
             pj.load(A, N, j0, k + ks + KS, N, N);
         }
         __syncthreads();
+        if (ru[0] && cv[0])
 #pragma unroll
         for (int k0 = 0; k0 < KS; k0 += 4) {
             const int kk = k0 + g;
             double a[2], b[2];
 #pragma unroll
-            for (int u = 0; u < 2; u++) { a[u] = Pi[r0 + 16 * u][kk]; b[u] = Pj[c0 + 16 * u][kk]; }
+            for (int u = 0; u < 2; u++) { a[u] = ru[u] ? Pi[r0 + 16 * u][kk] : 0.; b[u] = cv[u] ? Pj[c0 + 16 * u][kk] : 0.; }
 #pragma unroll
             for (int u = 0; u < 2; u++)
 #pragma unroll
                 for (int v = 0; v < 2; v++)
-                    acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+                    if (ru[u] && cv[v]) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
         }
     }
     if (!NEXT || blockIdx.x != 0) {
@@ -444,9 +458,12 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
     pj.load(A, N, j0, 0, N, N);
     if (*job.info != 0) return;
     f64x4 acc[2][2] = {};
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane & 15, g = lane >> 4;
     const int r0 = 32 * (w >> 1) + li, c0 = 32 * (w & 1) + li;
+    const int rmax = N - i0, cmax = N - j0;            // accumulators wholly outside the matrix are skipped
+    const bool ru[2] = {32 * (w >> 1) < rmax, 32 * (w >> 1) + 16 < rmax};
+    const bool cv[2] = {32 * (w & 1) < cmax, 32 * (w & 1) + 16 < cmax};
     for (int kc = 0; kc < j0; kc += KS) {              // half-panels: columns [kc, kc + KS) of the factor so far
         __syncthreads();
 #pragma unroll
@@ -460,17 +477,18 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
             pj.load(A, N, j0, kc + KS, N, N);
         }
         __syncthreads();
+        if (ru[0] && cv[0])
 #pragma unroll
         for (int k0 = 0; k0 < KS; k0 += 4) {
             const int kk = k0 + g;
             double a[2], b[2];
 #pragma unroll
-            for (int u = 0; u < 2; u++) { a[u] = Pi[r0 + 16 * u][kk]; b[u] = Pj[c0 + 16 * u][kk]; }
+            for (int u = 0; u < 2; u++) { a[u] = ru[u] ? Pi[r0 + 16 * u][kk] : 0.; b[u] = cv[u] ? Pj[c0 + 16 * u][kk] : 0.; }
 #pragma unroll
             for (int u = 0; u < 2; u++)
 #pragma unroll
                 for (int v = 0; v < 2; v++)
-                    acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
+                    if (ru[u] && cv[v]) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
         }
         if ((kc + KS) % CH_NB == 0) {                 // a panel is complete: its update, rounded like k_chol_update's
             TILE_FOR_EACH(u, v, r) {
@@ -494,7 +512,9 @@ static inline int chol_lower_jobs_on(hipStream_t stream, const ChJobs &J, int nj
     if (njobs <= 0) return APMF_OK;
     // few matrices: the chain of launches is what costs, so each update launch also factors the next
     // diagonal block; many: the block in a launch of its own (and 4 update blocks per CU)
-    const bool next = njobs <= CH_FUSE_JOBS;
+    // (APMF_CHOL_FUSE_JOBS overrides the threshold: tuning runs; the two routes give the same bits)
+    static const int fuse_jobs = getenv("APMF_CHOL_FUSE_JOBS") ? atoi(getenv("APMF_CHOL_FUSE_JOBS")) : CH_FUSE_JOBS;
+    const bool next = njobs <= fuse_jobs;
     constexpr size_t next_lds = 2 * (size_t)CH_NB * TP * sizeof(double);
     if (next && next_lds > 64 * 1024)      // (67.6 KB; set per call: the attribute is per device)
         (void)hipFuncSetAttribute((const void *)k_chol_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

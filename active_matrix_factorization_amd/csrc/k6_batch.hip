@@ -929,7 +929,8 @@ __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__
     tile_place(tb, sb, B);
     __syncthreads();
     f64x4 acc[2][2] = {};
-    tile_mfma<MM_NN>(acc, A, B, 64);
+    const int rmax = N - i * 64;                  // a short last block: accumulators outside the matrix are skipped
+    tile_mfma<MM_NN>(acc, A, B, 64, rmax);
     __syncthreads();
     // out = (j < k ? W_ij : 0) - acc
     TILE_FOR_EACH(u, v, r) {
@@ -942,7 +943,8 @@ __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__
         tile_place(tc, sc, A);
         __syncthreads();
         TILE_FOR_EACH(u, v, r) acc[u][v][r] = 0.;
-        tile_mfma<MM_NN>(acc, A, B, 64);
+        // (inner dimension = the rows of block i: rows of B beyond them are zero)
+        tile_mfma<MM_NN>(acc, A, B, min(64, (rmax + 3) & ~3), rmax);
     }
     TILE_FOR_EACH(u, v, r) {
         const int rr = i * 64 + tile_row(u, r), cc = j * 64 + tile_col(v);
@@ -978,7 +980,9 @@ __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restr
             tile_request(tb, src_b(k + 1));
         }
         __syncthreads();
-        tile_mfma<MM_TN>(acc, A, B, 64);
+        // rows of W beyond N are zero (a padded Linv: unit vectors whose outputs are dropped): the inner
+        // dimension of a short last block stops there, and so do the kept rows / columns of the output
+        tile_mfma<MM_TN>(acc, A, B, min(64, (N - k * 64 + 3) & ~3), N - ti * 64, N - tj * 64);
     }
     // the identity padding of a short last block must not leak into the sums: rows beyond N of a
     // padded Linv are unit vectors whose columns are beyond N too, and those outputs are dropped
