@@ -28,7 +28,9 @@
 //                 Measured (tools/bench_k2full.py): 1000 x 2000, d = 5 (400 MB streamed, past the
 //                 Infinity Cache) 0.095 ms = 4.4 TB/s = 0.55 of the HBM peak (first version 0.47 ms);
 //                 94 x 425, d = 5 (configs[3]; 8 MB, launch-bound) 11 us.
-// d > 8: k_full_grid, one thread per candidate straight from global memory (the first version,
+//   k_full_sweep_q<D>  (9 <= d <= 16: the headline rank 10 among them) four lanes per candidate, the cross block
+//                 contracted straight from LDS: see the comment at the kernel.
+// d > 16: k_full_grid, one thread per candidate straight from global memory (the first version,
 // kept as the general path).
 #include "common.h"
 
@@ -280,6 +282,251 @@ void launch_full_t(hipStream_t st, dim3 &grid, int n, int m, int ld, int rows, c
                            o_mean, want, want_sum, ps, pv, pi);
 }
 
+// ---- the sweep for 9 <= d <= 16: FOUR lanes per candidate, the cross block read from LDS -------------------
+// At d = 10 - the rank of the headline metric - a lane cannot hold its own 10 x 10 cross block, its item's
+// covariance block and the staging registers (620 VGPRs), and 64 items x d^2 doubles per wave do not fit LDS at a
+// useful occupancy.  So: one wave = 16 adjacent items x ROWS user rows, lane = (q, jj), q = lane >> 4, jj = lane & 15;
+// the four lanes of an item split every contraction (k = q, q + 4, ...) and are added with two xor-shuffles.
+//   * The cross block of (row i, 16 items) is D row segments of 16 D CONTIGUOUS doubles: coalesced 512-byte
+//     nontemporal loads, those of row r + 1 in flight while row r is contracted, staged through LDS at an odd
+//     item stride (conflict-free) - and NOT copied to registers: tr(C C) reads C[k][l] and C[l][k] straight from
+//     LDS, C a likewise (2 d^2 eight-byte LDS reads per candidate: a fifth of the LDS bandwidth at the HBM rate).
+//   * The terms without the cross block, <A + a a', Bm> + b'A b, are ONE inner product of length d (d + 1)
+//     between a per-user record X_i = [w (A + a a') | w A]  (upper triangles, w = 2 off the diagonal) and a
+//     per-item record Y_j = [Bm | b b'] packed by k_full_prep_q (Y transposed: lane-contiguous over j); a lane keeps
+//     its quarter of Y_j in registers for all its rows and reads X_i from an LDS copy of the row's record.
+// Per candidate 8 d^2 bytes streamed + 8 written, as before.
+template <int D>
+struct FullQ {
+    static constexpr int TS = D * (D + 1) / 2;         // entries of one symmetric pack
+    static constexpr int T = 2 * TS;                   // inner-product length of the cross-block-free terms
+    static constexpr int REC = T + D;                  // record: [.. | a] (users) / [.. | b] (items)
+    static constexpr int TQ = (T + 3) / 4;             // per lane
+    static constexpr int DQ = (D + 3) / 4;
+    static constexpr int DP = D | 1;                   // odd item stride in LDS
+    static constexpr int NIT = (16 * D + 63) / 64;     // 64-lane load iterations per row segment
+};
+
+__global__ __launch_bounds__(256) void k_full_prep_q(int n, int m, int d, int ld, const double *__restrict__ mean,
+                                                     const double *__restrict__ cov, double *__restrict__ xrec,
+                                                     double *__restrict__ yt)
+{
+    const size_t K = (size_t)(n + m) * d;
+    const int ts = d * (d + 1) / 2, rec = 2 * ts + d;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) {
+        const int i = t;
+        double *x = xrec + (size_t)i * rec;
+        int e = 0;
+        for (int k = 0; k < d; k++) {
+            const double ak = mean[(size_t)i * d + k];
+            x[2 * ts + k] = ak;
+            for (int l = k; l < d; l++, e++) {
+                const double A = cov[((size_t)i * d + k) * K + (size_t)i * d + l];
+                const double w = k == l ? 1. : 2.;
+                x[e] = w * (A + ak * mean[(size_t)i * d + l]);
+                x[ts + e] = w * A;
+            }
+        }
+    } else if (t < n + ld) {
+        const int j = t - n;
+        if (j < m) {
+            const size_t vb = (size_t)n * d + (size_t)j * d;
+            int e = 0;
+            for (int k = 0; k < d; k++) {
+                const double bk = mean[vb + k];
+                yt[(size_t)(2 * ts + k) * ld + j] = bk;
+                for (int l = k; l < d; l++, e++) {
+                    yt[(size_t)e * ld + j] = cov[(vb + k) * K + vb + l];
+                    yt[(size_t)(ts + e) * ld + j] = bk * mean[vb + l];
+                }
+            }
+        } else {
+            for (int e = 0; e < rec; e++) yt[(size_t)e * ld + j] = 0.;
+        }
+    }
+}
+
+// The four waves of a block share nothing (each stages its own 16 items in its own LDS region): what orders a
+// wave's LDS writes before its lanes' reads of each other's data is the in-order LDS queue of the wave itself - a
+// block barrier would only make the waves march in step and idle together on every load.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int D, int ROWS>
+__global__ __launch_bounds__(256) void k_full_sweep_q(int n, int m, int ld, const double *__restrict__ cov,
+                                                      const double *__restrict__ xrec, const double *__restrict__ yt,
+                                                      const uint8_t *__restrict__ mask, double *__restrict__ o_var,
+                                                      double *__restrict__ o_mean, int want, int want_sum,
+                                                      double *__restrict__ part_sum, double *__restrict__ part_val,
+                                                      long long *__restrict__ part_idx)
+{
+    using Q = FullQ<D>;
+    constexpr int DP = Q::DP, NIT = Q::NIT, T = Q::T, REC = Q::REC, TQ = Q::TQ, DQ = Q::DQ;
+    extern __shared__ __attribute__((aligned(16))) double q_lds[];
+    const int lane = threadIdx.x & 63, w = wave_id_uniform();
+    double *sC = q_lds + (size_t)w * (D * 16 * DP + REC);      // [D][16 * DP]
+    double *sX = sC + D * 16 * DP;                              // [REC]
+    const int q = lane >> 4, jj = lane & 15;
+    const int j0 = (blockIdx.x * 4 + w) * 16, j = j0 + jj;
+    const size_t K = (size_t)(n + m) * D;
+    const bool jin = j < m, jst = j < ld;
+    const int span = max(0, min(16, m - j0)) * D;              // valid doubles of a row segment
+    // the lane's quarter of the item record: entries q, q + 4, ... (zero beyond m: yt is padded to ld)
+    const int jc = jst ? j : 0;
+    double yq[TQ], bq[DQ];
+#pragma unroll
+    for (int s = 0; s < TQ; s++) yq[s] = (4 * s + q < T && jst) ? yt[(size_t)(4 * s + q) * ld + jc] : 0.;
+#pragma unroll
+    for (int s = 0; s < DQ; s++) bq[s] = (4 * s + q < D && jst) ? yt[(size_t)(T + 4 * s + q) * ld + jc] : 0.;
+    double s_acc = 0., bv = 0.;
+    long long bi = -1;
+    double st[D][NIT];
+    double xr[(REC + 63) / 64];
+    const int i_first = blockIdx.y * ROWS;
+#pragma unroll
+    for (int it = 0; it < (REC + 63) / 64; it++) xr[it] = 0.;
+    auto fetch = [&](int i) {
+        if (i < n && span > 0) {        // (a group of padding columns only has nothing to stage: zeros are written)
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const double *src = cov + ((size_t)i * D + k) * K + (size_t)n * D + (size_t)j0 * D;
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int e = it * 64 + lane;
+                    // (clamped address: the segment of the grid's last items may be short - masked below;
+                    // span > 0, so element 0 of the segment is inside the matrix)
+                    st[k][it] = __builtin_nontemporal_load(src + (e < span ? e : 0));
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < (REC + 63) / 64; it++) {
+                const int e = it * 64 + lane;
+                xr[it] = xrec[(size_t)i * REC + (e < REC ? e : 0)];
+            }
+        }
+    };
+    fetch(i_first);
+    for (int r = 0; r < ROWS; r++) {
+        const int i = i_first + r;
+        const bool row_ok = i < n;                  // wave-uniform
+        wave_lds_fence();                           // the previous row's reads of the tile are over
+        if (row_ok) {
+#pragma unroll
+            for (int k = 0; k < D; k++)
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int e = it * 64 + lane;
+                    if (e < 16 * D) {
+                        const int ej = e / D, el = e - ej * D;
+                        sC[k * 16 * DP + ej * DP + el] = e < span ? st[k][it] : 0.;
+                    }
+                }
+#pragma unroll
+            for (int it = 0; it < (REC + 63) / 64; it++) {
+                const int e = it * 64 + lane;
+                if (e < REC) sX[e] = xr[it];
+            }
+        }
+        wave_lds_fence();
+        if (r + 1 < ROWS) fetch(i + 1);
+        if (!row_ok) continue;
+        const double *cj = sC + jj * DP;            // this item's block: C[k][l] = cj[k * 16 * DP + l]
+        double g = 0., ab = 0., trCC = 0., bCa = 0., trC = 0.;
+#pragma unroll
+        for (int s = 0; s < TQ; s++) g += (4 * s + q < T ? sX[4 * s + q] : 0.) * yq[s];
+#pragma unroll
+        for (int s = 0; s < DQ; s++) {
+            const int k = 4 * s + q;
+            if (k < D) {                            // (lanes of the last quarter idle when 4 does not divide D)
+                double Ca = 0., cc = 0.;
+#pragma unroll
+                for (int l = 0; l < D; l++) {
+                    const double ckl = cj[k * 16 * DP + l];
+                    Ca += ckl * sX[T + l];
+                    cc += ckl * cj[l * 16 * DP + k];
+                }
+                bCa += bq[s] * Ca;
+                trCC += cc;
+                trC += cj[k * 16 * DP + k];
+                ab += sX[T + k] * bq[s];
+            }
+        }
+        double var = g + trCC + 2. * bCa, mn = ab + trC;
+        var += __shfl_xor(var, 16, 64);
+        var += __shfl_xor(var, 32, 64);
+        mn += __shfl_xor(mn, 16, 64);
+        mn += __shfl_xor(mn, 32, 64);
+        if (q == 0 && jst) {
+            if (o_var) o_var[(size_t)i * ld + j] = jin ? var : 0.;
+            if (o_mean) o_mean[(size_t)i * ld + j] = jin ? mn : 0.;
+        }
+        if (want || want_sum) {
+            const bool cand = q == 0 && jin && (!mask || mask[(size_t)i * ld + j]);
+            if (cand) {
+                s_acc += var;
+                const long long idx = (long long)i * m + j;
+                if (bi < 0 || (want > 0 ? var > bv : var < bv)) { bv = var; bi = idx; }
+            }
+        }
+    }
+    if (want || want_sum) {
+        double s = wave_sum(s_acc);
+        if (want) wave_argext(bv, bi, want);
+        __shared__ double sh_s[4], sh_v[4];
+        __shared__ long long sh_i[4];
+        __syncthreads();
+        if (lane == 0) { sh_s[w] = s; sh_v[w] = bv; sh_i[w] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int x = 1; x < 4; x++) {
+                s += sh_s[x];
+                if (want) argext_merge(bv, bi, sh_v[x], sh_i[x], want);
+            }
+            const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            part_sum[slot] = s; part_val[slot] = bv; part_idx[slot] = bi;
+        }
+    }
+}
+
+// user rows per wave (the item record stays in registers for all of them): as many as still leave >= 2 blocks per CU
+static inline int full_q_rows(int n, int ld)
+{
+    const size_t col_blocks = (size_t)(ld / 16 + 3) / 4;
+    for (int rows = 16; rows > 4; rows >>= 1)
+        if (col_blocks * ((n + rows - 1) / rows) >= 512) return rows;
+    return 4;
+}
+
+template <int D, int ROWS>
+int launch_full_q_rows(hipStream_t st, dim3 grid, int n, int m, int ld, const double *cov, const double *xrec,
+                       const double *yt, const uint8_t *mask, double *o_var, double *o_mean, int want, int want_sum,
+                       double *ps, double *pv, long long *pi)
+{
+    using Q = FullQ<D>;
+    const size_t lds = 4 * (size_t)(D * 16 * Q::DP + Q::REC) * sizeof(double);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)k_full_sweep_q<D, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return 1;
+    hipLaunchKernelGGL((k_full_sweep_q<D, ROWS>), grid, dim3(256), lds, st, n, m, ld, cov, xrec, yt, mask, o_var, o_mean,
+                       want, want_sum, ps, pv, pi);
+    return 0;
+}
+
+template <int D>
+int launch_full_q(hipStream_t st, dim3 grid, int rows, int n, int m, int ld, const double *cov, const double *xrec,
+                  const double *yt, const uint8_t *mask, double *o_var, double *o_mean, int want, int want_sum, double *ps,
+                  double *pv, long long *pi)
+{
+    if (rows == 16) return launch_full_q_rows<D, 16>(st, grid, n, m, ld, cov, xrec, yt, mask, o_var, o_mean, want, want_sum, ps, pv, pi);
+    if (rows == 8) return launch_full_q_rows<D, 8>(st, grid, n, m, ld, cov, xrec, yt, mask, o_var, o_mean, want, want_sum, ps, pv, pi);
+    return launch_full_q_rows<D, 4>(st, grid, n, m, ld, cov, xrec, yt, mask, o_var, o_mean, want, want_sum, ps, pv, pi);
+}
+
 __global__ __launch_bounds__(256) void k_full_finish(int nblk, int want, const double *__restrict__ part_sum,
                                                      const double *__restrict__ part_val,
                                                      const long long *__restrict__ part_idx,
@@ -331,12 +578,17 @@ extern "C" int apmf_full_score_grid_f64(apmf_ctx *ctx, int n, int m, int d, int 
     // compile-time rank (d <= 8): ROWS user rows per wave, 8 when that still fills the machine
     int rows_t = 0;
     if (d >= 2 && d <= 8) rows_t = (size_t)((ld + 63) / 64) * ((n + 31) / 32) >= 1024 ? 8 : 2;
+    bool quad = d >= 9 && d <= 16;                // four lanes per candidate, 16 items x qrows rows per wave
+    const int qrows = full_q_rows(n, ld);
     if (const char *e = getenv("APMF_K2FULL_KERNEL"))
-        if (!strcmp(e, "general")) rows_t = 0;
-    dim3 grid = rows_t ? dim3((ld + 63) / 64, (n + 4 * rows_t - 1) / (4 * rows_t)) : dim3((m + 255) / 256, n);
+        if (!strcmp(e, "general")) { rows_t = 0; quad = false; }
+    dim3 grid = rows_t ? dim3((ld + 63) / 64, (n + 4 * rows_t - 1) / (4 * rows_t))
+                       : quad ? dim3((ld / 16 + 3) / 4, (n + qrows - 1) / qrows) : dim3((m + 255) / 256, n);
     const size_t nblk = (size_t)grid.x * grid.y;
     const size_t dd = (size_t)d * d;
-    const size_t pack_doubles = rows_t ? (size_t)n * (2 * dd + d) + (dd + d) * (size_t)ld : 0;
+    const size_t qrec = (size_t)d * (d + 1) + d;
+    const size_t pack_doubles = rows_t ? (size_t)n * (2 * dd + d) + (dd + d) * (size_t)ld
+                                       : quad ? qrec * ((size_t)n + ld) : 0;
     void *w;
     APMF_TRY(apmf_ws(ctx, 1, nblk * 24 + pack_doubles * sizeof(double) + 64, &w));
     double *part_sum = (double *)w;
@@ -354,6 +606,20 @@ extern "C" int apmf_full_score_grid_f64(apmf_ctx *ctx, int n, int m, int d, int 
         FULL_T(2) FULL_T(3) FULL_T(4) FULL_T(5) FULL_T(6) FULL_T(7) FULL_T(8)
 #undef FULL_T
         }
+    } else if (quad) {
+        double *xrec = (double *)(part_idx + nblk);
+        double *yt = xrec + (size_t)n * qrec;
+        hipLaunchKernelGGL(k_full_prep_q, dim3((n + ld + 255) / 256), dim3(256), 0, ctx->stream, n, m, d, ld, d_mean,
+                           d_cov, xrec, yt);
+        ProfScope prof(ctx);
+        const int ws = d_sum != nullptr;
+        int bad = 0;
+        switch (d) {
+#define FULL_Q(DV) case DV: bad = launch_full_q<DV>(ctx->stream, grid, qrows, n, m, ld, d_cov, xrec, yt, d_mask, d_var, d_pmean, want, ws, part_sum, part_val, part_idx); break;
+        FULL_Q(9) FULL_Q(10) FULL_Q(11) FULL_Q(12) FULL_Q(13) FULL_Q(14) FULL_Q(15) FULL_Q(16)
+#undef FULL_Q
+        }
+        APMF_REQUIRE(!bad, "hipFuncSetAttribute(dynamic LDS) failed");
     } else {
         const size_t smem = ((size_t)d * d + d) * sizeof(double);
         ProfScope prof(ctx);

@@ -546,6 +546,52 @@ def test_full_grid_golden(ctx, name):
     assert abs(dsum.to_host()[0] - g['pool_vals'].sum()) <= 1e-11 * abs(g['pool_vals'].sum())
 
 
+@pytest.mark.parametrize('shape', [(9, 17, 9), (23, 70, 10), (8, 16, 10), (1, 15, 12), (17, 65, 13), (10, 129, 16),
+                                   (33, 31, 11), (64, 64, 10)])
+def test_full_grid_quad_kernel(ctx, shape, monkeypatch):
+    """The sweep for 9 <= d <= 16 (k_full_sweep_q: four lanes per candidate, cross block contracted from LDS; d = 10
+    is the headline rank) against the oracle's restatement of normal_exps_cy.exp_dotprod_sq (normal_exps_cy.pyx:111-135)
+    and against the general one-thread-per-candidate kernel: values, masked sum, arg-max and arg-min; item counts
+    that leave short and padding-only groups of 16, row counts that leave a short last group of 8."""
+    from active_matrix_factorization_amd._lib import grid_ld
+    n, m, d = shape
+    rs = np.random.RandomState(n * 1000 + m * 10 + d)
+    K = (n + m) * d
+    a = rs.normal(size=(K, K)) / np.sqrt(K)
+    cov = a @ a.T + .05 * np.eye(K)
+    mean = rs.normal(size=K)
+    ld = grid_ld(m)
+    mask = rs.rand(n, m) < .7
+    mask[0, 0] = True
+    dmask = ctx.upload_grid(mask.astype(np.uint8), np.uint8, ld=ld)
+    dm, dc = ctx.array(mean), ctx.array(cov)
+    pm0, pv0, e2 = orc.full_pred_means_vars(n, m, d, mean, cov, want_e2=True)
+    res = {}
+    for kern in ('quad', 'general'):
+        if kern == 'general':
+            monkeypatch.setenv('APMF_K2FULL_KERNEL', 'general')
+        for want in (1, -1):
+            var, pm = ctx.empty((n, ld)), ctx.empty((n, ld))
+            dsum, bv, bi = ctx.empty(1), ctx.empty(1), ctx.empty(1, np.int64)
+            ctx.full_score_grid(n, m, d, ld, dm, dc, mask=dmask, var=var, pmean=pm, dsum=dsum, want=want, best_val=bv,
+                                best_idx=bi)
+            v, p = ctx.download_grid(var, m), ctx.download_grid(pm, m)
+            assert np.all(np.abs(v - pv0) <= 256 * EPS * np.abs(e2)), kern
+            assert np.all(np.abs(p - pm0) <= 256 * EPS * (np.abs(pm0) + np.sqrt(np.abs(e2)))), kern
+            assert not var.to_host()[:, m:].any() and not pm.to_host()[:, m:].any()        # padding written as zeros
+            b = int(bi.to_host()[0])
+            cand = np.where(mask, v, -np.inf if want > 0 else np.inf)
+            k = int(np.argmax(cand)) if want > 0 else int(np.argmin(cand))
+            assert b == k and bv.to_host()[0] == v.ravel()[k], (kern, want)
+            assert abs(dsum.to_host()[0] - v[mask].sum()) <= 1e-12 * abs(v[mask].sum())
+            res[kern, want] = (b, v)
+        # sum only (no grid written)
+        dsum = ctx.empty(1)
+        ctx.full_score_grid(n, m, d, ld, dm, dc, dsum=dsum)
+        assert abs(dsum.to_host()[0] - pv0.sum()) <= 1e-11 * abs(pv0.sum())
+    assert res['quad', 1][0] == res['general', 1][0] and res['quad', -1][0] == res['general', -1][0]
+
+
 # ---------------------------------------------------------------------------- K3 / K4
 BAYES_CASES = ['bayes_20x15_d4', 'bayes_c1_10x10_d2', 'bayes_100x90_d15']
 

@@ -44,7 +44,10 @@ def run(ctx, n, m, d, reps=10):
 
 def main():
     ctx = _lib.Context(0)
-    res = [run(ctx, 94, 425, 5), run(ctx, 1000, 2000, 5), run(ctx, 600, 900, 10, reps=5)]
+    # d = 10 is the rank of the headline metric; 600 x 900 and 800 x 1000 stream 436 MB / 1.1 GB (d = 16) past the
+    # 256 MB Infinity Cache
+    res = [run(ctx, 94, 425, 5), run(ctx, 1000, 2000, 5), run(ctx, 600, 900, 10, reps=5), run(ctx, 400, 700, 16, reps=5),
+           run(ctx, 1000, 1500, 10, reps=3), run(ctx, 94, 425, 10)]
     print(json.dumps(res, indent=1))
 
 
