@@ -125,6 +125,73 @@ def _parallel_map(fn, items, procs=None):
     return list(_workers.map(gated, items))
 
 
+# 21-point Gauss-Kronrod abscissae of QUADPACK's dqk21, in the order the routine evaluates its integrand:
+# the centre, then +- the 10-point Gauss nodes' neighbours (xgk(2), xgk(4), ...), then +- xgk(1), xgk(3), ...
+_XGK21 = (0.995657163025808080735527280689003, 0.973906528517171720077964012084452,
+          0.930157491355708226001207180059508, 0.865063366688984510732096688423493,
+          0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+          0.562757134668604683339000099272694, 0.433395394129247190799265943165784,
+          0.294392862701460198131126603103866, 0.148874338981631210884826001129720)
+_quad_patch_lock = threading.Lock()
+
+
+def _gk21_points(a, b):
+    """The 21 points dqk21 evaluates on [a, b], with its arithmetic (centr +- hlgth * xgk)."""
+    centr, hlgth = 0.5 * (a + b), 0.5 * (b - a)
+    pts = [centr]
+    for idx in (1, 3, 5, 7, 9, 0, 2, 4, 6, 8):
+        absc = hlgth * _XGK21[idx]
+        pts += [centr - absc, centr + absc]
+    return pts
+
+
+class _Quadrature(object):
+    """What stats.norm.expect(f, loc=mean, scale=std, lb=left, ub=right, epsrel=.02) - the call of the reference's
+    continuous lookahead (mn_active_pmf.py:686-691) - will evaluate f at, known BEFORE f is: the first Gauss-Kronrod
+    pass over each of its intervals does not depend on the integrand (found by running that very call on a constant
+    integrand: zero error estimate, no interval is bisected - so it is right for whichever SciPy is installed), and
+    when the adaptive routine later bisects an interval it evaluates the 21 points of each half, which follow from
+    the interval's end points (captured from the integrate.quad calls of the dry run; QUADPACK's dqagse / dqk21
+    arithmetic, checked against the dry run's own first pass and switched off if it does not reproduce it)."""
+
+    def __init__(self, mean, std, left, right):
+        import scipy.integrate
+        seen, bounds = [], []
+        me = threading.get_ident()
+
+        def constant(v):
+            seen.append(float(v))
+            return 1.
+
+        with _quad_patch_lock:
+            orig = scipy.integrate.quad
+
+            def spy(func, a, b, *args, **kw):
+                if threading.get_ident() == me:
+                    bounds.append((float(a), float(b)))
+                return orig(func, a, b, *args, **kw)
+            scipy.integrate.quad = spy
+            try:
+                stats.norm.expect(constant, loc=mean, scale=std, lb=left, ub=right, epsrel=.02)
+            finally:
+                scipy.integrate.quad = orig
+        self.first_pass = seen
+        predicted = [v for a, b in bounds for v in _gk21_points(a, b)]
+        self.intervals = list(bounds) if predicted == seen else None
+
+    def bisection_points(self, v):
+        """v was asked for and is not known: if it is the centre of the left half of a tracked interval, that
+        interval is being bisected - the 42 points of its two halves; else None."""
+        if self.intervals is None:
+            return None
+        for idx, (a, b) in enumerate(self.intervals):
+            mid = 0.5 * (a + b)
+            if 0.5 * (a + mid) == v:
+                self.intervals[idx:idx + 1] = [(a, mid), (mid, b)]
+                return _gk21_points(a, mid) + _gk21_points(mid, b)
+        return None
+
+
 class _Evaluator(object):
     """Picklable `key(ij)` callable (the reference's *Evaluator classes)."""
 
@@ -521,6 +588,7 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
         return self._exp_with_rij(ij, type(self)._total_variance, use_map=False)
 
     # -- one-step lookahead (mn_active_pmf.py:627-696) -------------------------------------------
+    quadrature_limit = 50             # subdivisions of the continuous lookahead's quadrature (scipy's default)
     _approx_init_uses_rng = False     # initialize_approx() draws from np.random (ActivePMF)
 
     def _hypothesis_model(self, i, j, v):
@@ -600,13 +668,47 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             return out
         if discretize and points is None:
             warnings.warn("{} has no rating_values; doing integral".format(type(self).__name__))
-        for (i, j), mean, var in zip(pool, means, variances):
+        # Continuous integration: scipy's adaptive quadrature (QUADPACK, 21-point Gauss-Kronrod per interval) asks
+        # for one rating value at a time - but the points of its FIRST pass over every interval do not depend on the
+        # integrand: a dry run with a constant integrand lists them, the hypotheses (candidate, point) of the whole
+        # pool are then evaluated as ONE batch, and the real quadrature is served from that cache.  A point it asks
+        # for beyond the first pass (an interval it decides to bisect) is evaluated on its own, as before.  The
+        # hypotheses are independent, so every value - and the integral - is the one-at-a-time result bit for bit.
+        spans = []
+        for mean, var in zip(means, variances):
             std = math.sqrt(var)
-            left, right = mean - 2 * std, mean + 2 * std
-            # adaptive quadrature asks for one rating value at a time
-            est = stats.norm.expect(
-                lambda v: self._hypothesis_values([(i, j, float(v))], fn, pass_v, 1)[0],
-                loc=mean, scale=std, lb=left, ub=right, epsrel=.02)
+            spans.append((mean, std, mean - 2 * std, mean + 2 * std))
+        caches = [dict() for _ in pool]
+        plans = [None] * len(pool)
+        if lookahead_batched() and len(pool) > 0:
+            hyps, owner = [], []
+            for c, ((i, j), span) in enumerate(zip(pool, spans)):
+                plans[c] = _Quadrature(*span)
+                for v in plans[c].first_pass:
+                    if v not in caches[c]:
+                        caches[c][v] = None
+                        hyps.append((i, j, v))
+                        owner.append(c)
+            if hyps:
+                for (i, j, v), c, val in zip(hyps, owner, self._hypothesis_values(hyps, fn, pass_v, procs)):
+                    caches[c][v] = val
+        for (i, j), (mean, std, left, right), cache, plan in zip(pool, spans, caches, plans):
+            def integrand(v, i=i, j=j, cache=cache, plan=plan):
+                v = float(v)
+                val = cache.get(v)
+                if val is None:
+                    more = plan.bisection_points(v) if plan is not None else None
+                    if more and v in more:
+                        # the interval being bisected: the 21 points of each half as one batch
+                        new = [x for x in dict.fromkeys(more) if cache.get(x) is None]
+                        for x, y in zip(new, self._hypothesis_values([(i, j, x) for x in new], fn, pass_v, procs)):
+                            cache[x] = y
+                        val = cache[v]
+                    else:
+                        val = cache[v] = self._hypothesis_values([(i, j, v)], fn, pass_v, 1)[0]
+                return val
+            est = stats.norm.expect(integrand, loc=mean, scale=std, lb=left, ub=right, epsrel=.02,
+                                    limit=self.quadrature_limit)
             s = "from {:5.1f} to {:5.1f}".format(left, right)
             print("\t{:>20}({},{}) {}: {: 10.2f}".format(name, i, j, s, est))
             out.append(est)

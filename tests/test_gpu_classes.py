@@ -966,6 +966,42 @@ def test_lookahead_batched_equals_per_hypothesis(pkg, monkeypatch, key):
         assert batched == alone
 
 
+def test_lookahead_continuous_batched_equals_one_at_a_time(pkg, monkeypatch):
+    """The CONTINUOUS lookahead (no rating_values: the class default; mn_active_pmf.py:686-691 integrates the
+    criterion over R_ij with stats.norm.expect = adaptive Gauss-Kronrod quadrature, one rating value per call): the
+    first pass of the quadrature over every interval - 21 points each, known before any value is - is evaluated for
+    the whole pool as ONE device batch and the quadrature served from it; bit for bit the integral of the
+    one-hypothesis-at-a-time evaluation (APMF_LOOKAHEAD_BATCH=0)."""
+    g = load_golden('lookahead_c1_mn')
+    a = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=2)          # rating_values=None: continuous ratings
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+    a.quadrature_limit = 3                       # (the integrand is a stopped search: the quadrature never converges)
+    pool = sorted(a.unrated)[:2]
+    from active_matrix_factorization_amd import _active_base as base
+    calls = []
+    real = pkg.mn.MNActivePMF._lookahead_batch_local
+
+    def spy(self, hyps, fn, pass_v):
+        calls.append(len(hyps))
+        return real(self, hyps, fn, pass_v)
+    monkeypatch.setattr(pkg.mn.MNActivePMF, '_lookahead_batch_local', spy)
+    import warnings
+    for key in ('total-variance', 'total-variance-approx'):
+        k = pkg.mn.KEY_FUNCS[key]
+        calls.clear()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')          # IntegrationWarning: the subdivision limit
+            batched = a._get_key_vals(pool, k)
+            nodes = len(base._Quadrature(0., 1., -2., 2.).first_pass)
+            # one batch for the first pass of the whole pool, then one batch of <= 42 per bisected interval
+            assert calls[0] == len(pool) * nodes and all(1 < c <= 42 for c in calls[1:]), calls
+            monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', '0')
+            alone = a._get_key_vals(pool[:1], k, procs=1)
+            monkeypatch.delenv('APMF_LOOKAHEAD_BATCH')
+        assert batched[0] == alone[0] and np.isfinite(batched).all(), key
+
+
 def test_lookahead_batched_refit_equals_per_hypothesis(pkg, monkeypatch):
     """--refit-lookahead: every hypothesis re-fits the MAP estimate first and restarts the
     approximation from it (mn_active_pmf.py:662-665)."""
