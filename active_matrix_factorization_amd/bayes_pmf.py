@@ -375,24 +375,23 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
                     chain.append((hu, hv, zs))
                 draws.append(chain)
             # ---- starting points: the model's MAP factors, re-fitted with the extra rating if fit_first
-            U0 = np.empty((H, n, d))
-            V0 = np.empty((H, m, d))
             mean_sub = np.zeros(H)
+            means_plus = np.zeros(H)
             for h, (_c, _k, i, j, v) in enumerate(part):
-                plus = np.vstack([base, [i, j, v]])
-                mr = float(np.mean(plus[:, 2]))
-                mean_sub[h] = mr if self.subtract_mean else 0.
-                if fit_first:
-                    rth = ctx.ratings(plus, n, m)
-                    dU, dV = ctx.array(self.users, np.float64), ctx.array(self.items, np.float64)
-                    ctx.pmf_fit_lls(rth, dU, dV, d, sig[0], sig[1], sig[2], self.subtract_mean, mr,
-                                    float(self.learning_rate), float(self.min_learning_rate),
-                                    float(self.stop_thresh), max_steps=-1, max_trace=0)
-                    U0[h], V0[h] = dU.to_host(), dV.to_host()
-                    rth.free()
-                else:
-                    U0[h], V0[h] = self.users, self.items
+                # the mean add_rating() leaves behind (pmf_cy.pyx:152-153): np.mean of the extended column
+                means_plus[h] = float(np.mean(np.append(base[:, 2], v)))
+                mean_sub[h] = means_plus[h] if self.subtract_mean else 0.
+            U0 = np.ascontiguousarray(np.broadcast_to(self.users, (H, n, d)), np.float64)
+            V0 = np.ascontiguousarray(np.broadcast_to(self.items, (H, m, d)), np.float64)
             d_users, d_items = ctx.array(U0), ctx.array(V0)
+            if fit_first:
+                # the MAP re-fit of every hypothesis (bayes_pmf.py:240 under samples(fit_first=True)): all H fit_lls
+                # searches as ONE chain of launches over the shared container (apmf_pmf_batch_fit_lls: bit-identical
+                # to H fits on containers rebuilt with the hypothesis' rating)
+                ctx.pmf_batch_fit_lls(rt, d_users, d_items, d, H, [p[2] for p in part], [p[3] for p in part],
+                                      [p[4] for p in part], sig[0], sig[1], sig[2], self.subtract_mean, means_plus,
+                                      float(self.learning_rate), float(self.min_learning_rate), float(self.stop_thresh))
+                U0, V0 = d_users.to_host(), d_items.to_host()
             d_ms = ctx.array(mean_sub)
             d_ei = ctx.array(np.array([p[2] for p in part], np.int32), np.int32)
             d_ej = ctx.array(np.array([p[3] for p in part], np.int32), np.int32)
