@@ -96,6 +96,44 @@ def test_batch_kl_and_gradient_vs_numpy(ctx, shape):
     b.free()
 
 
+@pytest.mark.parametrize('shape', [(20, 13, 3), (40, 23, 2), (17, 15, 4), (50, 15, 5), (2, 31, 2)])
+def test_batch_trial_point_edge_shapes(ctx, shape):
+    """kb_trial_S forms the trial point in 32 x 32 tiles whose loads are all issued up front at addresses CLAMPED to
+    the matrix (min(row, N - 1), min(col, N - 1): always inside the N x N array, masked afterwards - VERDICT r2 #9):
+    matrix sizes one past / one short of / exactly on a tile edge (N = 33, 63, 32, 65, 33; the last with two users only).  One accepted step at a
+    tiny learning rate must land on  sym(S - lr g_S), mean - lr g_mean, sym(Omega - lr g_Omega)  with the gradient the
+    engine itself reports (checked against NumPy above), element by element - under the suite's memory poisoning a
+    stray read would show as NaN."""
+    n, m, d = shape
+    N = n + m
+    rs, ratings, mean, S, O = _problem(n, m, d, 77 * n + m)
+    sig, su, sv = 1., 10., 10.
+    rt = ctx.ratings(ratings, n, m)
+    b = ctx.mn_batch(rt, d, 2)
+    ex = _unrated(rs, ratings, n, m, 1)[0]
+    b.set_state(ctx.array(mean), ctx.array(S), ctx.array(O))
+    b.set_extra([ex[0], -1], [ex[1], -1], [2., 0.])
+    lr0 = 1e-7
+    grads = []
+    for h in range(2):
+        gm, gs, go = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+        b.gradient(h, sig, su, sv, gm, gs, go)
+        grads.append((gm.to_host(), gs.to_host(), go.to_host()))
+    lr, kl, nsteps, conv, _ = b.fit(sig, su, sv, 1e-5, lr0, max_steps=1)
+    assert list(nsteps) == [1, 1] and np.allclose(lr, 1.25 * lr0)          # first trial accepted
+    for h in range(2):
+        dm, ds, do = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+        b.get_state(h, dm, ds, do)
+        gm, gs, go = grads[h]
+        cs = S - lr0 * gs
+        co = O - lr0 * go
+        assert np.isfinite(ds.to_host()).all()
+        np.testing.assert_allclose(ds.to_host(), (cs + cs.T) / 2, rtol=1e-14, atol=1e-16)
+        np.testing.assert_allclose(dm.to_host(), mean - lr0 * gm, rtol=1e-14, atol=1e-16)
+        np.testing.assert_allclose(do.to_host(), (co + co.T) / 2, rtol=1e-14, atol=1e-16)
+    b.free()
+
+
 @pytest.mark.parametrize('name', ['mn_c1_10x10_d2_eye', 'mn_c1_10x10_d2_rand', 'mn_24x17_d5_rand'])
 def test_batch_fit_golden_trace(ctx, name):
     """Three accepted fit_normal_kls steps of the reference (mn_active_pmf.py:242-288), run as

@@ -826,6 +826,43 @@ def test_rank64_paths(ctx):
     np.testing.assert_allclose(out.to_host()[:50], ref, rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize('case', ['tail_rows_empty', 'short_tail_block', 'long_row_4_waves'])
+def test_pmf_gradient_ll_edge_shapes(ctx, case):
+    """K1's row kernels issue every load of a trip unconditionally, entries past the end of a row read at the row's
+    LAST entry and masked afterwards: that address is inside the array because a wave only enters
+    the loop when its share of the row is non-empty (span > 0, so end - 1 >= beg).  Shapes whose last block of 4
+    row slots is mostly padding, whose trailing rows have no rating at all, and a row split over 4 waves of which
+    the last ones get nothing: gradient and log-likelihood against the oracle, under the suite's memory poisoning."""
+    rs = np.random.RandomState(len(case))
+    if case == 'tail_rows_empty':
+        n, m, d = 6, 9, 3                      # users 4, 5 and items 7, 8 have no rating
+        ii, jj = rs.randint(0, 4, 25), rs.randint(0, 7, 25)
+    elif case == 'short_tail_block':
+        n, m, d = 5, 2, 10                     # 7 row slots: the second block of 4 holds 3 rows
+        ii, jj = rs.randint(0, n, 9), rs.randint(0, m, 9)
+    else:
+        n, m, d = 2, 150, 4                    # 120 ratings over 2 users: 60 per row -> 4 waves per row (>= 48)
+        ii, jj = np.repeat([0, 1], [117, 3]), np.concatenate([rs.permutation(m)[:117], [0, 1, 2]])
+    keep = np.sort(np.unique(ii * m + jj, return_index=True)[1])
+    ii, jj = ii[keep], jj[keep]
+    ratings = np.column_stack([ii, jj, rs.normal(size=ii.size)]).astype(float)
+    U, V = rs.normal(size=(n, d)), rs.normal(size=(m, d))
+    rt = ctx.ratings(ratings, n, m)
+    dU, dV, gU, gV = ctx.array(U), ctx.array(V), ctx.empty((n, d)), ctx.empty((m, d))
+    ctx.pmf_gradient(rt, dU, dV, d, 1., 10., 10., False, 0., gU, gV)
+    oU, oV = orc.pmf_gradient(ratings, U, V)
+    np.testing.assert_allclose(gU.to_host(), oU, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(gV.to_host(), oV, rtol=1e-12, atol=1e-13)
+    ll, _ = ctx.pmf_log_likelihood(rt, dU, dV, d, 1., 10., 10., False, 0.)
+    assert abs(ll - orc.pmf_log_likelihood(ratings, U, V)) <= 1e-12 * abs(ll)
+    tr, steps, lr, conv = ctx.pmf_fit_lls(rt, dU, dV, d, 1., 10., 10., False, 0., 1e-4, 1e-10, 1e-2, max_steps=5)
+    oUf, oVf, otr = orc.pmf_fit_lls(ratings, U, V, max_steps=5)
+    assert steps == otr.size
+    np.testing.assert_allclose(tr, otr, rtol=1e-11)
+    np.testing.assert_allclose(dU.to_host(), oUf, rtol=1e-10, atol=1e-12)
+    rt.free()
+
+
 def _batch_fit_case(ctx, ratings, n, m, d, hyps, subtract_mean=False, max_steps=40, seed=0):
     """H batched re-fits (apmf_pmf_batch_fit_lls) against H separate apmf_pmf_fit_lls calls on containers REBUILT
     with the hypothesis' rating appended: factors, log-likelihood and step counts must agree bit for bit."""
