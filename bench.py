@@ -83,6 +83,11 @@ def main():
     ap.add_argument('--states', type=int, default=256, help='posterior states per sweep (B)')
     ap.add_argument('--grad-steps-per-call', type=int, default=25)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--workload', choices=('c2', 'c5'), default='c2',
+                    help="c2: the metric's 943x1682-d10-B256 workload (default); c5: BASELINE.json configs[4] - ONE fixed "
+                         "100000x20000 rank-64 problem, 5e7 ratings, row-sharded over the ranks (strong scaling)")
+    ap.add_argument('--c5-rows', type=int, default=100000, help='user rows of the c5 workload (reduce for rehearsals)')
+    ap.add_argument('--c5-ratings', type=int, default=50000000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-class-level', action='store_true')
     ap.add_argument('--no-f64', action='store_true', help='skip the float64 sweep legs (roofline_f64)')
@@ -122,6 +127,14 @@ def main():
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
     strong = args.scaling == 'strong'
+    if args.workload == 'c5':
+        out = bench_c5(args, ctx, comm, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        comm.barrier()
+        comm.close()
+        ctx.close()
+        return
 
     def max_over_ranks(x):
         return float(comm.all_gather_scalars([x]).max())
@@ -295,6 +308,104 @@ def main():
     comm.barrier()
     comm.close()
     ctx.close()
+
+
+def bench_c5(args, ctx, comm, rank, world):
+    """BASELINE.json configs[4] as ONE fixed problem, strong-scaled: 100 000 x 20 000, rank 64,
+    5e7 ratings.  Rank g keeps its block of user rows of the Sigma cross block and of the candidate mask RESIDENT
+    (f32, what the batched API streams) and the whole ratings container; a scoring step = every rank sweeps its rows
+    (scores written + sum + arg-max over unrated) and ONE all-gather of the (sum, value, index) record per rank; the
+    PMF half = ONE fit_lls row-sharded over the ranks (sharding.sharded_fit_lls: one grouped all-gather per trial).
+    value = candidates of the WHOLE grid per second.  At N = 1 this is configs[4] on one GPU."""
+    from active_matrix_factorization_amd import _lib, sharding
+    n, m, d, N = args.c5_rows, 20000, 64, args.c5_ratings
+    K, W = min(args.steps, 50), min(args.warmup, 5)
+    lo, hi = sharding.block_range(n, rank, world)
+    nl = hi - lo
+    ld = _lib.grid_ld(m)
+    rs = np.random.RandomState(5)                      # the same problem on every rank
+    flat = np.unique(rs.randint(0, n * m, size=int(N * 1.04), dtype=np.int64))
+    flat = flat[rs.permutation(flat.size)[:N]]
+    N = flat.size
+    ratings = np.empty((N, 3))
+    ratings[:, 0], ratings[:, 1] = flat // m, flat % m
+    ratings[:, 2] = rs.randint(1, 6, size=N)
+    U, V = .35 * rs.standard_normal((n, d)), .35 * rs.standard_normal((m, d))
+    A = rs.standard_normal((d, d)) / np.sqrt(d)
+    omega = (A @ A.T).astype(np.float32)
+    diag = (1. + rs.random_sample(n + m)).astype(np.float32)
+    period = 1024
+    blk = (.3 * rs.standard_normal((period, m))).astype(np.float32)
+    # this rank's rows, resident: cross block, mask, [U rows ; V], [diag rows ; diag items]
+    d_cross = ctx.zeros((max(nl, 1), ld), np.float32)
+    for r0 in range(lo, hi, period):
+        k = min(period - r0 % period, hi - r0)
+        _lib._check(ctx._lib.apmf_h2d_2d(ctx._h, d_cross.ptr + (r0 - lo) * ld * 4, ld * 4,
+                                         blk[r0 % period:].ctypes.data, m * 4, m * 4, k))
+    mine = (flat // m >= lo) & (flat // m < hi)
+    cand = np.ones((max(nl, 1), m), np.uint8)
+    cand[flat[mine] // m - lo, flat[mine] % m] = 0
+    d_mask = ctx.upload_grid(cand, np.uint8, ld=ld)
+    del cand, flat
+    d_mean = ctx.array(np.vstack([U[lo:hi], V]).astype(np.float32))
+    d_diag = ctx.array(np.concatenate([diag[lo:hi], diag[n:]]))
+    d_omega = ctx.array(omega)
+    d_var = ctx.empty((max(nl, 1), ld), np.float32)
+    rec = ctx.zeros(4)                                   # [sum f64 | value f32 .. | index i64]
+    libc = _lib.load_comm() if comm.has_rccl else None
+
+    def step():
+        if nl:
+            ctx.mn_score_grid(np.float32, 1, nl, m, d, ld, d_mean, d_cross, d_diag, d_omega, mask=d_mask, var=d_var,
+                              dsum=rec.ptr, want=1, best_val=rec.ptr + 8, best_idx=rec.ptr + 16)
+        return comm.all_gather_multi([rec])[0]
+
+    for _ in range(W):
+        step()
+    comm.barrier()
+    ctx.profile_begin(min(K, 1024))
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        got = step()
+    comm.barrier()
+    t_score = float(comm.all_gather_scalars([time.perf_counter() - t0]).max())
+    kern_ms = ctx.profile_end()
+    kern_ms = kern_ms[kern_ms > 0]
+    sums = got.to_host()[:, 0]
+    if not (np.isfinite(sums).all() and (sums > 0).sum() >= min(world, n)):
+        sys.exit('bench.py: the exchanged per-rank results are not valid on rank %d' % rank)
+    # ---- the PMF half: ONE fit, row-sharded
+    eng = sharding.HipEngine(ctx, ratings, n, m, d)
+    Kg = 6
+    sharding.sharded_fit_lls(eng, comm, U, V, n, m, learning_rate=1e-6, min_learning_rate=1e-12, stop_thresh=0., max_steps=1)
+    comm.barrier()
+    t0 = time.perf_counter()
+    _, _, tr = sharding.sharded_fit_lls(eng, comm, U, V, n, m, learning_rate=1e-6, min_learning_rate=1e-12, stop_thresh=0.,
+                                        max_steps=Kg)
+    comm.barrier()
+    t_grad = float(comm.all_gather_scalars([time.perf_counter() - t0]).max())
+    if rank != 0:
+        return None
+    avg_ms = float(kern_ms.mean()) if kern_ms.size else None
+    algo = 8. * nl * m
+    ach = algo / (avg_ms * 1e-3) / 1e9 if avg_ms else None
+    gs_bytes = N * (12 + 16 * d) + N * (12 + 8 * d) + 16 * (n + m) * d
+    return {'metric': 'candidate (i,j) scores/sec + PMF grad-steps/sec, configs[4] 100000x20000 rank-64 (strong scaling)',
+            'value': n * m * K / t_score, 'unit': 'candidate scores/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': 1e3 * t_score / K, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%dx%d-d%d-N%d' % (n, m, d, N), 'rows_per_rank': nl,
+                       'parallelism': 'user rows split over %d rank(s), cross block and mask resident per rank' % world,
+                       'exchange': '%s all-gather of one 32-byte (sum, value, index) record per rank after every sweep'
+                                   % ('RCCL' if comm.has_rccl else 'host-staged' if world > 1 else 'single rank: local copy')},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_mn_grid_mfma<64,...> (rank 0\'s rows)', 'achieved': ach, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS if ach else None, 'traffic': None,
+                         'algorithmic_bytes_per_launch': algo, 'avg_kernel_ms': avg_ms, 'launches_timed': int(kern_ms.size)},
+            'grad_steps': {'value': tr.size / t_grad, 'unit': 'PMF grad-steps/s', 'dtype': 'f64',
+                           'ms_per_grad_step': 1e3 * t_grad / max(tr.size, 1), 'grad_steps_timed': int(tr.size),
+                           'algorithmic_GBs': gs_bytes * tr.size / t_grad / 1e9,
+                           'workload': 'ONE fit_lls row-sharded over %d rank(s): one grouped all-gather per trial' % world}}
 
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X float64 matrix peak (vendor figure; the guide lists none for f64)
