@@ -591,6 +591,10 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
     quadrature_limit = 50             # subdivisions of the continuous lookahead's quadrature (scipy's default)
     _approx_init_uses_rng = False     # initialize_approx() draws from np.random (ActivePMF)
 
+    def _lookahead_batch_ok(self):
+        """Whether this model's hypotheses can go through the class' device batch (_lookahead_batch)."""
+        return True
+
     def _hypothesis_model(self, i, j, v):
         """deepcopy(self) with R_ij = v added: the model a hypothesis is evaluated on."""
         apmf = deepcopy(self)
@@ -603,7 +607,7 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
         all of them in one batch on the device (_lookahead_batch); otherwise every hypothesis is a
         deep copy re-fitted on its own, a few at a time on worker threads."""
         batch = getattr(self, '_lookahead_batch', None)
-        if batch is not None and len(hyps) > 0 and lookahead_batched():
+        if batch is not None and len(hyps) > 0 and lookahead_batched() and self._lookahead_batch_ok():
             # what calculate_fn's deepcopy + add_rating would have done besides the arithmetic: refuse a
             # hypothesis about an entry that is already rated (pmf_cy.pyx:143-150), and - when the reference
             # evaluates in-process (procs == 1; its default hands the pool to forked workers, whose draws the

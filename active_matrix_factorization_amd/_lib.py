@@ -126,6 +126,18 @@ _DENSE_SIGS.update({
     'apmf_mn_batch_score_pool': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _vp, _vp]),
     'apmf_mn_batch_score_grid': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
 })
+_DENSE_SIGS.update({
+    'apmf_full_batch_create': (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    'apmf_full_batch_destroy': (_i, [_vp, _vp]),
+    'apmf_full_batch_set_state': (_i, [_vp, _vp, _vp, _vp, _i]),
+    'apmf_full_batch_set_extra': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'apmf_full_batch_get_state': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'apmf_full_batch_fit': (_i, [_vp, _vp, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    'apmf_full_batch_fit_stats': (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    'apmf_full_batch_kl': (_i, [_vp, _vp, _dbl, _dbl, _dbl, _vp]),
+    'apmf_full_batch_logdet': (_i, [_vp, _vp, _vp]),
+    'apmf_full_batch_total_variance': (_i, [_vp, _vp, _vp]),
+})
 DENSE_LIB_PATH = os.path.join(_HERE, 'libapmf_dense.so')
 
 _COMM_SIGS = {
@@ -496,6 +508,85 @@ class MNBatch(object):
                                                     _ptr(best_val), _ptr(best_idx)))
 
 
+class FullBatch(object):
+    """H full-covariance approximations N(mean, cov) resident on the device (apmf_full_batch): the batched
+    one-step lookahead of ActivePMF and - with H = 1 - the engine behind its fit_normal."""
+
+    def __init__(self, ctx, rt, d, H):
+        self.ctx, self.rt = ctx, rt          # rt is kept alive: the batch borrows it
+        self.H, self.d, self.n, self.m = int(H), int(d), rt.n, rt.m
+        self.K = (rt.n + rt.m) * int(d)
+        self._dense = load_dense()
+        h = _vp()
+        _check(self._dense.apmf_full_batch_create(ctx._h, rt._h, self.d, self.H, C.byref(h)))
+        self._h = h.value
+
+    def free(self):
+        if getattr(self, '_h', None):
+            if self.ctx._h:
+                self._dense.apmf_full_batch_destroy(self.ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def set_state(self, mean, cov, per_hypothesis=0):
+        _check(self._dense.apmf_full_batch_set_state(self.ctx._h, self._h, _ptr(mean), _ptr(cov), int(per_hypothesis)))
+
+    def set_extra(self, hi=None, hj=None, hv=None):
+        if hi is None:
+            _check(self._dense.apmf_full_batch_set_extra(self.ctx._h, self._h, None, None, None))
+            return
+        hi = np.ascontiguousarray(hi, np.int32)
+        hj = np.ascontiguousarray(hj, np.int32)
+        hv = np.ascontiguousarray(hv, np.float64)
+        if not (hi.size == hj.size == hv.size == self.H):
+            raise ValueError('one extra rating per hypothesis expected')
+        _check(self._dense.apmf_full_batch_set_extra(self.ctx._h, self._h, hi.ctypes.data, hj.ctypes.data,
+                                                     hv.ctypes.data))
+
+    def get_state(self, h, mean=None, cov=None):
+        _check(self._dense.apmf_full_batch_get_state(self.ctx._h, self._h, int(h), _ptr(mean), _ptr(cov)))
+
+    def fit(self, sig, sig_u, sig_v, min_eig, lr, old_kl=None, max_steps=-1, trace_cap=0):
+        """-> (lr (H), old_kl (H), steps (H), converged (H), kl_trace (H, trace_cap))"""
+        lr_io = np.ascontiguousarray(np.broadcast_to(np.asarray(lr, np.float64), (self.H,))).copy()
+        kl_io = np.full(self.H, np.nan) if old_kl is None else \
+            np.ascontiguousarray(np.broadcast_to(np.asarray(old_kl, np.float64), (self.H,))).copy()
+        steps = np.zeros(self.H, np.int64)
+        conv = np.zeros(self.H, np.int32)
+        trace = np.full((self.H, max(int(trace_cap), 1)), np.nan)
+        _check(self._dense.apmf_full_batch_fit(self.ctx._h, self._h, float(sig), float(sig_u), float(sig_v),
+                                               float(min_eig), lr_io.ctypes.data, kl_io.ctypes.data, int(max_steps),
+                                               trace.ctypes.data if trace_cap else None, int(trace_cap),
+                                               steps.ctypes.data, conv.ctypes.data))
+        return lr_io, kl_io, steps, conv.astype(bool), trace
+
+    def fit_stats(self):
+        v = [C.c_int64(0) for _ in range(3)]
+        _check(self._dense.apmf_full_batch_fit_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(('iterations', 'trials', 'projected'), (int(x.value) for x in v)))
+
+    def kl(self, sig, sig_u, sig_v):
+        out = np.empty(self.H)
+        _check(self._dense.apmf_full_batch_kl(self.ctx._h, self._h, float(sig), float(sig_u), float(sig_v),
+                                              out.ctypes.data))
+        return out
+
+    def logdet(self):
+        out = np.empty(self.H)
+        _check(self._dense.apmf_full_batch_logdet(self.ctx._h, self._h, out.ctypes.data))
+        return out
+
+    def total_variance(self):
+        out = np.empty(self.H)
+        _check(self._dense.apmf_full_batch_total_variance(self.ctx._h, self._h, out.ctypes.data))
+        return out
+
+
 def batch_launch_count():
     """Kernel launches enqueued by the batch engine (k6_batch.hip) in this process so far."""
     v = _i64(0)
@@ -608,6 +699,9 @@ class Context(object):
 
     def mn_batch(self, rt, d, H, trace_cap=0):
         return MNBatch(self, rt, d, H, trace_cap)
+
+    def full_batch(self, rt, d, H):
+        return FullBatch(self, rt, d, H)
 
     # -- K1 ---------------------------------------------------------------------------
     def pmf_gradient(self, rt, dU, dV, d, sig, sig_u, sig_v, subtract_mean, mean_rating, dgU, dgV):

@@ -10,6 +10,7 @@ normal_exps_cy.exp_dotprod_sq.
 """
 import itertools
 import numbers
+import os
 import random
 import warnings
 
@@ -79,22 +80,31 @@ class ActivePMF(_ActiveBase):
         return div - logabsdet(cov) / 2
 
     def _fit_normal_device(self, max_steps):
-        """fit_normal_kls with the approximation resident on the device (apmf_full_fit_normal):
-        gradient, trial point, projection, KL and the accept / reject decision of the search
-        (active_pmf.py:250-288) without the K x K covariance crossing PCIe per trial; the host
-        arrays are re-bound after every call, like the reference re-binds them per accepted step."""
+        """fit_normal_kls with the approximation resident on the device: a batch of ONE in the engine that also
+        fits the lookahead's hypotheses (csrc/k8_fullbatch.hip) - gradient, trial point, projection, KL and the
+        accept / reject decision of the search (active_pmf.py:250-288) without the K x K covariance crossing PCIe
+        per trial; the host arrays are re-bound after every call, like the reference re-binds them per accepted
+        step."""
         if self.mean is None or self.cov is None:
             raise ValueError("run initialize_approx first")
         ctx, rt = self._device_ratings()
-        dm, dc = ctx.array(self.mean, np.float64), ctx.array(self.cov, np.float64)
-        lr, old_kl, converged = self.normal_learning_rate, None, False
-        while not converged:
-            trace, steps, lr, converged, old_kl = ctx.full_fit_normal(
-                rt, self.latent_d, dm, dc, float(self.sigma_sq), float(self.sigma_u_sq), float(self.sigma_v_sq),
-                self.min_eig, lr, old_kl, max_steps=max_steps)
-            if steps:
-                self.mean, self.cov = dm.to_host(), dc.to_host()
-            yield trace, converged
+        batch = ctx.full_batch(rt, self.latent_d, 1)
+        try:
+            dm, dc = ctx.array(self.mean, np.float64), ctx.array(self.cov, np.float64)
+            batch.set_state(dm, dc)
+            sig = (float(self.sigma_sq), float(self.sigma_u_sq), float(self.sigma_v_sq))
+            lr, old_kl, converged = self.normal_learning_rate, None, False
+            cap = 1 if max_steps == 1 else 1 << 14
+            while not converged:
+                lrs, kls, steps, conv, trace = batch.fit(sig[0], sig[1], sig[2], self.min_eig, lr, old_kl,
+                                                         max_steps=max_steps, trace_cap=cap)
+                lr, old_kl, converged = float(lrs[0]), float(kls[0]), bool(conv[0])
+                if steps[0]:
+                    batch.get_state(0, dm, dc)
+                    self.mean, self.cov = dm.to_host(), dc.to_host()
+                yield trace[0, :min(int(steps[0]), cap)], converged
+        finally:
+            batch.free()
 
     def fit_normal_kls(self):
         '''Projected gradient descent on the KL, yielding it after each accepted step
@@ -144,6 +154,62 @@ class ActivePMF(_ActiveBase):
 
     def _total_variance(self):
         return self._score_grid(total_only=True)
+
+    # ------------------------------------------------------------------ batched one-step lookahead
+    def _lookahead_batch_ok(self):
+        # with refit_lookahead every hypothesis draws a fresh random covariance (initialize_approx) between its own
+        # MAP re-fit and its variational fit: kept on the one-at-a-time path, in the reference's RNG order
+        return not self.refit_lookahead
+
+    def _lookahead_batch(self, hyps, fn, pass_v):
+        """fn(model refitted with R_ij = v) for every hypothesis (i, j, v), all fitted TOGETHER on the device
+        (active_pmf.py:660-672 for the whole pool at once): H approximations starting from this model's, each with one
+        extra rating, advanced by one chain of launches (apmf_full_batch_fit); _total_variance and _approx_entropy then
+        come from the resident states, any other `fn` gets a real model object per hypothesis filled from the batch.
+        The same engine with H = 1 is this class' fit_normal: the values equal the one-at-a-time evaluation bit for
+        bit."""
+        if self.mean is None or self.cov is None:
+            raise ValueError("run initialize_approx first")
+        ctx, rt = self._device_ratings()
+        K = self.approx_dim
+        sig = (float(self.sigma_sq), float(self.sigma_u_sq), float(self.sigma_v_sq))
+        cls = type(self)
+        special = None
+        if not pass_v and fn is getattr(cls, '_total_variance', None) and cls._total_variance is ActivePMF._total_variance:
+            special = 'tv'
+        elif not pass_v and fn is getattr(cls, '_approx_entropy', None) and cls._approx_entropy is ActivePMF._approx_entropy:
+            special = 'ent'
+        per_hyp = (6 * K * K + 4 * K + 64 * 64 * (K // 64 + 3)) * 8
+        budget = int(float(os.environ.get('APMF_LOOKAHEAD_GB', '96')) * (1 << 30))
+        chunk = max(1, min(len(hyps), budget // per_hyp, 16384))
+        dm, dc = ctx.array(self.mean, np.float64), ctx.array(self.cov, np.float64)
+        out, batch = [], None
+        try:
+            for lo in range(0, len(hyps), chunk):
+                part = hyps[lo:lo + chunk]
+                H = len(part)
+                if batch is None or batch.H != H:
+                    if batch is not None:
+                        batch.free()
+                    batch = ctx.full_batch(rt, self.latent_d, H)
+                batch.set_state(dm, dc)
+                batch.set_extra([h[0] for h in part], [h[1] for h in part], [h[2] for h in part])
+                batch.fit(sig[0], sig[1], sig[2], self.min_eig, self.normal_learning_rate, None, max_steps=-1)
+                if special == 'tv':
+                    out.extend(batch.total_variance().tolist())
+                elif special == 'ent':
+                    out.extend(batch.logdet().tolist())
+                else:
+                    hm, hc = ctx.empty(K), ctx.empty((K, K))
+                    for k, (i, j, v) in enumerate(part):
+                        apmf = self._hypothesis_model(i, j, v)
+                        batch.get_state(k, hm, hc)
+                        apmf.mean, apmf.cov = hm.to_host(), hc.to_host()
+                        out.append(fn(apmf, v=v) if pass_v else fn(apmf))
+        finally:
+            if batch is not None:
+                batch.free()
+        return out
 
     # ------------------------------------------------------------------ entropy-bound criteria
     def approx_pred_covs(self):

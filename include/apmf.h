@@ -413,6 +413,39 @@ int apmf_full_fit_normal(apmf_ctx *ctx, const apmf_ratings *r, int d, double *d_
                          double *h_lr, double *h_old_kl, int64_t max_steps, double *h_kl_trace,
                          int64_t trace_cap, int64_t *h_steps, int *h_converged);
 
+/* H variational fits of the FULL-covariance approximation as one chain of launches (csrc/k8_fullbatch.hip): the
+ * one-step lookahead of the full-covariance class (active_pmf.py:635-704: deepcopy, add_rating(i, j, v),
+ * fit_normal per hypothesis and rating value) for a whole pool at once, and - with H = 1 - ActivePMF.fit_normal
+ * itself, so that the batched lookahead equals the per-hypothesis one bit for bit.  Hypothesis h is the shared
+ * container `r` plus ONE extra rating, taken as the last entry of user row i / item row j (where add_rating() and a
+ * rebuilt container put it); its state (mean (K), cov (K x K), K = (n+m) d) stays on the device. */
+typedef struct apmf_full_batch apmf_full_batch;
+int apmf_full_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, apmf_full_batch **out);
+int apmf_full_batch_destroy(apmf_ctx *ctx, apmf_full_batch *b);
+/* every hypothesis starts from (d_mean, d_cov) - the deep copies of the reference - or, per_hypothesis != 0, from
+ * its own (H x K, H x K x K) */
+int apmf_full_batch_set_state(apmf_ctx *ctx, apmf_full_batch *b, const double *d_mean, const double *d_cov,
+                              int per_hypothesis);
+/* the hypotheses' extra ratings (host arrays of H; h_i[h] < 0: none; NULL: none at all) */
+int apmf_full_batch_set_extra(apmf_ctx *ctx, apmf_full_batch *b, const int32_t *h_i, const int32_t *h_j,
+                              const double *h_v);
+int apmf_full_batch_get_state(apmf_ctx *ctx, apmf_full_batch *b, int h, double *d_mean, double *d_cov);
+/* fit_normal_kls (active_pmf.py:250-288) of every hypothesis: h_lr / h_old_kl (H each) in = learning rate and KL to
+ * resume from (NaN: evaluate it), out = where the search stands; max_steps < 0: to convergence (an accepted step
+ * improving the KL by < 0.005, or lr < 1e-10).  h_kl_trace (H x trace_cap, nullable): the KL after each accepted
+ * step of this call.  h_steps / h_converged (H, nullable). */
+int apmf_full_batch_fit(apmf_ctx *ctx, apmf_full_batch *b, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                        double min_eig, double *h_lr, double *h_old_kl, int64_t max_steps, double *h_kl_trace,
+                        int64_t trace_cap, int64_t *h_steps, int *h_converged);
+/* counters of the last fit: search iterations, trial points, trials whose project_psd really clipped eigenvalues */
+int apmf_full_batch_fit_stats(const apmf_full_batch *b, int64_t *iterations, int64_t *trials, int64_t *projected);
+/* kl_divergence() (active_pmf.py:202-246), log|det cov| (_approx_entropy, :519-521) and _total_variance()
+ * (:597-598: the K2-full sweep with the fused sum) of every current point */
+int apmf_full_batch_kl(apmf_ctx *ctx, apmf_full_batch *b, double sigma_sq, double sigma_u_sq, double sigma_v_sq,
+                       double *h_kl);
+int apmf_full_batch_logdet(apmf_ctx *ctx, apmf_full_batch *b, double *h_logdet);
+int apmf_full_batch_total_variance(apmf_ctx *ctx, apmf_full_batch *b, double *h_out);
+
 /* Optional device-side standard-normal draws for the Gibbs sweeps (Philox4x32-10 + Box-Muller,
  * counter = offset + index / 2): d_out[0..count) ~ N(0, 1).  Not NumPy's stream - BayesianPMF
  * uses it only with device_rng switched on (the reference draws np.random.normal per row,
