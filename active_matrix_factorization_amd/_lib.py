@@ -91,6 +91,7 @@ _SIGS = {
     'apmf_sample_stats_f64': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _dbl, _dbl, _vp, _vp, _vp]),
     'apmf_gibbs_sample_hyperparam': (_i, [_vp, _vp, _i, _i, _vp, _dbl, _dbl, _vp, _vp, C.c_uint64, C.c_uint64, _vp,
                                           _vp, _vp]),
+    'apmf_gibbs_sample_hyperparam_batched': (_i, [_vp, _i, _vp, _i, _i, _vp, _dbl, _dbl, _vp, _vp, _i, _vp, _vp, _vp]),
     'apmf_fill_normal_f64': (_i, [_vp, _vp, _i64, C.c_uint64, C.c_uint64]),
     'apmf_grid_gather_f64': (_i, [_vp, _vp, _i, _vp, _vp, _i64, _vp]),
     'apmf_pool_argext_f64': (_i, [_vp, _vp, _i64, _i, C.POINTER(_i64), C.POINTER(_dbl)]),
@@ -884,6 +885,12 @@ class Context(object):
                                                       float(df), _ptr(mu0), _ptr(variates),
                                                       int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1),
                                                       _ptr(mu), _ptr(alpha), _ptr(status)))
+
+    def gibbs_sample_hyperparam_batched(self, H, feats, N, d, wi, b0, df, mu0, variates, direct_dof, mu, alpha, status):
+        """(mu, alpha) of H chains at once from supplied variates (bayes_pmf.py:157-186 per chain)."""
+        _check(self._lib.apmf_gibbs_sample_hyperparam_batched(self._h, int(H), _ptr(feats), int(N), int(d), _ptr(wi),
+                                                              float(b0), float(df), _ptr(mu0), _ptr(variates),
+                                                              int(direct_dof), _ptr(mu), _ptr(alpha), _ptr(status)))
 
     def gibbs_half_sweep_batched(self, rt, side, H, oth, d, alpha, mu, beta, mean_sub, z, out, ei=None, ej=None,
                                  ev=None):

@@ -41,6 +41,15 @@ def _wishart_variates(n, dof):
     return ('bartlett', chi, np.random.normal(size=(n * (n - 1) // 2)))
 
 
+def _pack_variates(v):
+    """(Wishart variates, z) of one sample_hyperparam call -> (flat array in k7_hyper.hip's layout, direct_dof):
+    Bartlett [chi | strict lower triangle, row-major | z] (direct_dof 0) or the small-dof scheme [G (d x dof) | z]."""
+    w, z = v
+    if w[0] == 'direct':
+        return np.concatenate([np.ascontiguousarray(w[1]).ravel(), z]), int(w[1].shape[1])
+    return np.concatenate([w[1], w[2], z]), 0
+
+
 def _wishart_from_variates(sigma, variates):
     n = sigma.shape[0]
     chol = np.linalg.cholesky(sigma)
@@ -398,12 +407,32 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
             d_ev = ctx.array(np.array([p[4] for p in part], np.float64))
             hist_U, hist_V = ctx.empty((H, num_samps, n, d)), ctx.empty((H, num_samps, m, d))
             users_h, items_h = U0, V0
+            # the hyper-parameter step of all H chains on the device (k7_hyper.hip, one block per chain) from the
+            # variates NumPy drew above - no factor leaves the device between the sweeps; APMF_BATCH_HYPER=0 (or
+            # d > 32, or fewer than two rows) keeps the host arithmetic (values agree to ~1e-10, not to the bit)
+            dev_hyper = d <= 32 and n >= 2 and m >= 2 and os.environ.get('APMF_BATCH_HYPER', '1') != '0'
+            if dev_hyper:
+                hp_u = tuple(ctx.array(np.asarray(x, np.float64)) for x in (self.u_hyperparams[0], self.u_hyperparams[3]))
+                hp_v = tuple(ctx.array(np.asarray(x, np.float64)) for x in (self.v_hyperparams[0], self.v_hyperparams[3]))
+                d_mu_u, d_al_u, d_mu_v, d_al_v = ctx.empty((H, d)), ctx.empty((H, d, d)), ctx.empty((H, d)), ctx.empty((H, d, d))
+                d_status = ctx.zeros(1, np.int32)
             for s in range(num_samps):
-                mus_u, als_u, mus_v, als_v = np.empty((H, d)), np.empty((H, d, d)), np.empty((H, d)), np.empty((H, d, d))
-                for h in range(H):
-                    mus_u[h], als_u[h] = self._hyper_from_variates(users_h[h], True, draws[h][s][0])
-                    mus_v[h], als_v[h] = self._hyper_from_variates(items_h[h], False, draws[h][s][1])
-                d_mu_u, d_al_u, d_mu_v, d_al_v = ctx.array(mus_u), ctx.array(als_u), ctx.array(mus_v), ctx.array(als_v)
+                if dev_hyper:
+                    for side, (d_feats, rows, hp, hyp, d_mu, d_al) in enumerate((
+                            (d_users, n, hp_u, self.u_hyperparams, d_mu_u, d_al_u),
+                            (d_items, m, hp_v, self.v_hyperparams, d_mu_v, d_al_v))):
+                        packed = [_pack_variates(draws[h][s][side]) for h in range(H)]
+                        ctx.gibbs_sample_hyperparam_batched(H, d_feats, rows, d, hp[0], hyp[1], hyp[2], hp[1],
+                                                            ctx.array(np.stack([p[0] for p in packed])), packed[0][1],
+                                                            d_mu, d_al, d_status)
+                else:
+                    if s > 0:
+                        users_h, items_h = d_users.to_host(), d_items.to_host()
+                    mus_u, als_u, mus_v, als_v = np.empty((H, d)), np.empty((H, d, d)), np.empty((H, d)), np.empty((H, d, d))
+                    for h in range(H):
+                        mus_u[h], als_u[h] = self._hyper_from_variates(users_h[h], True, draws[h][s][0])
+                        mus_v[h], als_v[h] = self._hyper_from_variates(items_h[h], False, draws[h][s][1])
+                    d_mu_u, d_al_u, d_mu_v, d_al_v = ctx.array(mus_u), ctx.array(als_u), ctx.array(mus_v), ctx.array(als_v)
                 for g in range(num_gibbs):
                     zu = ctx.array(np.stack([draws[h][s][2][g][0] for h in range(H)]))
                     new_users = ctx.empty((H, n, d))
@@ -418,8 +447,8 @@ class BayesianPMF(ProbabilisticMatrixFactorization):
                 for h in range(H):
                     ctx.copy(hist_U, d_users, n * d * 8, dst_off=((h * num_samps + s) * n * d) * 8, src_off=h * n * d * 8)
                     ctx.copy(hist_V, d_items, m * d * 8, dst_off=((h * num_samps + s) * m * d) * 8, src_off=h * m * d * 8)
-                if s + 1 < num_samps:
-                    users_h, items_h = d_users.to_host(), d_items.to_host()
+            if dev_hyper and int(d_status.to_host()[0]):
+                raise np.linalg.LinAlgError('a matrix of a hyper-parameter step is not positive definite')
             # ---- total variance over the samples of every hypothesis (K4), from the device history
             var = ctx.empty((n, ld))
             for h, (c, k, i, j, v) in enumerate(part):

@@ -185,15 +185,26 @@ __device__ __forceinline__ void inv_any(const double *L, double *X, double *Ainv
     else inv_from_chol(L, X, Ainv, d, P, t);
 }
 
+// blockIdx.x = chain (apmf_gibbs_sample_hyperparam_batched: H feature matrices, H sets of supplied variates, H
+// outputs; the hyper-priors are shared).  direct_dof > 0: the reference's small-dof branch of sample_wishart
+// (bayes_pmf.py:47-52: X = chol(WI) G with G a d x dof matrix of normals) instead of Bartlett's factor; the variates
+// are then [G (d x dof, row-major) | z (d)].
 __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int N, int d,
                                                const double *__restrict__ W0, double b0, double df,
                                                const double *__restrict__ mu0,
                                                const double *__restrict__ variates, uint64_t seed, uint64_t offset,
                                                double *__restrict__ mu_out, double *__restrict__ alpha_out,
-                                               int *__restrict__ status)
+                                               int *__restrict__ status, int direct_dof = 0, size_t nvar = 0)
 {
     extern __shared__ double sm[];
     const int P = d + 1, t = threadIdx.x;
+    {
+        const size_t hb = blockIdx.x;
+        F += hb * (size_t)N * d;
+        if (variates) variates += hb * nvar;
+        mu_out += hb * d;
+        alpha_out += hb * (size_t)d * d;
+    }
     double *xbar = sm;                 // d
     double *part = xbar + HY_MAXD;     // 8 x 32 partials
     double *A = part + 8 * HY_MAXD;    // d x P each
@@ -308,7 +319,16 @@ __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int
     const int nlow = d * (d - 1) / 2;
     for (int e = t; e < d * d; e += 256) T[(e / d) * P + e % d] = 0.;
     __syncthreads();
-    if (variates) {
+    if (variates && direct_dof > 0) {
+        // X = chol(WI) G into the staging area (the feature matrix is done with it): d x dof <= HY_STAGE
+        for (int e = t; e < d * direct_dof; e += 256) {
+            const int i = e / direct_dof, c = e % direct_dof;
+            double v = 0.;
+            for (int k = 0; k <= i; k++) v += B[i * P + k] * variates[(size_t)k * direct_dof + c];
+            stage[e] = v;
+        }
+        if (t < d) vec[t] = variates[(size_t)d * direct_dof + t];
+    } else if (variates) {
         if (t < d) T[t * P + t] = sqrt(variates[t]);
         for (int e = t; e < nlow; e += 256) {
             int i = (int)((1. + sqrt(1. + 8. * e)) / 2.);
@@ -347,21 +367,31 @@ __global__ __launch_bounds__(256) void k_hyper(const double *__restrict__ F, int
         }
     }
     __syncthreads();
-    // ---- X = chol(WI) T   into C;  alpha = X X'   into A
-    for (int e = t; e < d * d; e += 256) {
-        const int i = e / d, j = e % d;
-        double v = 0.;
-        for (int k = j; k <= i; k++) v += B[i * P + k] * T[k * P + j];
-        C[i * P + j] = v;
-    }
-    __syncthreads();
-    for (int e = t; e < d * d; e += 256) {
-        const int i = e / d, j = e % d;
-        double v = 0.;
-        const int kmax = i < j ? i : j;
-        for (int k = 0; k <= kmax; k++) v += C[i * P + k] * C[j * P + k];
-        A[i * P + j] = v;
-        alpha_out[e] = v;
+    // ---- X = chol(WI) T   into C;  alpha = X X'   into A   (direct scheme: X is d x dof, in the staging area)
+    if (variates && direct_dof > 0) {
+        for (int e = t; e < d * d; e += 256) {
+            const int i = e / d, j = e % d;
+            double v = 0.;
+            for (int c = 0; c < direct_dof; c++) v += stage[i * direct_dof + c] * stage[j * direct_dof + c];
+            A[i * P + j] = v;
+            alpha_out[e] = v;
+        }
+    } else {
+        for (int e = t; e < d * d; e += 256) {
+            const int i = e / d, j = e % d;
+            double v = 0.;
+            for (int k = j; k <= i; k++) v += B[i * P + k] * T[k * P + j];
+            C[i * P + j] = v;
+        }
+        __syncthreads();
+        for (int e = t; e < d * d; e += 256) {
+            const int i = e / d, j = e % d;
+            double v = 0.;
+            const int kmax = i < j ? i : j;
+            for (int k = 0; k <= kmax; k++) v += C[i * P + k] * C[j * P + k];
+            A[i * P + j] = v;
+            alpha_out[e] = v;
+        }
     }
     __syncthreads();
     // ---- lam = chol(inv((b0 + N) alpha));  mu = lam z + (b0 mu0 + N x_bar) / (b0 + N)
@@ -411,5 +441,29 @@ extern "C" int apmf_gibbs_sample_hyperparam(apmf_ctx *ctx, const double *d_feats
         apmf_set_error("a matrix of the hyper-parameter step is not positive definite");
         return APMF_ENOTPD;
     }
+    return APMF_OK;
+}
+
+// H chains at once with SUPPLIED variates (the batched exp_variance lookahead, bayes_pmf.py:457-525: every
+// hypothesis' Gibbs chain takes its hyper-parameter step here instead of on the host, with the random numbers NumPy
+// drew for it): d_feats (H, N, d), d_variates (H, nvar), d_mu (H, d), d_alpha (H, d, d).  direct_dof = 0: Bartlett
+// variates [chi (d) | normals (d (d - 1) / 2) | z (d)]; > 0: the small-dof scheme, [G (d x dof) | z (d)].
+extern "C" int apmf_gibbs_sample_hyperparam_batched(apmf_ctx *ctx, int H, const double *d_feats, int N, int d,
+                                                    const double *d_wi, double b0, double df, const double *d_mu0,
+                                                    const double *d_variates, int direct_dof, double *d_mu,
+                                                    double *d_alpha, int *d_status)
+{
+    APMF_REQUIRE(ctx && d_feats && d_wi && d_mu0 && d_variates && d_mu && d_alpha && d_status, "NULL operand");
+    APMF_REQUIRE(H >= 1 && N >= 2, "need at least one chain and two feature rows (np.cov)");
+    APMF_REQUIRE(d >= 1 && d <= HY_MAXD, "latent_d=%d: the device hyper-parameter step supports 1..%d", d, HY_MAXD);
+    APMF_REQUIRE(direct_dof >= 0 && (size_t)d * direct_dof <= (size_t)HY_STAGE, "direct Wishart scheme: d x dof = %d x %d "
+                 "exceeds the staging area", d, direct_dof);
+    const size_t nvar = direct_dof > 0 ? (size_t)d * direct_dof + d : (size_t)d + (size_t)d * (d - 1) / 2 + d;
+    const size_t smem = (HY_MAXD + 8 * HY_MAXD + 4 * (size_t)d * (d + 1) + HY_MAXD + (size_t)HY_STAGE) * sizeof(double);
+    if (smem > 64 * 1024)
+        APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_hyper, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k_hyper, dim3(H), dim3(256), smem, ctx->stream, d_feats, N, d, d_wi, b0, df, d_mu0, d_variates,
+                       (uint64_t)0, (uint64_t)0, d_mu, d_alpha, d_status, direct_dof, nvar);
+    APMF_CHECK_LAUNCH();
     return APMF_OK;
 }

@@ -492,6 +492,15 @@ int apmf_gibbs_sample_hyperparam(apmf_ctx *ctx, const double *d_feats, int N, in
                                  double b0, double df, const double *d_mu0, const double *d_variates,
                                  uint64_t seed, uint64_t offset, double *d_mu, double *d_alpha,
                                  int *d_status);
+/* H chains at once with SUPPLIED variates - the hyper-parameter steps of the batched exp_variance lookahead
+ * (bayes_pmf.py:457-525: one Gibbs chain per hypothesis): d_feats (H, N, d), d_variates (H, nvar), d_mu (H, d),
+ * d_alpha (H, d, d); d_status: one device int (zeroed by the caller), set if a matrix was not positive definite.
+ * direct_dof = 0: Bartlett variates [chi (d) | normals (d (d-1) / 2) | z (d)]; direct_dof > 0: the reference's
+ * small-dof branch of sample_wishart (bayes_pmf.py:47-52), variates [G (d x dof, row-major) | z (d)]. */
+int apmf_gibbs_sample_hyperparam_batched(apmf_ctx *ctx, int H, const double *d_feats, int N, int d,
+                                         const double *d_wi, double b0, double df, const double *d_mu0,
+                                         const double *d_variates, int direct_dof, double *d_mu,
+                                         double *d_alpha, int *d_status);
 
 #ifdef __cplusplus
 }

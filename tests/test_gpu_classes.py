@@ -1508,8 +1508,15 @@ def test_bayes_exp_variance_batched_equals_sequential(pkg, monkeypatch):
         alone = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
         monkeypatch.delenv('APMF_LOOKAHEAD_BATCH')
         assert batched.shape == (4,) and np.all(np.isfinite(batched))
-        np.testing.assert_allclose(batched, alone, rtol=1e-12)
+        # (the batch takes its chains' hyper-parameter steps on the device, the sequential evaluation in NumPy:
+        # the same variates, summation orders of their own)
+        np.testing.assert_allclose(batched, alone, rtol=1e-9)
         assert np.array_equal(state, np.random.get_state()[1][:8])       # the same random stream was consumed
+        monkeypatch.setenv('APMF_BATCH_HYPER', '0')                      # host hyper-parameter steps: to rounding
+        seed(6)
+        host_hyper = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
+        monkeypatch.delenv('APMF_BATCH_HYPER')
+        np.testing.assert_allclose(host_hyper, alone, rtol=1e-12)
     # a rated entry among the candidates: NaN, like the reference
     r0 = tuple(int(x) for x in g['ratings'][0, :2])
     both = (np.array([r0[0], unr[0, 0]]), np.array([r0[1], unr[1, 0]]))

@@ -1053,6 +1053,36 @@ def test_device_hyperparam_step_vs_numpy(ctx, shape):
     np.testing.assert_allclose(d_mu.to_host(), mu, rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize('shape', [(10, 2, 2.), (40, 5, 5.), (300, 16, 16.), (90, 15, 15.)])
+def test_device_hyperparam_step_batched(ctx, shape):
+    """apmf_gibbs_sample_hyperparam_batched: H chains, one block each, supplied variates - against the package's own
+    host arithmetic (BayesianPMF._hyper_from_variates = bayes_pmf.py:157-186 + sample_wishart's two branches,
+    :41-59): the small-dof DIRECT scheme (dof = df + N <= 81 + d: what the 10 x 10 configs take) and Bartlett's."""
+    from active_matrix_factorization_amd import bayes_pmf as bp
+    N, d, df = shape
+    H = 5
+    rs = np.random.RandomState(int(N + d))
+    np.random.seed(N * 7 + d)
+    wi, b0, mu0 = np.eye(d) + .1 * np.ones((d, d)), 2., rs.normal(size=d) * .1
+    b = bp.BayesianPMF.__new__(bp.BayesianPMF)
+    b.latent_d = d
+    b.u_hyperparams = (wi, b0, df, mu0)
+    F = rs.normal(0.3, 1.5, (H, N, d))
+    draws = [b._hyper_variates(N, True) for _ in range(H)]
+    packed = [bp._pack_variates(v) for v in draws]
+    direct = packed[0][1]
+    assert (direct > 0) == (df + N <= 81 + d)
+    d_mu, d_al, status = ctx.empty((H, d)), ctx.empty((H, d, d)), ctx.zeros(1, np.int32)
+    ctx.gibbs_sample_hyperparam_batched(H, ctx.array(F), N, d, ctx.array(wi), b0, df, ctx.array(mu0),
+                                        ctx.array(np.stack([p[0] for p in packed])), direct, d_mu, d_al, status)
+    assert int(status.to_host()[0]) == 0
+    mu, al = d_mu.to_host(), d_al.to_host()
+    for h in range(H):
+        rm, ra = b._hyper_from_variates(F[h], True, draws[h])
+        np.testing.assert_allclose(al[h], ra, rtol=1e-9, atol=1e-12 * np.abs(ra).max())
+        np.testing.assert_allclose(mu[h], rm, rtol=1e-9, atol=1e-11)
+
+
 def test_device_hyperparam_generator_moments(ctx):
     """The same step drawing its own variates (Philox: Box-Muller normals, Marsaglia-Tsang
     chi-squares): E[alpha] = dof * WI for a Wishart draw, mu centred on the posterior mean;
