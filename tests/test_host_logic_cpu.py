@@ -1,0 +1,77 @@
+"""Host-side logic that needs no GPU: the quadrature predictor of the continuous lookahead and the packing of
+the Gibbs hyper-parameter variates."""
+import warnings
+
+import numpy as np
+import pytest
+from scipy import stats
+
+
+def test_quadrature_first_pass_and_bisections_are_predicted():
+    """The continuous lookahead (mn_active_pmf.py:686-691) integrates with stats.norm.expect = adaptive 21-point
+    Gauss-Kronrod quadrature.  _Quadrature must know, before any integrand value exists, every point of the first
+    pass (so that the pool's hypotheses can be fitted as one batch) and, when the routine bisects an interval, the 42
+    points of its two halves: run the real quadrature on a noisy integrand (it never converges: 50 subdivisions per
+    interval) and check that no point it asks for was unpredicted."""
+    from active_matrix_factorization_amd._active_base import _Quadrature, _gk21_points
+    for mean, std in ((3.0, 1.3), (-0.4, 0.25), (120., 40.)):
+        left, right = mean - 2 * std, mean + 2 * std
+        q = _Quadrature(mean, std, left, right)
+        assert q.intervals is not None, 'the QUADPACK node formula does not reproduce the dry run'
+        assert len(q.first_pass) == 21 * len(q.intervals)
+        assert q.first_pass[:21] == _gk21_points(*q.intervals[0])
+        assert abs(q.intervals[0][0] - left) < 1e-12 and abs(q.intervals[-1][1] - right) < 1e-12
+        rs = np.random.RandomState(0)
+        known = {v: 1. + rs.rand() for v in q.first_pass}
+        stats_ = {'batches': 0, 'stray': 0}
+
+        def integrand(v):
+            v = float(v)
+            if v not in known:
+                more = q.bisection_points(v)
+                if more and v in more:
+                    stats_['batches'] += 1
+                    for x in more:
+                        known.setdefault(x, 1. + rs.rand())
+                else:
+                    stats_['stray'] += 1
+                    known[v] = 1. + rs.rand()
+            return known[v]
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            val = stats.norm.expect(integrand, loc=mean, scale=std, lb=left, ub=right, epsrel=.02)
+        assert np.isfinite(val) and stats_['stray'] == 0 and stats_['batches'] > 10, stats_
+    # a smooth integrand converges on the first pass: nothing beyond it is asked for
+    q = _Quadrature(0., 1., -2., 2.)
+    seen = []
+    stats.norm.expect(lambda v: seen.append(float(v)) or float(v) ** 2, loc=0., scale=1., lb=-2., ub=2., epsrel=.02)
+    assert seen == q.first_pass
+
+
+def test_pack_variates_layouts():
+    """k7_hyper.hip's supplied-variates layouts: Bartlett [chi (d) | strict lower triangle row-major | z (d)] and the
+    reference's small-dof direct scheme [G (d x dof) row-major | z (d)] (bayes_pmf.py:41-59)."""
+    from active_matrix_factorization_amd import bayes_pmf as bp
+    d = 4
+    np.random.seed(1)
+    w = bp._wishart_variates(d, 10)                 # dof <= 81 + d, integral: direct
+    assert w[0] == 'direct' and w[1].shape == (d, 10)
+    z = np.arange(d, dtype=float)
+    flat, dof = bp._pack_variates((w, z))
+    assert dof == 10 and flat.size == d * 10 + d and np.array_equal(flat[:d * 10].reshape(d, 10), w[1])
+    assert np.array_equal(flat[-d:], z)
+    w = bp._wishart_variates(d, 200.)               # Bartlett
+    assert w[0] == 'bartlett'
+    flat, dof = bp._pack_variates((w, z))
+    assert dof == 0 and flat.size == d + d * (d - 1) // 2 + d
+    A = np.diag(np.sqrt(w[1]))
+    A[np.tri(d, k=-1, dtype=bool)] = w[2]
+    low = flat[d:d + d * (d - 1) // 2]
+    assert [A[1, 0], A[2, 0], A[2, 1], A[3, 0], A[3, 1], A[3, 2]] == list(low)
+    # the two host branches agree with what they replace
+    s = np.eye(d) + .1
+    np.random.seed(2)
+    a = bp.sample_wishart(s, 10)
+    np.random.seed(2)
+    b = bp._wishart_from_variates(s, bp._wishart_variates(d, 10))
+    assert np.array_equal(a, b)
