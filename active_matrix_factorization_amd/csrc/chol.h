@@ -50,6 +50,27 @@ __device__ __forceinline__ double *ch_linv(const ChJob &job, int k)
     return job.linv + (job.linv_keep ? (size_t)(k / CH_NB) * CH_NB * CH_NB : 0);
 }
 
+// XCD-aware (tile, job) of a block of a grid (tiles, jobs).  Workgroups are dealt round-robin over the 8 XCDs, each
+// with an L2 of its own (blocks b and b + 8 share one): with the plain mapping the tiles of ONE matrix - which read
+// the same panels - land on eight different L2s and every one of them fetches those panels again.  Here the blocks
+// an XCD executes one after the other are the tiles of one matrix, then of the next: the shared operands are fetched
+// once per matrix.  A bijection of the grid whatever the placement really is (jobs beyond the last full group of 8
+// keep the plain mapping): placement changes the speed, never the result.
+__device__ __forceinline__ void xcd_tile_job(int &tile, int &job)
+{
+    const unsigned nx = gridDim.x, ny = gridDim.y;
+    const unsigned lin = blockIdx.y * nx + blockIdx.x;
+    const unsigned nfull = ny & ~7u;
+    if (lin < nfull * nx) {
+        const unsigned s = lin >> 3;
+        job = (int)((lin & 7u) + 8u * (s / nx));
+        tile = (int)(s % nx);
+    } else {
+        job = (int)blockIdx.y;
+        tile = (int)blockIdx.x;
+    }
+}
+
 // lane `src` 's value of a wave-resident double, as a wave-uniform value
 __device__ __forceinline__ double lane_value(double v, int src)
 {
@@ -297,13 +318,15 @@ __global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
 // per block of 64 rows on the matrix cores, both operands in LDS
 __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k)
 {
-    const ChJob job = ch_job(J, blockIdx.y);
+    int bx, by;
+    xcd_tile_job(bx, by);
+    const ChJob job = ch_job(J, by);
     double *__restrict__ A = job.A;
     const double *__restrict__ linv = ch_linv(job, k);
     __shared__ double P[CH_NB][TP], X[CH_NB][TP];
     const int nb = min(CH_NB, N - k);
     if (*job.info != 0) return;
-    const int r0 = k + nb + blockIdx.x * 64;
+    const int r0 = k + nb + bx * 64;
     const int rows = min(64, N - r0);
     {
         TileRegs<CH_NB, CH_NB> x, t;
@@ -342,7 +365,9 @@ __device__ __forceinline__ void tri_tile(int b, int &ti, int &tj)
 template <bool NEXT>
 __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int k)
 {
-    const ChJob job = ch_job(J, blockIdx.y);
+    int bx, by;
+    xcd_tile_job(bx, by);
+    const ChJob job = ch_job(J, by);
     double *__restrict__ A = job.A;
     // the panel is staged 32 columns at a time: 35 KB of LDS per block -> 4 blocks (16 waves) per CU
     // instead of 2; this kernel is latency-bound (PMC: ~1.7 TB/s of HBM traffic), occupancy is what helps
@@ -355,7 +380,7 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
     const int nb = min(CH_NB, N - k);
     const int base = k + nb;
     int ti, tj;
-    tri_tile((int)blockIdx.x, ti, tj);
+    tri_tile(bx, ti, tj);
     const int i0 = base + ti * 64, j0 = base + tj * 64;
     // everything the block reads is requested up front: the tile being updated and the first
     // half-panels; the second half-panels while the first are multiplied
@@ -403,7 +428,7 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
                     if (ru[u] && cv[v]) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
         }
     }
-    if (!NEXT || blockIdx.x != 0) {
+    if (!NEXT || bx != 0) {
         TILE_FOR_EACH(u, v, r) {
             const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
             if (i < N && j <= i) A[(size_t)i * N + j] = old[u][v][r] - acc[u][v][r];
@@ -441,21 +466,30 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
 // but stays in registers in between instead of going through memory once per panel: half the traffic.
 __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
 {
-    const ChJob job = ch_job(J, blockIdx.y);
+    int bx, by;
+    xcd_tile_job(bx, by);
+    const ChJob job = ch_job(J, by);
     double *__restrict__ A = job.A;
     constexpr int KS = 32, KP = KS + 2;
     __shared__ double stat_lds[2 * 64 * KP];
     double (*Pi)[KP] = (double (*)[KP])stat_lds;
     double (*Pj)[KP] = Pi + 64;
-    const int j0 = jb * CH_NB, i0 = j0 + (int)blockIdx.x * 64;
+    const int j0 = jb * CH_NB, i0 = j0 + bx * 64;
     f64x4 old[2][2];
     TILE_FOR_EACH(u, v, r) {
         const int i = min(i0 + tile_row(u, r), N - 1), j = min(j0 + tile_col(v), N - 1);
         old[u][v][r] = A[(size_t)i * N + j];
     }
-    TileRegs<64, KS> pi, pj;
-    pi.load(A, N, i0, 0, N, N);
-    pj.load(A, N, j0, 0, N, N);
+    // Two half-panels of operands are in flight: the loads of half-panel h + 2 are issued while h is multiplied, so a
+    // load has two multiply phases to arrive in (one was not enough: a block spent 2.8 us per half-panel, 0.85 of them
+    // in its 32 MFMAs, and with two blocks per CU the matrix pipe sat idle 59 % of the time)
+    TileRegs<64, KS> pi0, pj0, pi1, pj1;
+    pi0.load(A, N, i0, 0, N, N);
+    pj0.load(A, N, j0, 0, N, N);
+    if (j0 > KS) {
+        pi1.load(A, N, i0, KS, N, N);
+        pj1.load(A, N, j0, KS, N, N);
+    }
     if (*job.info != 0) return;
     f64x4 acc[2][2] = {};
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -464,7 +498,7 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
     const int rmax = N - i0, cmax = N - j0;            // accumulators wholly outside the matrix are skipped
     const bool ru[2] = {32 * (w >> 1) < rmax, 32 * (w >> 1) + 16 < rmax};
     const bool cv[2] = {32 * (w & 1) < cmax, 32 * (w & 1) + 16 < cmax};
-    for (int kc = 0; kc < j0; kc += KS) {              // half-panels: columns [kc, kc + KS) of the factor so far
+    auto half = [&](TileRegs<64, KS> &pi, TileRegs<64, KS> &pj, int next_kc) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < pi.PER; q++) {
@@ -472,9 +506,9 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
             Pi[r][c] = i0 + r < N ? pi.v[q] : 0.;
             Pj[r][c] = j0 + r < N ? pj.v[q] : 0.;
         }
-        if (kc + KS < j0) {
-            pi.load(A, N, i0, kc + KS, N, N);
-            pj.load(A, N, j0, kc + KS, N, N);
+        if (next_kc < j0) {
+            pi.load(A, N, i0, next_kc, N, N);
+            pj.load(A, N, j0, next_kc, N, N);
         }
         __syncthreads();
         if (ru[0] && cv[0])
@@ -490,11 +524,13 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
                 for (int v = 0; v < 2; v++)
                     if (ru[u] && cv[v]) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
         }
-        if ((kc + KS) % CH_NB == 0) {                 // a panel is complete: its update, rounded like k_chol_update's
-            TILE_FOR_EACH(u, v, r) {
-                old[u][v][r] = old[u][v][r] - acc[u][v][r];
-                acc[u][v][r] = 0.;
-            }
+    };
+    for (int kp = 0; kp < j0; kp += CH_NB) {           // one panel = two half-panels (j0 is a multiple of 64)
+        half(pi0, pj0, kp + CH_NB);
+        half(pi1, pj1, kp + CH_NB + KS);
+        TILE_FOR_EACH(u, v, r) {                       // the panel's update, rounded like k_chol_update's
+            old[u][v][r] = old[u][v][r] - acc[u][v][r];
+            acc[u][v][r] = 0.;
         }
     }
     TILE_FOR_EACH(u, v, r) {

@@ -905,9 +905,11 @@ __device__ __forceinline__ void tile_place(const TileRegs<64, 64> &t, const Tile
 __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__restrict__ sel, int k)
 {
     __shared__ double A[64][TP], B[64][TP];
-    const int h = sel[blockIdx.y];
+    int bx, by;
+    xcd_tile_job(bx, by);                 // the tiles of one hypothesis on one XCD: they share L_ik and W_kj
+    const int h = sel[by];
     const int N = R.N, nb = R.nbk;
-    const int i = k + 1 + (int)blockIdx.x / (k + 1), j = (int)blockIdx.x % (k + 1);
+    const int i = k + 1 + bx / (k + 1), j = bx % (k + 1);
     const double *__restrict__ L = tabp(R, T_S_F, h);
     double *__restrict__ W = tabp(R, T_S_W, h);
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
@@ -957,10 +959,12 @@ __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__
 __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restrict__ sel, double half_mult)
 {
     __shared__ double A[64][TP], B[64][TP];
-    const int h = sel[blockIdx.y];
+    int bx, by;
+    xcd_tile_job(bx, by);                 // the tiles of one hypothesis on one XCD: every W tile is read by ~9 of them
+    const int h = sel[by];
     const int N = R.N, nb = R.nbk;
     int ti, tj;
-    tri_tile((int)blockIdx.x, ti, tj);       // ti >= tj
+    tri_tile(bx, ti, tj);       // ti >= tj
     const double *__restrict__ W = tabp(R, T_S_W, h);
     double *__restrict__ G = tabp(R, T_S_GRAD, h);
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
@@ -1003,8 +1007,8 @@ __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restr
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = inv2;
         __syncthreads();
         if (threadIdx.x == 0) {
-            R.invp[(size_t)h * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-            if (blockIdx.x == 0) R.hs[h].inv_ok = 1;
+            R.invp[(size_t)h * gridDim.x + bx] = (red[0] + red[1]) + (red[2] + red[3]);
+            if (bx == 0) R.hs[h].inv_ok = 1;
         }
     }
 }

@@ -200,9 +200,11 @@ __device__ __forceinline__ void ft_place(const TileRegs<64, 64> &t, const FTile 
 __global__ __launch_bounds__(256) void kf_trinv_step(const FRefs R, const int *__restrict__ sel, int k)
 {
     __shared__ double A[64][TP], B[64][TP];
-    const int h = sel[blockIdx.y];
+    int bx, by;
+    xcd_tile_job(bx, by);
+    const int h = sel[by];
     const int N = R.K, nb = R.nbk;
-    const int i = k + 1 + (int)blockIdx.x / (k + 1), j = (int)blockIdx.x % (k + 1);
+    const int i = k + 1 + bx / (k + 1), j = bx % (k + 1);
     const double *__restrict__ L = R.F + (size_t)h * N * N;
     double *__restrict__ W = R.W + (size_t)h * N * N;
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
@@ -246,10 +248,12 @@ __global__ __launch_bounds__(256) void kf_trinv_step(const FRefs R, const int *_
 __global__ __launch_bounds__(256) void kf_lauum(const FRefs R, const int *__restrict__ sel)
 {
     __shared__ double A[64][TP], B[64][TP];
-    const int h = sel[blockIdx.y];
+    int bx, by;
+    xcd_tile_job(bx, by);
+    const int h = sel[by];
     const int N = R.K, nb = R.nbk;
     int ti, tj;
-    tri_tile((int)blockIdx.x, ti, tj);
+    tri_tile(bx, ti, tj);
     const double *__restrict__ W = R.W + (size_t)h * N * N;
     double *__restrict__ G = R.gcov + (size_t)h * N * N;
     const double *__restrict__ linv = R.linvF + (size_t)h * nb * CH_NB * CH_NB;
