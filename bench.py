@@ -414,18 +414,22 @@ F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X float64 matrix peak (vendor figure; the g
 def f64_sweeps(ctx, B, ld, d_mean, d_cross, d_diag, d_omega, d_mask, K, W):
     """The SAME 943x1682-d10-B256 workload through apmf_mn_score_grid_f64 - the sweep every class of the
     package actually calls: (a) scores written + per-state sum + arg-max, 8 B read + 8 B written = 16 B per
-    candidate (what get_key_evals / pick_query_point run), (b) reduction only (per-state sum + arg-max, no grid
-    written: 8 B per candidate) - how the batched lookahead reduces its H hypothesis states (_total_variance).
+    candidate (what get_key_evals / pick_query_point run), (b) reduction only (per-state sums, no grid written:
+    8 B per candidate) - how the batched lookahead reduces its H hypothesis states (_total_variance) - and (c) the
+    same with the masked arg-max fused.
     HIP events around the kernel, in-library, on the launch stream."""
     n, m, d = N_USERS, N_ITEMS, LATENT_D
     m64, c64, g64, o64 = (ctx.cast(x, np.float64) for x in (d_mean, d_cross, d_diag, d_omega))
     var = ctx.empty((B, n, ld), np.float64)
     dsum, bv, bi = ctx.empty(B), ctx.empty(B), ctx.empty(B, np.int64)
     out = {'workload': '943x1682-d10-B%d' % B, 'dtype': 'f64', 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
-    for name, v, bpc in (('written', var, 16.), ('reduce_only', None, 8.)):
+    # (the reduction leg is called exactly as the lookahead calls it - apmf_mn_batch_total_variance: per-state sums
+    # only, no mask, no arg-extremum; 'reduce_argmax' adds the masked arg-max a selection over hypotheses would)
+    for name, v, bpc, msk, want in (('written', var, 16., d_mask, 1), ('reduce_only', None, 8., None, 0),
+                                    ('reduce_argmax', None, 8., d_mask, 1)):
         def step():
-            ctx.mn_score_grid(np.float64, B, n, m, d, ld, m64, c64, g64, o64, mask=d_mask, var=v, dsum=dsum, want=1,
-                              best_val=bv, best_idx=bi)
+            ctx.mn_score_grid(np.float64, B, n, m, d, ld, m64, c64, g64, o64, mask=msk, var=v, dsum=dsum, want=want,
+                              best_val=bv if want else None, best_idx=bi if want else None)
         for _ in range(W):
             step()
         ctx.sync()
