@@ -1253,6 +1253,51 @@ def test_configs3_golden_lookahead_pool_pick(pkg):
             np.testing.assert_allclose(b._total_variance(), tr['total_variance_1'], rtol=1e-8)
 
 
+def test_configs3_golden_lookahead_pool_ranking(pkg):
+    """configs[3]: the RANKING of a realistic pool under the lookahead criterion (make_golden.py section W): 24 unrated
+    entries x 2 rating values from the reference's converged approximation, every hypothesis advanced by exactly 100
+    accepted fit_normal_kls steps - where both searches still agree to rounding - then _total_variance and the
+    expectation over the rating values as _exp_with_rij forms it (mn_active_pmf.py:676-681).  All 48 KL traces
+    (1e-8), all 48 totals and the 24 criterion values (1e-8), and the order of the whole pool - not just its
+    arg-min - must be the reference's."""
+    import math
+    import os
+    from scipy import stats
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, 'lookahead_c4_pool_ranked.npz')):
+        pytest.skip('fixture lookahead_c4_pool_ranked.npz not generated yet (make_golden.py --only r3b: hours of reference time)')
+    g = load_golden('mn_c4_94x425_d5')
+    w = load_golden('lookahead_c4_pool_ranked')
+    a = _c4_model(pkg, g, 'fit')
+    pool = [tuple(int(x) for x in ij) for ij in w['pool']]
+    steps = int(w['steps'])
+    vals = a.rating_values
+    hyps = [(i, j, float(v)) for i, j in pool for v in vals]
+    H = len(hyps)
+    res = a._resident()
+    ctx, rt = a._device_ratings()
+    n_all, d = a.num_users + a.num_items, a.latent_d
+    base = (ctx.empty((n_all, d)), ctx.empty((n_all, n_all)), ctx.empty((d, d)))
+    res.batch.get_state(0, *base)
+    b = ctx.mn_batch(rt, d, H, trace_cap=steps)
+    b.set_state(*base)
+    b.set_extra([h[0] for h in hyps], [h[1] for h in hyps], [h[2] for h in hyps])
+    sig = a._sigmas()
+    lr, kl, nst, conv, trace = b.fit(sig[0], sig[1], sig[2], a.min_eig, a.normal_learning_rate, None, max_steps=steps)
+    assert (nst == steps).all()
+    np.testing.assert_allclose(trace, w['kls'], rtol=1e-8)
+    tv = b.total_variance().reshape(len(pool), len(vals))
+    np.testing.assert_allclose(tv, w['tv'], rtol=1e-8)
+    est = []
+    for (i, j), evals in zip(pool, tv):
+        mean = float(np.dot(a.users[i, :], a.items[j, :]))
+        cdfs = stats.norm.cdf(a.rating_bounds, loc=mean, scale=math.sqrt(a.sigma_sq))
+        est.append((evals * np.diff(cdfs)).sum())
+    np.testing.assert_allclose(est, w['vals'], rtol=1e-8)
+    assert np.array_equal(np.argsort(est, kind='stable'), w['order'])          # the whole ranking, exactly
+    b.free()
+
+
 def test_headline_shape_golden_scoring_and_selection(pkg):
     """BASELINE.json's metric shape - 943 x 1682, rank 10 - recorded from the real reference
     (make_golden.py section J: approx_pred_means_vars over all 1 586 126 entries, pick_query_point over
