@@ -916,6 +916,40 @@ def test_pmf_batch_fit_lls_equals_rebuilt(ctx, d):
     _batch_fit_case(ctx, ratings, n, m, d, hyps[:4], subtract_mean=True, max_steps=25, seed=1)
 
 
+def test_pmf_batch_fit_lls_headline_shape(ctx):
+    """The batched MAP re-fit at the metric's own shape - 943 x 1682, rank 10, N = 100 000 (106 ratings per user: the
+    4-waves-per-row kernels, some rows beyond 192 ratings) - six hypotheses against six fits on rebuilt containers,
+    bit for bit, and against the reference's recorded log-likelihood trace of this very fit (fixture
+    pmf_c2_fit_943x1682_d10) for the hypothesis-free case."""
+    from conftest import c2_inputs
+    ratings, U0, V0 = c2_inputs()
+    n, m, d = 943, 1682, 10
+    rated = set(zip(ratings[:, 0].astype(int).tolist(), ratings[:, 1].astype(int).tolist()))
+    rs = np.random.RandomState(3)
+    hyps = []
+    while len(hyps) < 6:
+        i, j = int(rs.randint(n)), int(rs.randint(m))
+        if (i, j) not in rated:
+            hyps.append((i, j, float(rs.randint(1, 6))))
+    H = len(hyps)
+    rt = ctx.ratings(ratings, n, m)
+    dU = ctx.array(np.broadcast_to(U0, (H, n, d)).copy())
+    dV = ctx.array(np.broadcast_to(V0, (H, m, d)).copy())
+    ll, steps, conv = ctx.pmf_batch_fit_lls(rt, dU, dV, d, H, [h[0] for h in hyps], [h[1] for h in hyps],
+                                            [h[2] for h in hyps], 1., 10., 10., False, None, 1e-4, 1e-10, 1e-2, max_steps=8)
+    bU, bV = dU.to_host(), dV.to_host()
+    assert (steps == 8).all()
+    for h, (i, j, v) in enumerate(hyps[:3]):
+        rth = ctx.ratings(np.vstack([ratings, [i, j, v]]), n, m)
+        aU, aV = ctx.array(U0), ctx.array(V0)
+        _, st, lr, cv, ll1 = ctx.pmf_fit_lls(rth, aU, aV, d, 1., 10., 10., False, 0., 1e-4, 1e-10, 1e-2, max_steps=8,
+                                             max_trace=0, return_ll=True)
+        assert st == 8 and ll1 == ll[h]
+        assert np.array_equal(aU.to_host(), bU[h]) and np.array_equal(aV.to_host(), bV[h])
+        rth.free()
+    rt.free()
+
+
 def test_pmf_batch_fit_lls_block_shapes(ctx):
     """A hypothesis can change the block shape its re-fit runs with - a row growing past 192 ratings (4 waves per
     row in k_fit_iter), N + 1 reaching 48 ratings per row (4 waves per row in the gradient / log-likelihood
