@@ -932,18 +932,20 @@ def _hyp_trunc_mn(args):
     import itertools
     from copy import deepcopy
     import numpy as np
+    from threadpoolctl import threadpool_limits
     a, i, j, v, steps = args
-    b = deepcopy(a)
-    b.add_rating(i, j, v)
-    kls = np.array(list(itertools.islice(b.fit_normal_kls(), steps)))
-    return kls, b._total_variance()
+    with threadpool_limits(1):      # 7 workers on 8 cores: one BLAS thread each
+        b = deepcopy(a)
+        b.add_rating(i, j, v)
+        kls = np.array(list(itertools.islice(b.fit_normal_kls(), steps)))
+        return kls, b._total_variance()
 
 
 def round3b(np, mn_active_pmf, save, seed, _print):
     """W. configs[3] (DrugBank 94 x 425 rank 5): the RANKING of a realistic pool under the lookahead criterion.
     24 unrated entries x 2 rating values from the converged approximation of section G, every hypothesis
-    (deepcopy + add_rating + fit_normal_kls, mn_active_pmf.py:660-668) advanced by exactly 100 accepted steps -
-    where the search has not yet amplified rounding differences - then _total_variance and the expectation over the
+    (deepcopy + add_rating + fit_normal_kls, mn_active_pmf.py:660-668) advanced by at most 100 accepted steps -
+    where the search has not yet amplified rounding differences; `lens` holds the count where it converged earlier - then _total_variance and the expectation over the
     rating values exactly as _exp_with_rij forms it (:676-681): 48 KL traces, 48 totals, 24 criterion values."""
     import math
     import multiprocessing as mp
@@ -962,17 +964,24 @@ def round3b(np, mn_active_pmf, save, seed, _print):
     steps = 100
     t0 = time.perf_counter()
     jobs = [(a, i, j, v, steps) for i, j in pool for v in a.rating_values]
+    got = []
     with mp.Pool(7) as workers:
-        got = workers.map(_hyp_trunc_mn, jobs, chunksize=1)
+        for r in workers.imap(_hyp_trunc_mn, jobs, chunksize=1):
+            got.append(r)
+            _print('  hypothesis %d/%d, %.0f s' % (len(got), len(jobs), time.perf_counter() - t0))
     _print('c4 truncated pool: %d hypotheses x %d steps, %.0f s' % (len(jobs), steps, time.perf_counter() - t0))
-    assert all(len(r[0]) == steps for r in got)
+    lens = np.array([len(r[0]) for r in got])      # a hypothesis may converge before the cut
+    kls = np.full((len(got), steps), np.nan)
+    for k, r in enumerate(got):
+        kls[k, :lens[k]] = r[0]
+    _print('   accepted steps: %s' % lens.tolist())
     tv = np.array([r[1] for r in got]).reshape(len(pool), 2)
     est = []
     for (i, j), evals in zip(pool, tv):
         mean = np.dot(a.users[i, :], a.items[j, :])
         cdfs = stats.norm.cdf(a.rating_bounds, loc=mean, scale=math.sqrt(a.sigma_sq))
         est.append((evals * np.diff(cdfs)).sum())
-    save('lookahead_c4_pool_ranked', pool=np.array(pool), steps=steps, kls=np.array([r[0] for r in got]),
+    save('lookahead_c4_pool_ranked', pool=np.array(pool), steps=steps, lens=lens, kls=kls,
          tv=tv, vals=np.array(est), order=np.argsort(est, kind='stable'))
 
 
