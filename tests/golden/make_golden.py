@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a', 'r3b': sections V, W (round 3)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a', 'r3b', 'r3c': sections V, W, X (round 3)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -160,6 +160,9 @@ def main():
         return
     if args.only == 'r3a':
         round3a(np, active_pmf, save, seed, _print)
+        return
+    if args.only == 'r3c':
+        round3c(np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r3b':
         round3b(np, mn_active_pmf, save, seed, _print)
@@ -983,6 +986,77 @@ def round3b(np, mn_active_pmf, save, seed, _print):
         est.append((evals * np.diff(cdfs)).sum())
     save('lookahead_c4_pool_ranked', pool=np.array(pool), steps=steps, lens=lens, kls=kls,
          tv=tv, vals=np.array(est), order=np.argsort(est, kind='stable'))
+
+
+def _hyp_refit_mn(args):
+    """One matrix-normal hypothesis with refit_lookahead (mn_active_pmf.py:660-668): the MAP re-fit, the restarted
+    approximation's KL, `steps` accepted fit_normal_kls steps and the total variance there."""
+    import itertools
+    from copy import deepcopy
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+    a, i, j, v, steps = args
+    with threadpool_limits(1):
+        b = deepcopy(a)
+        b.add_rating(i, j, v)
+        lls = [ll for ll in b.fit_lls()]
+        b.initialize_approx()
+        kl0 = b.kl_divergence()
+        kls = np.array(list(itertools.islice(b.fit_normal_kls(), steps)))
+        return b.users.copy(), b.items.copy(), np.array(lls), kl0, kls, b._total_variance()
+
+
+def round3c(np, mn_active_pmf, save, seed, _print):
+    """X. configs[3] as the reference's own Makefile runs it (results/drugbank-94x425/Makefile: LATENT_D = 20,
+    --refit-lookahead): from the MAP estimate of a seeded rank-20 model on the DrugBank subset, every hypothesis of
+    an 8-entry pool x 2 rating values re-fits the MAP estimate (fit_lls to convergence, pmf_cy.pyx:298-301),
+    restarts the approximation from it (initialize_approx, :202-219) and advances it by 60 accepted fit_normal_kls
+    steps; then _total_variance and the expectation over the rating values (:676-681).  Stored: the base MAP state,
+    per hypothesis the log-likelihood trace of the re-fit, the KL of the restarted approximation (a function of the
+    whole re-fitted MAP state), the KL trace, the total; the criterion values and their ranking; the re-fitted MAP
+    state itself for the first two hypotheses."""
+    import math
+    import multiprocessing as mp
+    from scipy import stats
+    g = np.load(os.path.join(HERE, 'mn_c4_94x425_d5.npz'))
+    seed(11)
+    a = mn_active_pmf.MNActivePMF(g['ratings'].copy(), latent_d=20, rating_values=(0., 1.), discrete_expectations=True,
+                                  refit_lookahead=True)
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    users0, items0 = a.users.copy(), a.items.copy()
+    base_lls = np.array([ll for ll in a.fit_lls()])
+    a.initialize_approx()
+    _print('c4 d=20 base MAP: %d fit_lls values, ll %.6f, KL of the restarted approximation %.6f'
+           % (len(base_lls), base_lls[-1], a.kl_divergence()))
+    unrated = sorted(a.unrated)
+    idx = [11, 12, 20011] + [int(x) for x in np.linspace(3000, len(unrated) - 3000, 5)]
+    pool = [unrated[k] for k in idx]
+    steps = 60
+    t0 = time.perf_counter()
+    jobs = [(a, i, j, v, steps) for i, j in pool for v in a.rating_values]
+    got = []
+    with mp.Pool(7) as workers:
+        for r in workers.imap(_hyp_refit_mn, jobs, chunksize=1):
+            got.append(r)
+            _print('  hypothesis %d/%d: %d re-fit values, %d steps, %.0f s' % (len(got), len(jobs), len(r[2]), len(r[4]), time.perf_counter() - t0))
+    lens = np.array([len(r[4]) for r in got])
+    kls = np.full((len(got), steps), np.nan)
+    for k, r in enumerate(got):
+        kls[k, :lens[k]] = r[4]
+    ll_lens = np.array([len(r[2]) for r in got])
+    lls = np.full((len(got), ll_lens.max()), np.nan)
+    for k, r in enumerate(got):
+        lls[k, :ll_lens[k]] = r[2]
+    tv = np.array([r[5] for r in got]).reshape(len(pool), 2)
+    est = []
+    for (i, j), evals in zip(pool, tv):
+        mean = np.dot(a.users[i, :], a.items[j, :])
+        cdfs = stats.norm.cdf(a.rating_bounds, loc=mean, scale=math.sqrt(a.sigma_sq))
+        est.append((evals * np.diff(cdfs)).sum())
+    save('lookahead_c4_d20_refit', users0=users0, items0=items0, base_lls=base_lls, users=a.users, items=a.items,
+         pool=np.array(pool), steps=steps, lens=lens, kls=kls, ll_lens=ll_lens, lls=lls,
+         kl0=np.array([r[3] for r in got]), tv=tv, vals=np.array(est), order=np.argsort(est, kind='stable'),
+         map_users=np.array([got[0][0], got[1][0]]), map_items=np.array([got[0][1], got[1][1]]))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -1306,6 +1306,86 @@ def test_configs3_golden_lookahead_pool_ranking(pkg):
     b.free()
 
 
+def test_configs3_d20_refit_golden(pkg):
+    """configs[3] as the reference's own Makefile runs it - LATENT_D = 20, --refit-lookahead - against the reference
+    itself (make_golden.py section X): the base fit_lls search from the reference's seeded start (85 values), then for
+    an 8-entry pool x 2 rating values the hypothesis chain of mn_active_pmf.py:660-668 with the same device calls the
+    class makes (_lookahead_batch_local): ALL MAP re-fits as one apmf_pmf_batch_fit_lls over the shared container,
+    the restarted approximation (mean = MAP, identity covariances), 60 accepted fit_normal_kls steps, the totals,
+    the expectation over the rating values and the ranking of the pool."""
+    import math
+    from scipy import stats
+    from active_matrix_factorization_amd import _lib
+    g = load_golden('mn_c4_94x425_d5')
+    x = load_golden('lookahead_c4_d20_refit')
+    a = pkg.mn.MNActivePMF(g['ratings'].copy(), latent_d=20, rating_values=(0., 1.), discrete_expectations=True,
+                           refit_lookahead=True)
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(v) for v in g['sigma'])
+    a.users, a.items = x['users0'].copy(), x['items0'].copy()
+    lls = np.array(list(a.fit_lls()))
+    assert len(lls) == len(x['base_lls'])
+    np.testing.assert_allclose(lls, x['base_lls'], rtol=1e-10)
+    print('base MAP: worst |difference| users %.2g items %.2g' % (np.abs(a.users - x['users']).max(), np.abs(a.items - x['items']).max()))
+    np.testing.assert_allclose(a.users, x['users'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(a.items, x['items'], rtol=0, atol=1e-9)
+    a.users, a.items = x['users'].copy(), x['items'].copy()       # the hypotheses start from the reference's MAP state
+    a.initialize_approx()
+    pool = [tuple(int(v) for v in ij) for ij in x['pool']]
+    steps = int(x['steps'])
+    hyps = [(i, j, float(v)) for i, j in pool for v in a.rating_values]
+    H = len(hyps)
+    ctx, rt = a._device_ratings()
+    n_u, n_all, d = a.num_users, a.num_users + a.num_items, a.latent_d
+    dd_, s_, su_, sv_, sub_, _mr = a._hyper()
+    dU = ctx.array(np.broadcast_to(a.users, (H,) + a.users.shape), np.float64)
+    dV = ctx.array(np.broadcast_to(a.items, (H,) + a.items.shape), np.float64)
+    hv = np.array([h[2] for h in hyps])
+    means_r = [float(np.mean(np.append(a.ratings[:, 2], v))) for v in hv] if sub_ else None
+    ll, nst, conv = ctx.pmf_batch_fit_lls(rt, dU, dV, d, H, [h[0] for h in hyps], [h[1] for h in hyps], hv, s_, su_, sv_,
+                                          sub_, means_r, float(a.learning_rate), float(a.min_learning_rate),
+                                          float(a.stop_thresh))
+    assert conv.all()
+    ref_ll = np.array([x['lls'][h, x['ll_lens'][h] - 1] for h in range(H)])
+    print('MAP re-fits: accepted steps', nst.tolist(), 'reference values', x['ll_lens'].tolist())
+    assert np.array_equal(nst, x['ll_lens'])
+    print('re-fitted LL: worst relative difference %.2g' % np.abs(ll / ref_ll - 1).max())
+    np.testing.assert_allclose(ll, ref_ll, rtol=5e-6)       # 8e-7 measured: 60-85 steps of the x1.25 search amplify rounding
+    U, V = dU.to_host().reshape(H, n_u, d), dV.to_host().reshape(H, n_all - n_u, d)
+    for h in range(2):
+        print('re-fitted MAP %d: worst |difference| %.2g %.2g' % (h, np.abs(U[h] - x['map_users'][h]).max(), np.abs(V[h] - x['map_items'][h]).max()))
+        np.testing.assert_allclose(U[h], x['map_users'][h], rtol=0, atol=5e-9)
+        np.testing.assert_allclose(V[h], x['map_items'][h], rtol=0, atol=5e-9)
+    d_means = ctx.empty((H, n_all, d))
+    _lib._check(ctx._lib.apmf_d2d_2d(ctx._h, d_means.ptr, n_all * d * 8, dU.ptr, n_u * d * 8, n_u * d * 8, H))
+    _lib._check(ctx._lib.apmf_d2d_2d(ctx._h, d_means.ptr + n_u * d * 8, n_all * d * 8, dV.ptr, (n_all - n_u) * d * 8,
+                                     (n_all - n_u) * d * 8, H))
+    b = ctx.mn_batch(rt, d, H, trace_cap=steps)
+    b.set_state(d_means, ctx.array(np.eye(n_all)), ctx.array(np.eye(d)), per_hypothesis=1)
+    b.set_extra([h[0] for h in hyps], [h[1] for h in hyps], [h[2] for h in hyps])
+    sig = a._sigmas()
+    kl0 = b.kl(sig[0], sig[1], sig[2])
+    print('KL of the restarted approximation: worst relative difference %.2g' % np.abs(kl0 / x['kl0'] - 1).max())
+    np.testing.assert_allclose(kl0, x['kl0'], rtol=1e-7)        # a function of the whole re-fitted MAP state
+    lr, kl, fst, fconv, trace = b.fit(sig[0], sig[1], sig[2], a.min_eig, a.normal_learning_rate, None, max_steps=steps)
+    assert np.array_equal(fst, x['lens'])
+    rel = np.abs(trace / x['kls'] - 1)
+    by_step = np.nanmax(rel, axis=0)
+    print('worst relative KL difference by step 20/40/60: %.2g %.2g %.2g' % tuple(by_step[:k].max() for k in (20, 40, 60)))
+    assert by_step.max() < 2e-7                       # 3e-8 measured: inherited from the re-fitted MAP states
+    tv = b.total_variance().reshape(len(pool), 2)
+    print('totals: worst relative difference %.2g' % np.abs(tv / x['tv'] - 1).max())
+    np.testing.assert_allclose(tv, x['tv'], rtol=1e-7)
+    est = []
+    for (i, j), evals in zip(pool, tv):
+        mean = float(np.dot(a.users[i, :], a.items[j, :]))
+        cdfs = stats.norm.cdf(a.rating_bounds, loc=mean, scale=math.sqrt(a.sigma_sq))
+        est.append((evals * np.diff(cdfs)).sum())
+    print('criterion values: worst relative difference %.2g' % np.abs(np.array(est) / x['vals'] - 1).max())
+    np.testing.assert_allclose(est, x['vals'], rtol=1e-7)
+    assert np.array_equal(np.argsort(est, kind='stable'), x['order'])
+    b.free()
+
+
 def test_headline_shape_golden_scoring_and_selection(pkg):
     """BASELINE.json's metric shape - 943 x 1682, rank 10 - recorded from the real reference
     (make_golden.py section J: approx_pred_means_vars over all 1 586 126 entries, pick_query_point over
