@@ -413,10 +413,13 @@ static int gibbs_rows(apmf_ctx *ctx, const apmf_ratings *r, int side, int row_lo
     if (smem > 64 * 1024)
         APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_gibbs_rows<4>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    if (tl == 1) LAUNCH_GIBBS(1);
-    else if (tl == 2) LAUNCH_GIBBS(2);
-    else if (tl == 3) LAUNCH_GIBBS(3);
-    else LAUNCH_GIBBS(4);
+    {
+        ProfScope prof(ctx);
+        if (tl == 1) LAUNCH_GIBBS(1);
+        else if (tl == 2) LAUNCH_GIBBS(2);
+        else if (tl == 3) LAUNCH_GIBBS(3);
+        else LAUNCH_GIBBS(4);
+    }
 #undef LAUNCH_GIBBS
     APMF_CHECK_LAUNCH();
     int status = 0;

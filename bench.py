@@ -91,6 +91,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-class-level', action='store_true')
     ap.add_argument('--no-f64', action='store_true', help='skip the float64 sweep legs (roofline_f64)')
+    ap.add_argument('--no-gibbs', action='store_true', help='skip the configs[2] Gibbs / sample-statistics leg')
     ap.add_argument('--no-lookahead', action='store_true', help='skip the configs[3] batched-lookahead leg')
     ap.add_argument('--lookahead-candidates', type=int, default=100, help='pool size of the lookahead leg (x 5 rating values)')
     args = ap.parse_args()
@@ -296,6 +297,9 @@ def main():
         cl = class_level(ctx, ratings, rs)
         if out is not None:
             out['class_level'] = cl
+    if world == 1 and not args.no_gibbs:
+        print('bench.py: Gibbs sweep and sample statistics at configs[2] ...', file=sys.stderr, flush=True)
+        out['gibbs'] = gibbs_leg(ctx, ratings)
     if world == 1 and not args.no_lookahead:
         # the product's real hot loop: the batched one-step lookahead (K6) at configs[3]'s shape
         print('bench.py: batched lookahead at configs[3] (about 15 s) ...', file=sys.stderr, flush=True)
@@ -450,6 +454,76 @@ def f64_sweeps(ctx, B, ld, d_mean, d_cross, d_diag, d_omega, d_mask, K, W):
     sums = dsum.to_host()
     if not (np.isfinite(sums).all() and (sums > 0).all()):
         sys.exit('bench.py: the float64 sweep produced invalid sums')
+    return out
+
+
+def gibbs_leg(ctx, ratings, d=15, S=128):
+    """BASELINE.json configs[2] (the Bayesian class at 943 x 1682, rank 15): K3 - one Gibbs sweep = the user
+    half-sweep and the item half-sweep (bayes_pmf.py:266-300: per row alpha + beta F'F, its Cholesky factor, the
+    draw) - and K4 - the statistics of the predicted matrix over S = 128 samples (bayes_pmf.py:361-440), the
+    f64-MFMA kernel.  HIP events around each launch, in-library."""
+    from active_matrix_factorization_amd import _lib
+    n, m, N = N_USERS, N_ITEMS, ratings.shape[0]
+    rs = np.random.RandomState(7)
+    rt = ctx.ratings(ratings, n, m)
+    V = ctx.array(rs.normal(size=(m, d)))
+    al, mu = ctx.array(np.eye(d) * 2.), ctx.array(np.zeros(d))
+    zu, zv = ctx.array(rs.normal(size=(n, d))), ctx.array(rs.normal(size=(m, d)))
+    ou, ov = ctx.empty((n, d)), ctx.empty((m, d))
+
+    def sweep():
+        ctx.gibbs_half_sweep(rt, 0, V, d, al, mu, 2., 0., zu, ou)
+        ctx.gibbs_half_sweep(rt, 1, ou, d, al, mu, 2., 0., zv, ov)
+    for _ in range(3):
+        sweep()
+    ctx.sync()
+    R = 50
+    ctx.profile_begin(2 * R)
+    t0 = time.perf_counter()
+    for _ in range(R):
+        sweep()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / R
+    ms = ctx.profile_end()
+    ms = ms[ms > 0]
+    pair = float(ms.sum() / R) if ms.size else None
+    # per row: its ratings (4 B index + 8 B value) and the other side's factor row per rating, z in, the row out
+    algo = 2 * N * (12 + 8 * d) + 2 * (n + m) * d * 8
+    # per rating a rank-1 update of the d x d precision (d^2 multiply-adds on the lower+upper square as the
+    # reference's F'F forms it) and of the d-vector; per row the factorisation and two triangular solves
+    flops = 2 * N * (2 * d * d + 2 * d) + (n + m) * (d ** 3 / 3 + 4 * d * d)
+    out = {'workload': 'configs[2]: 943x1682 rank %d, N=%d' % (d, N), 'dtype': 'f64',
+           'k3_sweep': {'kernel_ms_per_sweep': pair, 'ms_per_sweep_wall': dt * 1e3,
+                        'row_updates_per_s': (n + m) / (pair * 1e-3) if pair else None,
+                        'algorithmic_GBs': algo / (pair * 1e-3) / 1e9 if pair else None,
+                        'gflops': flops / (pair * 1e-3) / 1e9 if pair else None,
+                        'note': 'two launches of 943 / 1682 one-wave workgroups: latency-bound at this shape'}}
+    Us, Vs = ctx.array(rs.normal(size=(S, n, d))), ctx.array(rs.normal(size=(S, m, d)))
+    ld = _lib.grid_ld(m)
+    gv, gm = ctx.empty((n, ld)), ctx.empty((n, ld))
+    for _ in range(2):
+        ctx.sample_stats(S, n, m, d, ld, Us, Vs, 0., 0., mean=gm, var=gv)
+    ctx.sync()
+    R = 20
+    ctx.profile_begin(R)
+    for _ in range(R):
+        ctx.sample_stats(S, n, m, d, ld, Us, Vs, 0., 0., mean=gm, var=gv)
+    ctx.sync()
+    ms = ctx.profile_end()
+    ms = ms[ms > 0]
+    avg = float(ms.mean()) if ms.size else None
+    dp = (d + 3) // 4 * 4
+    mf = 2. * dp * S * n * m
+    out['k4_sample_stats'] = {'samples': S, 'avg_kernel_ms': avg, 'bound': 'mfma', 'unit': 'TFLOP/s',
+                              'peak': F64_MFMA_PEAK_TFLOPS,
+                              'achieved': mf / (avg * 1e-3) / 1e12 if avg else None,
+                              'frac': mf / (avg * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS if avg else None,
+                              'flops_per_launch': mf,
+                              'note': 'MFMA flops of the S x n x m inner products at d padded to %d; the mean / variance '
+                                      'accumulation rides on the VALU beside them' % dp}
+    if not np.isfinite(gv.to_host()[:, :m]).all():
+        sys.exit('bench.py: the sample-statistics kernel produced non-finite values')
+    rt.free()
     return out
 
 

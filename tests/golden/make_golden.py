@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a', 'r3b', 'r3c': sections V, W, X (round 3)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3d': sections V, W, X, Y (round 3)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -163,6 +163,9 @@ def main():
         return
     if args.only == 'r3c':
         round3c(np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r3d':
+        round3d(np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r3b':
         round3b(np, mn_active_pmf, save, seed, _print)
@@ -1057,6 +1060,46 @@ def round3c(np, mn_active_pmf, save, seed, _print):
          pool=np.array(pool), steps=steps, lens=lens, kls=kls, ll_lens=ll_lens, lls=lls,
          kl0=np.array([r[3] for r in got]), tv=tv, vals=np.array(est), order=np.argsort(est, kind='stable'),
          map_users=np.array([got[0][0], got[1][0]]), map_items=np.array([got[0][1], got[1][1]]))
+
+
+def _continuous_exp(args):
+    """E[total variance | R_ij] by the reference's CONTINUOUS integration (mn_active_pmf.py:683-691:
+    stats.norm.expect over mean +- 2 sd, epsrel .02), recording every integrand evaluation."""
+    import warnings
+    import numpy as np
+    from threadpoolctl import threadpool_limits
+    a, ij, use_map = args
+    seen = []
+
+    def fn(apmf, v):
+        t = apmf._total_variance()
+        seen.append((v, t))
+        return t
+    with threadpool_limits(1), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        est = a._exp_with_rij(ij, fn, use_map=use_map, pass_v=True)
+    return est, np.array(seen)
+
+
+def round3d(np, mn_active_pmf, save, seed, _print):
+    """Y. The CONTINUOUS lookahead (rating_values=None - the class default): exp_total_variance and
+    exp_total_variance_byapprox of two candidates on the state of section E2 (config 1), with every point the
+    adaptive quadrature asked for and the integrand's value there (a fit_normal to convergence per point)."""
+    import multiprocessing as mp
+    g = np.load(os.path.join(HERE, 'lookahead_c1_mn.npz'))
+    a = mn_active_pmf.MNActivePMF(g['ratings'].copy(), latent_d=2)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+    pool = sorted(a.unrated)[:2]
+    jobs = [(a, ij, um) for um in (True, False) for ij in pool]
+    t0 = time.perf_counter()
+    with mp.Pool(4) as workers:
+        got = workers.map(_continuous_exp, jobs, chunksize=1)
+    _print('continuous lookahead: %d integrals, %s evaluations, %.0f s' % (len(got), [len(r[1]) for r in got], time.perf_counter() - t0))
+    out = dict(pool=np.array(pool), est_map=np.array([got[0][0], got[1][0]]), est_approx=np.array([got[2][0], got[3][0]]))
+    for k, name in enumerate(('map0', 'map1', 'approx0', 'approx1')):
+        out['evals_' + name] = got[k][1]
+    save('lookahead_c1_mn_continuous', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -1002,6 +1002,58 @@ def test_lookahead_continuous_batched_equals_one_at_a_time(pkg, monkeypatch):
         assert batched[0] == alone[0] and np.isfinite(batched).all(), key
 
 
+def test_lookahead_continuous_golden(pkg):
+    """The CONTINUOUS lookahead against the reference itself (make_golden.py section Y: exp_total_variance and
+    exp_total_variance_byapprox of two config-1 candidates, with every point the adaptive quadrature asked for and
+    the integrand there).  The points of the quadrature's first pass over its intervals - which the package predicts,
+    to evaluate them as one batch - are all among the ones the reference's run asked for, bit for bit; the integrand there (a fit_normal to
+    convergence per point) to 1e-8 and the integrals to 1e-9 (the reference's own call asks for epsrel .02; both sides
+    run into its subdivision limit over the same 800 ... 2000 points)."""
+    import math
+    import warnings
+    from active_matrix_factorization_amd import _active_base as base
+    g = load_golden('lookahead_c1_mn')
+    y = load_golden('lookahead_c1_mn_continuous')
+    MN = pkg.mn.MNActivePMF
+    a = MN(g['ratings'].copy(), latent_d=2)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = g['mean'].copy(), g['cov_useritems'].copy(), g['cov_latents'].copy()
+    pool = [tuple(int(v) for v in ij) for ij in y['pool']]
+    assert pool == sorted(a.unrated)[:2]
+    for k, (i, j) in enumerate(pool):
+        for name in ('map', 'approx'):
+            if name == 'map':
+                mean, var = float(np.dot(a.users[i], a.items[j])), a.sigma_sq
+            else:
+                mean, var = a.approx_pred_mean_var(i, j)
+            std = math.sqrt(var)
+            q = base._Quadrature(mean, std, mean - 2 * std, mean + 2 * std)
+            ev = y['evals_%s%d' % (name, k)]
+            nodes = len(q.first_pass)
+            assert nodes >= 21 and q.intervals is not None
+            # the first interval's 21 points open the reference's run; the other intervals' first passes come
+            # once the adaptive routine is through with the interval before - every predicted point IS asked for
+            # (bit for bit with the MAP mean; the approximation's mean and variance carry our own last-place rounding)
+            tol = 0. if name == 'map' else 1e-12
+            fp = np.array(q.first_pass)
+            assert np.abs(fp[:21] - ev[:21, 0]).max() <= tol * np.abs(fp).max()
+            near = np.abs(ev[:, 0][None, :] - fp[:, None]).argmin(axis=1)
+            assert np.abs(ev[near, 0] - fp).max() <= tol * np.abs(fp).max()
+            ref = ev[near, 1]
+            got = a._lookahead_batch_local([(i, j, v) for v in q.first_pass], MN._total_variance, False)
+            worst = np.abs(np.array(got) / ref - 1).max()
+            print('candidate %d %s: %d first-pass nodes, integrand worst relative difference %.2g; the reference made %d evaluations'
+                  % (k, name, nodes, worst, len(ev)))
+            assert worst < 1e-8                      # 1.4e-10 measured
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')              # IntegrationWarning: the subdivision limit, as in the reference
+        est_map = a._get_key_vals(pool, pkg.mn.KEY_FUNCS['total-variance'])
+        est_approx = a._get_key_vals(pool, pkg.mn.KEY_FUNCS['total-variance-approx'])
+    print('integrals: map', est_map, y['est_map'].tolist(), 'approx', est_approx, y['est_approx'].tolist())
+    np.testing.assert_allclose(est_map, y['est_map'], rtol=1e-9)         # 1e-13 measured: the same ~1000-2000 points
+    np.testing.assert_allclose(est_approx, y['est_approx'], rtol=1e-9)   # are asked for, bisection by bisection
+
+
 def test_lookahead_batched_refit_equals_per_hypothesis(pkg, monkeypatch):
     """--refit-lookahead: every hypothesis re-fits the MAP estimate first and restarts the
     approximation from it (mn_active_pmf.py:662-665)."""
