@@ -14,7 +14,10 @@
 // chunks of the row-major sample arrays (32 rows of U_s, 64 rows of V_s): they are staged
 // into LDS (double-buffered, the next sample's chunk in flight during this sample's
 // MFMAs) and the 4 waves read their MFMA operands from there (lane l: row / column l & 15,
-// k = 4 q + (l >> 4)).  Measured 943 x 1682, d = 15, S = 128: 0.25 ms = 26 TFLOP/s (the 8 x 2 VALU
+// k = 4 q + (l >> 4)).  Measured 943 x 1682, d = 15, S = 128: 0.22-0.23 ms = 28-29 TFLOP/s (round 2: 0.25-0.27 ms;
+// with parts of the sample loop compiled out: no staging 0.17 ms, no statistics 0.21, no barrier 0.215, LDS reads +
+// MFMAs alone 0.15 - against 0.083 for the MFMAs at their peak rate and 0.11 for the 4-blocks-on-some-CUs
+// placement of 810 blocks; the 8 x 2 VALU
 // micro-tile kernel: 0.80 ms; per-wave operand gathers from global memory: 0.49 ms; a flat LDS copy
 // with run-time row length: 0.40 ms, VALU-bound on address arithmetic).
 // Variance is accumulated around the first sample (shifted sums), which matches numpy's
@@ -44,9 +47,21 @@ __device__ __forceinline__ void lds_barrier()
 // the contraction loop has no VALU instruction left.  (The flat copy with run-time d it replaces
 // spent 242 VALU instructions per wave and sample - address arithmetic - against 8 MFMAs: the
 // kernel was VALU-bound at 16 TFLOP/s.)
+//
+// Staging (round 3).  Thread (rp, sk) copies element sk of rows rp, rp + RPP, ... of the U part and of the V part:
+// per pass ONE global load at (scalar base of the sample) + (a 32-bit offset fixed for the whole launch) and ONE
+// LDS store at a fixed offset.  There are no masks and no branches: a thread without a slot of its own - beyond the
+// RPP x DP threads that tile a pass, a padding column k >= d, a row past the part or past the matrix edge - repeats
+// the copy of a thread that has one (same source, same destination, same value), and the padding columns are zeroed
+// once before the loop.  Rows past the matrix edge so hold a copy of its last row; their products are never written.
+// The sample loop is one basic block with the loads fenced above the MFMAs: in the round-2 form the compiler sank
+// them into the conditional store block BELOW the MFMAs (next to their use), so that every sample waited out the
+// whole L2 latency, and spent ~50 VALU instructions per sample on addresses and selects beside 8 MFMAs.
+// PROB: the exceedance counts (prob_ge_cutoff) are compiled in only where asked for (two VALU instructions and a
+// register per candidate and sample).
 // (NQ <= 5 is held to 128 VGPRs = 4 blocks per CU: at 943 x 1682 the 810 blocks then run as one wave
 // of blocks instead of two)
-template <int NQ>
+template <int NQ, bool PROB>
 __global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, int n, int m, int d, int ld,
                                                       const double *__restrict__ Us,
                                                       const double *__restrict__ Vs, double add,
@@ -57,7 +72,7 @@ __global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, in
     constexpr int DP = 4 * NQ;             // padded row length
     constexpr int LS = DP + 2;             // LDS row pitch (doubles)
     constexpr int RPP = 256 / DP;          // rows staged per pass of the block
-    constexpr int NIT = (BR + BC + RPP - 1) / RPP;
+    constexpr int NITU = (BR + RPP - 1) / RPP, NITV = (BC + RPP - 1) / RPP;
     constexpr int TILE = (BR + BC) * LS;
     extern __shared__ __attribute__((aligned(16))) double sm[];   // 2 x (BR + BC) x LS
     const int lane = threadIdx.x & 63;
@@ -65,33 +80,39 @@ __global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, in
     const int wr = wave >> 1, wc = wave & 1;
     const int ri = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.y * BR, col0 = blockIdx.x * BC;
+    const int u_rows = min(BR, n - row0), v_rows = min(BC, m - col0);   // >= 1: the grid covers ld < m + BC columns
 
-    // staging: thread (rp, k) = (tid / DP, tid % DP) takes element k of rows rp, rp + RPP, ...
-    const int sk = (int)threadIdx.x % DP, rp = (int)threadIdx.x / DP;
-    const bool s_act = rp < RPP;
-    const int u_rows = min(BR, n - row0), v_rows = max(0, min(BC, m - col0));
-    const bool k_in = sk < d;
-    double stg[NIT];
-    auto fetch = [&](int s) {
-        const double *ub = Us + ((size_t)s * n + row0) * d;
-        const double *vb = Vs + ((size_t)s * m + col0) * d;
+    const int tq = (int)threadIdx.x % (RPP * DP);
+    const int sk = min(tq % DP, d - 1), rp = tq / DP;
+    unsigned gu[NITU], gv[NITV];           // byte offsets from the sample's first row of the block
+    unsigned lu[NITU], lv[NITV];           // byte offsets into an LDS image
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int row = it * RPP + rp;
-            const bool isv = row >= BR;
-            const int cr = isv ? row - BR : row;
-            const bool ok = s_act && k_in && cr < (isv ? v_rows : u_rows);
-            const double x = *(ok ? (isv ? vb : ub) + cr * d + sk : Us);   // always a valid address
-            stg[it] = ok ? x : 0.;
-        }
+    for (int it = 0; it < NITU; it++) {
+        const int row = min(it * RPP + rp, BR - 1);
+        gu[it] = (unsigned)((min(row, u_rows - 1) * d + sk) * 8);
+        lu[it] = (unsigned)((row * LS + sk) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NITV; it++) {
+        const int row = min(it * RPP + rp, BC - 1);
+        gv[it] = (unsigned)((min(row, v_rows - 1) * d + sk) * 8);
+        lv[it] = (unsigned)(((BR + row) * LS + sk) * 8);
+    }
+    double su[NITU], sv[NITV];
+    auto fetch = [&](int s) {
+        const char *ub = (const char *)(Us + ((size_t)s * n + row0) * d);
+        const char *vb = (const char *)(Vs + ((size_t)s * m + col0) * d);
+#pragma unroll
+        for (int it = 0; it < NITU; it++) su[it] = *(const double *)(ub + gu[it]);
+#pragma unroll
+        for (int it = 0; it < NITV; it++) sv[it] = *(const double *)(vb + gv[it]);
     };
     auto commit = [&](int buf) {
-        double *dst = sm + (size_t)buf * TILE + sk;
+        char *dst = (char *)(sm + (size_t)buf * TILE);
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int row = it * RPP + rp;
-            if (s_act && row < BR + BC) dst[row * LS] = stg[it];
-        }
+        for (int it = 0; it < NITU; it++) *(double *)(dst + lu[it]) = su[it];
+#pragma unroll
+        for (int it = 0; it < NITV; it++) *(double *)(dst + lv[it]) = sv[it];
     };
 
     // operand slots of this lane within an LDS image: U row (16 wr + ri), V rows (32 wc + 16 t + ri),
@@ -109,11 +130,14 @@ __global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, in
         for (int r = 0; r < 4; r++) { c[t][r] = 0.; s1[t][r] = 0.; s2[t][r] = 0.; cnt[t][r] = 0; }
 
     fetch(0);
+    for (int k = threadIdx.x; k < 2 * TILE; k += 256) sm[k] = 0.;      // the padding columns stay zero from here on
+    __syncthreads();
     commit(0);
     __syncthreads();
     for (int s = 0; s < S; s++) {
         const int buf = s & 1;
         fetch(min(s + 1, S - 1));            // the last sample re-reads itself: no branch
+        __builtin_amdgcn_sched_barrier(0);   // the loads are in flight during this sample's MFMAs
         const double *img = sm + (size_t)buf * TILE;
         f64x4 acc[CT];
 #pragma unroll
@@ -125,6 +149,7 @@ __global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, in
             for (int t = 0; t < CT; t++)
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, img[boff[t] + 4 * q], acc[t], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         commit(buf ^ 1);
         if (s == 0) {            // the shift of the running sums is the first sample
 #pragma unroll
@@ -140,7 +165,7 @@ __global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, in
                 const double dlt = xv - c[t][r];
                 s1[t][r] += dlt;
                 s2[t][r] = fma(dlt, dlt, s2[t][r]);
-                cnt[t][r] += (xv >= cutoff) ? 1 : 0;
+                if (PROB) cnt[t][r] += (xv >= cutoff) ? 1 : 0;
             }
         lds_barrier();
     }
@@ -160,7 +185,7 @@ __global__ __launch_bounds__(256, NQ <= 5 ? 4 : 2) void k_sample_stats(int S, in
             const bool pad = col >= m;          // padding columns stay zero
             if (o_mean) o_mean[o] = pad ? 0. : c[t][r] + md;
             if (o_var) o_var[o] = pad ? 0. : var;
-            if (o_prob) o_prob[o] = pad ? 0. : (double)cnt[t][r] / (double)S;
+            if (PROB) o_prob[o] = pad ? 0. : (double)cnt[t][r] / (double)S;
         }
     }
 }
@@ -183,11 +208,19 @@ extern "C" int apmf_sample_stats_f64(apmf_ctx *ctx, int S, int n, int m, int d, 
 #define APMF_K4(NQ)                                                                                \
     case NQ: {                                                                                     \
         if (smem > 64 * 1024)                                                                      \
-            APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_sample_stats<NQ>,                   \
+        {                                                                                          \
+            APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_sample_stats<NQ, false>,            \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+            APMF_CHECK_HIP(hipFuncSetAttribute((const void *)k_sample_stats<NQ, true>,             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        }                                                                                          \
         ProfScope prof(ctx);                                                                       \
-        hipLaunchKernelGGL((k_sample_stats<NQ>), grid, dim3(256), smem, ctx->stream, S, n, m, d, ld, d_Us, \
-                           d_Vs, add, cutoff, d_mean, d_var, d_prob);                              \
+        if (d_prob)                                                                                \
+            hipLaunchKernelGGL((k_sample_stats<NQ, true>), grid, dim3(256), smem, ctx->stream, S, n, m, d, ld, \
+                               d_Us, d_Vs, add, cutoff, d_mean, d_var, d_prob);                    \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_sample_stats<NQ, false>), grid, dim3(256), smem, ctx->stream, S, n, m, d, ld, \
+                               d_Us, d_Vs, add, cutoff, d_mean, d_var, d_prob);                    \
     } break;
     switch (nq) {
         APMF_K4(1) APMF_K4(2) APMF_K4(3) APMF_K4(4) APMF_K4(5) APMF_K4(6) APMF_K4(7) APMF_K4(8)

@@ -699,6 +699,12 @@ def test_sample_stats_shapes_vs_oracle(ctx, shape):
     x = np.einsum('sik,sjk->sij', Us, Vs) + 1.25
     safe = np.all(np.abs(x - 1.5) > 1e-9, axis=0)
     assert np.array_equal(ctx.download_grid(prob, m)[safe], op[safe])
+    # the variant compiled without the exceedance counts (pred_variance / predict alone): the same bits
+    mean2, var2 = ctx.empty((n, ld)), ctx.empty((n, ld))
+    ctx.sample_stats(S, n, m, d, ld, ctx.array(Us), ctx.array(Vs), 1.25, 1.5, mean=mean2, var=var2)
+    assert np.array_equal(mean2.to_host(), mean.to_host()) and np.array_equal(var2.to_host(), var.to_host())
+    # padding columns of the grids are written as zeros
+    assert not mean.to_host()[:, m:].any() and not var.to_host()[:, m:].any() and not prob.to_host()[:, m:].any()
 
 
 # ---------------------------------------------------------------------------- dense (rocSOLVER)
