@@ -108,6 +108,27 @@ __device__ __forceinline__ void tile_mfma(f64x4 (&acc)[2][2], const double (*A)[
     const bool ru[2] = {32 * (w >> 1) < rmax, 32 * (w >> 1) + 16 < rmax};      // wave-uniform
     const bool cv[2] = {32 * (w & 1) < cmax, 32 * (w & 1) + 16 < cmax};
     if (!ru[0] || !cv[0]) return;
+    if (ru[1] && cv[1]) {
+        // all four accumulators kept (every tile but those of a short last block): straight-line code - with the
+        // wave-uniform tests below every MFMA sits in a basic block of its own, and no operand read of the next
+        // k-step can be hoisted above the products of this one
+        auto step = [&](int k0) {
+            const int k = k0 + g;
+            const double a0 = FORM == MM_TN ? A[k][r0] : A[r0][k], a1 = FORM == MM_TN ? A[k][r0 + 16] : A[r0 + 16][k];
+            const double b0 = FORM == MM_NT ? B[c0][k] : B[k][c0], b1 = FORM == MM_NT ? B[c0 + 16][k] : B[k][c0 + 16];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        };
+        if (K == 64) {
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 4) step(k0);
+        } else {
+            for (int k0 = 0; k0 < K; k0 += 4) step(k0);
+        }
+        return;
+    }
     for (int k0 = 0; k0 < K; k0 += 4) {
         const int k = k0 + g;
         double a[2], b[2];
@@ -148,7 +169,7 @@ struct TileRegs {
         for (int q = 0; q < PER; q++) {
             const int e = (int)threadIdx.x + 256 * q;
             const int i = min(row0 + e / C, row_end - 1), j = min(col0 + e % C, col_end - 1);
-            v[q] = src[(size_t)i * ld + j];
+            v[q] = gmem(src)[(size_t)i * ld + j];
         }
     }
     static __device__ __forceinline__ int row(int q) { return ((int)threadIdx.x + 256 * q) / C; }
@@ -325,13 +346,14 @@ __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k
     const double *__restrict__ linv = ch_linv(job, k);
     __shared__ double P[CH_NB][TP], X[CH_NB][TP];
     const int nb = min(CH_NB, N - k);
-    if (*job.info != 0) return;
+    const int info0 = *gmem(job.info);   // requested first, tested after the tiles are requested: one round trip, not two
     const int r0 = k + nb + bx * 64;
     const int rows = min(64, N - r0);
     {
         TileRegs<CH_NB, CH_NB> x, t;
         x.load(linv, CH_NB, 0, 0, CH_NB, CH_NB);
         t.load(A, N, r0, k, N, N);
+        if (info0 != 0) return;
 #pragma unroll
         for (int q = 0; q < t.PER; q++) {
             const int i = t.row(q), j = t.col(q);
@@ -344,7 +366,40 @@ __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k
     tile_mfma<MM_NT>(acc, P, X, CH_NB, rows, nb);
     TILE_FOR_EACH(u, v, r) {
         const int i = tile_row(u, r), j = tile_col(v);
-        if (i < rows && j < nb) A[(size_t)(r0 + i) * N + k + j] = acc[u][v][r];
+        if (i < rows && j < nb) gmem(A)[(size_t)(r0 + i) * N + k + j] = acc[u][v][r];
+    }
+}
+
+// acc += Pi Pj' over one staged half-panel of KS columns (the wave's 2 x 2 accumulators; see tile_mfma for the
+// skipping of accumulators outside a short last block and for why the all-kept case is straight-line code)
+template <int KS, int KP>
+__device__ __forceinline__ void half_panel_mfma(f64x4 (&acc)[2][2], const double (*Pi)[KP], const double (*Pj)[KP],
+                                                int r0, int c0, int g, const bool (&ru)[2], const bool (&cv)[2])
+{
+    if (!ru[0] || !cv[0]) return;
+    if (ru[1] && cv[1]) {
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += 4) {
+            const int kk = k0 + g;
+            const double a0 = Pi[r0][kk], a1 = Pi[r0 + 16][kk], b0 = Pj[c0][kk], b1 = Pj[c0 + 16][kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < KS; k0 += 4) {
+        const int kk = k0 + g;
+        double a[2], b[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) { a[u] = ru[u] ? Pi[r0 + 16 * u][kk] : 0.; b[u] = cv[u] ? Pj[c0 + 16 * u][kk] : 0.; }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int v = 0; v < 2; v++)
+                if (ru[u] && cv[v]) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
     }
 }
 
@@ -384,15 +439,16 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
     const int i0 = base + ti * 64, j0 = base + tj * 64;
     // everything the block reads is requested up front: the tile being updated and the first
     // half-panels; the second half-panels while the first are multiplied
+    const int info0 = *gmem(job.info);   // (first: loads return in order, its wait leaves the tiles in flight)
     f64x4 old[2][2];
     TILE_FOR_EACH(u, v, r) {
         const int i = min(i0 + tile_row(u, r), N - 1), j = min(j0 + tile_col(v), N - 1);
-        old[u][v][r] = A[(size_t)i * N + j];
+        old[u][v][r] = gmem(A)[(size_t)i * N + j];
     }
     TileRegs<64, KS> pi, pj;
     pi.load(A, N, i0, k, N, N);
     pj.load(A, N, j0, k, N, N);
-    if (*job.info != 0) return;
+    if (info0 != 0) return;
     f64x4 acc[2][2] = {};
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane & 15, g = lane >> 4;
@@ -414,24 +470,12 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
             pj.load(A, N, j0, k + ks + KS, N, N);
         }
         __syncthreads();
-        if (ru[0] && cv[0])
-#pragma unroll
-        for (int k0 = 0; k0 < KS; k0 += 4) {
-            const int kk = k0 + g;
-            double a[2], b[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) { a[u] = ru[u] ? Pi[r0 + 16 * u][kk] : 0.; b[u] = cv[u] ? Pj[c0 + 16 * u][kk] : 0.; }
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int v = 0; v < 2; v++)
-                    if (ru[u] && cv[v]) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
-        }
+        half_panel_mfma<KS, KP>(acc, Pi, Pj, r0, c0, g, ru, cv);
     }
     if (!NEXT || bx != 0) {
         TILE_FOR_EACH(u, v, r) {
             const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
-            if (i < N && j <= i) A[(size_t)i * N + j] = old[u][v][r] - acc[u][v][r];
+            if (i < N && j <= i) gmem(A)[(size_t)i * N + j] = old[u][v][r] - acc[u][v][r];
         }
         return;
     }
@@ -475,10 +519,11 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
     double (*Pi)[KP] = (double (*)[KP])stat_lds;
     double (*Pj)[KP] = Pi + 64;
     const int j0 = jb * CH_NB, i0 = j0 + bx * 64;
+    const int info0 = *gmem(job.info);   // (first: loads return in order, its wait leaves the tiles in flight)
     f64x4 old[2][2];
     TILE_FOR_EACH(u, v, r) {
         const int i = min(i0 + tile_row(u, r), N - 1), j = min(j0 + tile_col(v), N - 1);
-        old[u][v][r] = A[(size_t)i * N + j];
+        old[u][v][r] = gmem(A)[(size_t)i * N + j];
     }
     // Two half-panels of operands are in flight: the loads of half-panel h + 2 are issued while h is multiplied, so a
     // load has two multiply phases to arrive in (one was not enough: a block spent 2.8 us per half-panel, 0.85 of them
@@ -490,7 +535,7 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
         pi1.load(A, N, i0, KS, N, N);
         pj1.load(A, N, j0, KS, N, N);
     }
-    if (*job.info != 0) return;
+    if (info0 != 0) return;
     f64x4 acc[2][2] = {};
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int li = lane & 15, g = lane >> 4;
@@ -511,19 +556,7 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
             pj.load(A, N, j0, next_kc, N, N);
         }
         __syncthreads();
-        if (ru[0] && cv[0])
-#pragma unroll
-        for (int k0 = 0; k0 < KS; k0 += 4) {
-            const int kk = k0 + g;
-            double a[2], b[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) { a[u] = ru[u] ? Pi[r0 + 16 * u][kk] : 0.; b[u] = cv[u] ? Pj[c0 + 16 * u][kk] : 0.; }
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int v = 0; v < 2; v++)
-                    if (ru[u] && cv[v]) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
-        }
+        half_panel_mfma<KS, KP>(acc, Pi, Pj, r0, c0, g, ru, cv);
     };
     for (int kp = 0; kp < j0; kp += CH_NB) {           // one panel = two half-panels (j0 is a multiple of 64)
         half(pi0, pj0, kp + CH_NB);
@@ -535,7 +568,7 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
     }
     TILE_FOR_EACH(u, v, r) {
         const int i = i0 + tile_row(u, r), j = j0 + tile_col(v);
-        if (i < N && j <= i) A[(size_t)i * N + j] = old[u][v][r];
+        if (i < N && j <= i) gmem(A)[(size_t)i * N + j] = old[u][v][r];
     }
 }
 

@@ -113,6 +113,16 @@ static inline int64_t cdiv64(int64_t x, int64_t a) { return (x + a - 1) / a; }
 
 // ---- device helpers -------------------------------------------------------------
 #ifdef __HIPCC__
+// A pointer READ FROM DEVICE MEMORY (a job list, a table of per-hypothesis matrices) is a generic pointer to the
+// compiler, and loads / stores through it become FLAT instructions.  Those count on lgkmcnt as well as on vmcnt, so
+// every wait for an LDS read (s_waitcnt lgkmcnt(0) before each MFMA operand) also drains the global loads in
+// flight: a prefetch of the next tile issued before the products of this one is waited out before the first of them.
+// Everything these kernels address is hipMalloc'ed memory: say so at the access (address space 1 = global), and the
+// loads are global_load_*, on vmcnt alone.  (Casting the pointer and back does not survive instruction combining,
+// and an assume on is_shared / is_private is not picked up: the cast has to sit at the access.)
+template <typename T>
+__device__ __forceinline__ auto gmem(T *p) { return (T __attribute__((address_space(1))) *)p; }
+
 __device__ __forceinline__ int wave_id_uniform()
 {
     // threadIdx.x >> 6 is wave-uniform; say so, so that row-indexed operands become SGPRs

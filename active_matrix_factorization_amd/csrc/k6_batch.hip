@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__
     f64x4 old[2][2];
     TILE_FOR_EACH(u, v, r) {
         const int rr = min(i * 64 + tile_row(u, r), N - 1), cc = min(j * 64 + tile_col(v), N - 1);
-        old[u][v][r] = W[(size_t)rr * N + cc];
+        old[u][v][r] = gmem(W)[(size_t)rr * N + cc];
     }
     if (i == k + 1) tile_request(tc, sc);
     tile_place(ta, sa, A);
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256) void kb_trinv_step(const Refs R, const int *__
     }
     TILE_FOR_EACH(u, v, r) {
         const int rr = i * 64 + tile_row(u, r), cc = j * 64 + tile_col(v);
-        if (rr < N && cc < N) W[(size_t)rr * N + cc] = acc[u][v][r];
+        if (rr < N && cc < N) gmem(W)[(size_t)rr * N + cc] = acc[u][v][r];
     }
 }
 
@@ -995,8 +995,8 @@ __global__ __launch_bounds__(256) void kb_lauum(const Refs R, const int *__restr
         const int rr = ti * 64 + tile_row(u, r), cc = tj * 64 + tile_col(v);
         if (rr < N && cc < N && (ti != tj || cc <= rr)) {
             const double val = -half_mult * acc[u][v][r] * (rr == cc ? 1. : 2.);
-            G[(size_t)rr * N + cc] = val;
-            if (rr != cc) G[(size_t)cc * N + rr] = val;
+            gmem(G)[(size_t)rr * N + cc] = val;
+            if (rr != cc) gmem(G)[(size_t)cc * N + rr] = val;
             inv2 += acc[u][v][r] * acc[u][v][r] * (rr == cc ? 1. : 2.);
         }
     }

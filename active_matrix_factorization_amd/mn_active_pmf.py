@@ -10,6 +10,7 @@ loop through exp_dotprod_sq in the reference - is one batched HIP launch here (K
 csrc/k2_score.hip), in float64 so that the selected indices match the reference.
 """
 import os
+import threading
 import time
 
 import numpy as np
@@ -53,8 +54,30 @@ def lookahead_budget_bytes():
     return int(float(os.environ.get('APMF_LOOKAHEAD_GB', '96')) * (1 << 30))
 
 
-# counters of the most recent batched lookahead (summed over its chunks): MNBatch.fit_stats() keys
+# counters of the most recent batched lookahead (summed over its chunks and stream groups): MNBatch.fit_stats() keys
 LAST_BATCH_STATS = {}
+_stats_lock = threading.Lock()
+_MIN_STREAM_GROUP = 16          # hypotheses: smaller pools stay one batch
+
+
+def lookahead_streams():
+    """Streams (groups of hypotheses advancing side by side) of a batched lookahead: APMF_LOOKAHEAD_STREAMS,
+    default 3; 1 = one batch on the model's own stream."""
+    return max(1, min(8, int(os.environ.get('APMF_LOOKAHEAD_STREAMS', '3'))))
+
+
+_workers = {}
+
+
+def _stream_workers(count):
+    """The worker threads of this process' stream groups (kept: each owns the context _lib.default_context gives
+    its thread; per pid: threads do not survive a fork)."""
+    key = os.getpid()
+    pool = _workers.get(key)
+    if pool is None or pool._max_workers < count:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = _workers[key] = ThreadPoolExecutor(max_workers=8, thread_name_prefix='apmf-lookahead')
+    return pool
 
 
 class MNActivePMF(_ActiveBase):
@@ -361,8 +384,6 @@ class MNActivePMF(_ActiveBase):
         elif not pass_v and fn is getattr(cls, '_approx_entropy', None) and \
                 cls._approx_entropy is MNActivePMF._approx_entropy:
             special = 'ent'
-        per_hyp = (5 * n_all * n_all + (4 + d) * n_all * d + 64 * 64 * (n_all // 64 + 3)) * 8
-        chunk = max(1, min(len(hyps), lookahead_budget_bytes() // per_hyp, 16384))
         base = None
         if not self.refit_lookahead:
             res = self._resident()
@@ -370,9 +391,39 @@ class MNActivePMF(_ActiveBase):
             base = (ctx.empty((n_all, d)), ctx.empty((n_all, n_all)), ctx.empty((d, d)))
             res.batch.get_state(0, *base)
         ctx, rt = self._device_ratings()
+        LAST_BATCH_STATS.clear()
+        # Several streams: below a few hundred active hypotheses a launch of the fit's chain holds less than one
+        # wave of workgroups and lasts as long as ONE of them does (0.6 ms per search iteration whatever the count),
+        # so the pool is cut into groups that advance side by side, each a batch of its own on a stream (a context,
+        # a host thread) of its own.  A hypothesis' arithmetic never depends on who shares its batch: same bits.
+        groups = lookahead_streams()
+        if groups > 1 and special is not None and len(hyps) >= 2 * _MIN_STREAM_GROUP:
+            groups = min(groups, len(hyps) // _MIN_STREAM_GROUP)
+            ctx.sync()                                  # the base state is complete before another stream reads it
+            bounds = [len(hyps) * g // groups for g in range(groups + 1)]
+            parts = [hyps[bounds[g]:bounds[g + 1]] for g in range(groups)]
+            device = ctx.device
+            budget = lookahead_budget_bytes() // groups
+
+            def run(part):
+                wctx = _lib.default_context(device)     # this worker thread's own context (kept with the thread)
+                wrt = wctx.ratings(self.ratings, self.num_users, self.num_items)
+                try:
+                    return self._lookahead_run(wctx, wrt, base, part, fn, pass_v, special, budget)
+                finally:
+                    wctx.sync()
+                    wrt.free()
+            return [v for vals in _stream_workers(groups).map(run, parts) for v in vals]
+        return self._lookahead_run(ctx, rt, base, hyps, fn, pass_v, special, lookahead_budget_bytes())
+
+    def _lookahead_run(self, ctx, rt, base, hyps, fn, pass_v, special, budget):
+        """One group of the batched lookahead on one context (stream): see _lookahead_batch_local."""
+        n_all, d = self.num_users + self.num_items, self.latent_d
+        sig = self._sigmas()
+        per_hyp = (5 * n_all * n_all + (4 + d) * n_all * d + 64 * 64 * (n_all // 64 + 3)) * 8
+        chunk = max(1, min(len(hyps), budget // per_hyp, 16384))
         out = []
         batch = None
-        LAST_BATCH_STATS.clear()
         for lo in range(0, len(hyps), chunk):
             part = hyps[lo:lo + chunk]
             H = len(part)
@@ -414,13 +465,15 @@ class MNActivePMF(_ActiveBase):
                 batch.set_state(means if isinstance(means, _lib.DeviceArray) else ctx.array(means),
                                 ctx.array(np.eye(n_all)), ctx.array(np.eye(d)), per_hypothesis=1)
                 ctx.sync()
-                LAST_BATCH_STATS['refit_s'] = LAST_BATCH_STATS.get('refit_s', 0.) + time.perf_counter() - t_refit
+                with _stats_lock:
+                    LAST_BATCH_STATS['refit_s'] = LAST_BATCH_STATS.get('refit_s', 0.) + time.perf_counter() - t_refit
             else:
                 batch.set_state(*base)
             batch.set_extra([h[0] for h in part], [h[1] for h in part], [h[2] for h in part])
             batch.fit(sig[0], sig[1], sig[2], self.min_eig, self.normal_learning_rate, None, max_steps=-1)
-            for k, v in batch.fit_stats().items():
-                LAST_BATCH_STATS[k] = LAST_BATCH_STATS.get(k, 0) + v
+            with _stats_lock:
+                for k, v in batch.fit_stats().items():
+                    LAST_BATCH_STATS[k] = LAST_BATCH_STATS.get(k, 0) + v
             if special == 'tv':
                 out.extend(batch.total_variance().tolist())
             elif special == 'ent':

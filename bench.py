@@ -572,6 +572,7 @@ def lookahead_leg(n_cand):
     out = {'workload': 'configs[3] shape 94x425-d5, %d known, pool %d x 5 rating values' % (known, len(pool)),
            'hypotheses': H, 'seconds': dt, 'hypotheses_per_s': H / dt, 'launches': launches,
            'launches_per_hypothesis': launches / float(H), 'fit_stats': stats,
+           'stream_groups': mn.lookahead_streams() if hasattr(mn, 'lookahead_streams') else 1,
            'base_fit_normal_s': t_fit, 'argmin': [int(q) for q in pool[int(np.argmin(vals))]],
            'full_grid_estimate_s': len(a.unrated) * 5 / (H / dt), 'dtype': 'f64',
            'matrix_dim': N, 'bytes_per_hypothesis_state': 5 * N * N * 8}

@@ -1002,6 +1002,34 @@ def test_lookahead_continuous_batched_equals_one_at_a_time(pkg, monkeypatch):
         assert batched[0] == alone[0] and np.isfinite(batched).all(), key
 
 
+@pytest.mark.parametrize('refit', [False, True])
+def test_lookahead_stream_groups_equal_one_batch(pkg, monkeypatch, refit):
+    """A pool large enough to be cut into stream groups (APMF_LOOKAHEAD_STREAMS, default 3: each group a batch of
+    its own on a context, stream and host thread of its own, advancing beside the others) gives, hypothesis by
+    hypothesis, the bits of the whole pool as ONE batch: total variance and entropy, plain and with refit_lookahead."""
+    g = load_golden('lookahead_c1_mn')
+    a = _lookahead_model(pkg, g, refit_lookahead=refit)
+    pool = sorted(a.unrated)[:10]                       # x 5 rating values = 50 hypotheses: three groups
+    for key in ('total-variance', 'uv-entropy'):
+        k = pkg.mn.KEY_FUNCS[key]
+        monkeypatch.setenv('APMF_LOOKAHEAD_STREAMS', '1')
+        one = a._get_key_vals(pool, k)
+        monkeypatch.setenv('APMF_LOOKAHEAD_STREAMS', '3')
+        calls = []
+        real = pkg.mn.MNActivePMF._lookahead_run
+
+        def spy(self, ctx, rt, base, hyps, *rest):
+            calls.append((ctx, len(hyps)))
+            return real(self, ctx, rt, base, hyps, *rest)
+        monkeypatch.setattr(pkg.mn.MNActivePMF, '_lookahead_run', spy)
+        three = a._get_key_vals(pool, k)
+        monkeypatch.setattr(pkg.mn.MNActivePMF, '_lookahead_run', real)
+        assert sorted(n for _, n in calls) == [16, 17, 17] and len({id(c) for c, _ in calls}) == 3, calls
+        assert three == one, key
+        stats = dict(pkg.mn.LAST_BATCH_STATS)
+        assert stats['trials'] > 0
+
+
 def test_lookahead_continuous_golden(pkg):
     """The CONTINUOUS lookahead against the reference itself (make_golden.py section Y: exp_total_variance and
     exp_total_variance_byapprox of two config-1 candidates, with every point the adaptive quadrature asked for and
