@@ -112,20 +112,42 @@ __device__ __forceinline__ void tile_mfma(f64x4 (&acc)[2][2], const double (*A)[
         // all four accumulators kept (every tile but those of a short last block): straight-line code - with the
         // wave-uniform tests below every MFMA sits in a basic block of its own, and no operand read of the next
         // k-step can be hoisted above the products of this one
-        auto step = [&](int k0) {
+        // operands of k-step s + 1 are read while the four products of step s are issued (two register sets)
+        auto fetch = [&](int k0, double (&a)[2], double (&b)[2]) {
             const int k = k0 + g;
-            const double a0 = FORM == MM_TN ? A[k][r0] : A[r0][k], a1 = FORM == MM_TN ? A[k][r0 + 16] : A[r0 + 16][k];
-            const double b0 = FORM == MM_NT ? B[c0][k] : B[k][c0], b1 = FORM == MM_NT ? B[c0 + 16][k] : B[k][c0 + 16];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            a[0] = FORM == MM_TN ? A[k][r0] : A[r0][k];
+            a[1] = FORM == MM_TN ? A[k][r0 + 16] : A[r0 + 16][k];
+            b[0] = FORM == MM_NT ? B[c0][k] : B[k][c0];
+            b[1] = FORM == MM_NT ? B[c0 + 16][k] : B[k][c0 + 16];
+        };
+        auto mult = [&](const double (&a)[2], const double (&b)[2]) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc[1][1], 0, 0, 0);
         };
         if (K == 64) {
+            double a0[2], b0[2], a1[2], b1[2];
+            fetch(0, a0, b0);
 #pragma unroll
-            for (int k0 = 0; k0 < 64; k0 += 4) step(k0);
+            for (int k0 = 0; k0 < 64; k0 += 8) {
+                // (the fences keep the order written: left alone, the scheduler moves every read back down to
+                // just above its use - one register set, and the LDS latency exposed before each group of four)
+                fetch(k0 + 4, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+                mult(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k0 + 8 < 64) fetch(k0 + 8, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mult(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
-            for (int k0 = 0; k0 < K; k0 += 4) step(k0);
+            for (int k0 = 0; k0 < K; k0 += 4) {
+                double a[2], b[2];
+                fetch(k0, a, b);
+                mult(a, b);
+            }
         }
         return;
     }
@@ -378,14 +400,30 @@ __device__ __forceinline__ void half_panel_mfma(f64x4 (&acc)[2][2], const double
 {
     if (!ru[0] || !cv[0]) return;
     if (ru[1] && cv[1]) {
-#pragma unroll
-        for (int k0 = 0; k0 < KS; k0 += 4) {
+        // two operand register sets, the reads of k-step s + 1 fenced above the products of step s (see tile_mfma)
+        static_assert(KS % 8 == 0, "two k-steps per round");
+        auto fetch = [&](int k0, double (&a)[2], double (&b)[2]) {
             const int kk = k0 + g;
-            const double a0 = Pi[r0][kk], a1 = Pi[r0 + 16][kk], b0 = Pj[c0][kk], b1 = Pj[c0 + 16][kk];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            a[0] = Pi[r0][kk]; a[1] = Pi[r0 + 16][kk]; b[0] = Pj[c0][kk]; b[1] = Pj[c0 + 16][kk];
+        };
+        auto mult = [&](const double (&a)[2], const double (&b)[2]) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc[1][1], 0, 0, 0);
+        };
+        double a0[2], b0[2], a1[2], b1[2];
+        fetch(0, a0, b0);
+#pragma unroll
+        for (int k0 = 0; k0 < KS; k0 += 8) {
+            fetch(k0 + 4, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mult(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + 8 < KS) fetch(k0 + 8, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mult(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         return;
     }
