@@ -68,8 +68,8 @@ def test_pmf_class_golden(pkg, name, s):
     trace = list(p.fit_lls())
     assert len(trace) == g['ll_trace'].size
     np.testing.assert_allclose(trace, g['ll_trace'], rtol=1e-10)
-    np.testing.assert_allclose(p.users, g['U_fit'], rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(p.items, g['V_fit'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(p.users, g['U_fit'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(p.items, g['V_fit'], rtol=1e-11, atol=1e-13)
     # rmse() returns a C float in the reference (pmf_cy.pyx:25-29, 422-426)
     r = p.rmse(g['rmse_target'])
     assert r == float(np.float32(r)) and abs(r - float(g['rmse'])) <= 2e-7 * float(g['rmse'])
@@ -85,8 +85,8 @@ def test_pmf_fit_equals_generator(pkg, name, s):
     g = load_golden(name)
     p = _make_pmf(pkg, g, s)
     p.do_fit()      # one device call for the whole search
-    np.testing.assert_allclose(p.users, g['U_fit'], rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(p.items, g['V_fit'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(p.users, g['U_fit'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(p.items, g['V_fit'], rtol=1e-11, atol=1e-13)
 
 
 def test_pmf_errors_and_state(pkg):
@@ -234,12 +234,12 @@ def test_mn_variational_fit(pkg, name):
     np.testing.assert_allclose(gcl, g['g_cov_latents'], rtol=1e-9,
                                atol=1e-9 * np.abs(g['g_cov_latents']).max())
     kls = list(islice(a.fit_normal_kls(), g['kl_trace'].size))
-    np.testing.assert_allclose(kls, g['kl_trace'], rtol=1e-8)
-    np.testing.assert_allclose(a.mean, g['mean_fit'], rtol=1e-7, atol=1e-9)
-    np.testing.assert_allclose(a.cov_useritems, g['cov_useritems_fit'], rtol=1e-6, atol=1e-8)
-    np.testing.assert_allclose(a.cov_latents, g['cov_latents_fit'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(kls, g['kl_trace'], rtol=1e-12)
+    np.testing.assert_allclose(a.mean, g['mean_fit'], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(a.cov_useritems, g['cov_useritems_fit'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a.cov_latents, g['cov_latents_fit'], rtol=1e-12, atol=1e-14)
     pm, pv = a.approx_pred_means_vars()
-    np.testing.assert_allclose(pv, g['p_var_fit'], rtol=1e-6, atol=1e-8 * np.abs(g['p_var_fit']).max())
+    np.testing.assert_allclose(pv, g['p_var_fit'], rtol=1e-11, atol=1e-13 * np.abs(g['p_var_fit']).max())
 
 
 def test_mn_copy_and_pickle(pkg):
@@ -265,9 +265,9 @@ def test_config1_selection_trace(pkg):
     res = pkg.mn.compare(['random', 'pred-variance'], g['real'], g['ratings'],
                          rating_vals=(1, 2, 3, 4, 5), latent_d=2, do_threading=False, steps=5)
     init = res['_initial_apmf']
-    np.testing.assert_allclose(init.users, g['init_users'], rtol=1e-7, atol=1e-9)
-    np.testing.assert_allclose(init.mean, g['init_mean'], rtol=1e-6, atol=1e-8)
-    np.testing.assert_allclose(init.cov_useritems, g['init_cov_useritems'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(init.users, g['init_users'], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(init.mean, g['init_mean'], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(init.cov_useritems, g['init_cov_useritems'], rtol=1e-12, atol=1e-13)
     for key in ('random', 'pred-variance'):
         steps = res[key]
         assert [s[0] for s in steps] == list(g[key + '_n_rated'])
@@ -275,7 +275,7 @@ def test_config1_selection_trace(pkg):
         np.testing.assert_array_equal(picks, g[key + '_picks'])       # selected indices: exact
         np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=2e-6)
         for k, s in enumerate(steps[1:]):
-            np.testing.assert_allclose(s[3], g['%s_vals_%d' % (key, k)], rtol=1e-5, atol=1e-9)
+            np.testing.assert_allclose(s[3], g['%s_vals_%d' % (key, k)], rtol=1e-10, atol=1e-10)
             assert s[4].shape == g['real'].shape
     assert set(res) == {'_real', '_ratings', '_rating_vals', '_initial_apmf', 'random', 'pred-variance'}
 
@@ -297,11 +297,11 @@ def test_config1_lookahead_selection_step(pkg):
         ref, got = g[key + '_vals'], np.asarray(steps[1][3], float)
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         ok = ~np.isnan(ref)
-        # every hypothesis is a gradient descent stopped on a small change of the KL bound: converged values agree to
-        # the stopping tolerance's effect on the criterion, not to rounding
-        np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-3, atol=2e-3 * np.abs(ref[ok]).max())
+        # every hypothesis is a gradient descent stopped on a small change of the KL bound; on config 1 the searches
+        # are short enough that the converged criterion values agree to 1e-10 (measured; the bound below is 1e-8)
+        np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-8, atol=1e-9 * np.abs(ref[ok]).max())
         assert tuple(steps[1][2]) == tuple(g[key + '_pick']), key            # selected entry: exact
-        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-4)
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-12)
 
 
 def test_config1_bayes_selection_trace(pkg):
@@ -319,12 +319,12 @@ def test_config1_bayes_selection_trace(pkg):
         assert [s[0] for s in steps] == list(g[key + '_n_rated'])
         picks = np.array([s[2] for s in steps[1:]])
         np.testing.assert_array_equal(picks, g[key + '_picks'])       # selected indices: exact
-        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-5)
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-12)
         for k, s in enumerate(steps[1:]):
             ref = g['%s_vals_%d' % (key, k)]
             got = np.asarray(s[3], float)
             assert np.array_equal(np.isnan(got), np.isnan(ref))
-            np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-5, atol=1e-9)
+            np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-11, atol=1e-10)
 
 
 def test_config1_bayes_lookahead_selection_step(pkg):
@@ -342,9 +342,9 @@ def test_config1_bayes_lookahead_selection_step(pkg):
     ref, got = g['vals'], np.asarray(steps[1][3], float)
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     ok = ~np.isnan(ref)
-    np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-5)
+    np.testing.assert_allclose(got[ok], ref[ok], rtol=2e-6)
     assert tuple(int(x) for x in steps[1][2]) == tuple(int(x) for x in g['pick'])      # selected entry: exact
-    np.testing.assert_allclose([s[1] for s in steps], g['rmse'], rtol=1e-5)
+    np.testing.assert_allclose([s[1] for s in steps], g['rmse'], rtol=1e-12)
 
 
 def test_config1_full_selection_trace(pkg):
@@ -359,19 +359,19 @@ def test_config1_full_selection_trace(pkg):
                            real_ratings_vals=(g['real'], g['ratings'].copy(), (1, 2, 3, 4, 5)))
     init = res['_initial_apmf']
     np.testing.assert_allclose(init.users, g['init_users'], rtol=1e-7, atol=1e-9)
-    np.testing.assert_allclose(init.mean, g['init_mean'], rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose(init.cov, g['init_cov'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(init.mean, g['init_mean'], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(init.cov, g['init_cov'], rtol=1e-4, atol=4e-6)
     for key in keys:
         steps = res[key]
         assert [s[0] for s in steps] == list(g[key + '_n_rated'])
         picks = np.array([s[2] for s in steps[1:]])
         np.testing.assert_array_equal(picks, g[key + '_picks'])       # selected indices: exact
-        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-5)
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-12)
         for k, s in enumerate(steps[1:]):
             ref = g['%s_vals_%d' % (key, k)]
             got = np.asarray(s[3], float)
             assert np.array_equal(np.isnan(got), np.isnan(ref))
-            np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-4, atol=1e-8)
+            np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=2e-5, atol=1e-8)
 
 
 def test_config1_full_lookahead_selection_step(pkg):
@@ -392,7 +392,7 @@ def test_config1_full_lookahead_selection_step(pkg):
                            real_ratings_vals=(g['real'], g['ratings'].copy(), (1, 2, 3, 4, 5)))
     steps = res['total-variance']
     assert [s[0] for s in steps] == list(g['n_rated'])
-    np.testing.assert_allclose(steps[0][1], g['rmse'][0], rtol=1e-4)        # RMSE of the initial fit
+    np.testing.assert_allclose(steps[0][1], g['rmse'][0], rtol=1e-12)        # RMSE of the initial fit
     ref, got = g['vals'], np.asarray(steps[1][3], float)
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     ok = ~np.isnan(ref)
@@ -465,7 +465,7 @@ def test_config1_full_lookahead_pinned(pkg):
         tv_cut[k] = tv[k] if cut_tv is None else cut_tv
         head = g['hyp_kl_head'][k]
         nh = min(cut, len(trace), int(np.isfinite(head).sum()))
-        np.testing.assert_allclose(trace[:nh], head[:nh], rtol=1e-7, err_msg=str((i, j, v)))
+        np.testing.assert_allclose(trace[:nh], head[:nh], rtol=1e-9, err_msg=str((i, j, v)))
         if (i, j) in traced:
             ref = g['trace_%d_%d_%d' % (i, j, int(v))]
             nn = min(len(ref), len(trace))
@@ -473,14 +473,14 @@ def test_config1_full_lookahead_pinned(pkg):
             bad = np.nonzero(rel > 1e-9)[0]
             parts.append((int(bad[0]) if bad.size else None, len(trace), len(ref)))
     np.testing.assert_allclose(kl0, g['hyp_kl0'], rtol=1e-13)
-    np.testing.assert_allclose(tv_cut, g['hyp_tv_cut'], rtol=1e-7)
+    np.testing.assert_allclose(tv_cut, g['hyp_tv_cut'], rtol=1e-9)
     from scipy import stats
     pool = [tuple(int(x) for x in ij) for ij in g['pool']]
     est = np.empty(len(pool))
     for k, (i, j) in enumerate(pool):
         cdfs = stats.norm.cdf(a.rating_bounds, loc=np.dot(a.users[i], a.items[j]), scale=np.sqrt(a.sigma_sq))
         est[k] = (tv_cut.reshape(len(pool), -1)[k] * np.diff(cdfs)).sum()
-    np.testing.assert_allclose(est, g['vals_cut'], rtol=1e-7)
+    np.testing.assert_allclose(est, g['vals_cut'], rtol=1e-9)
     assert pool[int(np.argmin(est))] == tuple(int(x) for x in g['pick_cut'])           # selected entry: exact
     assert np.array_equal(np.argsort(est, kind='stable')[:10], np.argsort(g['vals_cut'], kind='stable')[:10])
     # 4: where the full searches part, and that nothing parts earlier
@@ -566,8 +566,8 @@ def test_bayes_class_golden(pkg, name):
     S = g['chain_U'].shape[0]
     seed(int(g['chain_seed']))
     samps = list(islice(b.samples(), S))
-    np.testing.assert_allclose([u for u, v in samps], g['chain_U'], rtol=1e-6, atol=1e-8)
-    np.testing.assert_allclose([v for u, v in samps], g['chain_V'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose([u for u, v in samps], g['chain_U'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose([v for u, v in samps], g['chain_V'], rtol=1e-9, atol=1e-11)
     # criteria over the reference's own samples
     ref = list(zip(g['chain_U'], g['chain_V']))
     which = tuple(g['which'])
@@ -629,8 +629,8 @@ def test_pmf_fit_with_sigmas_golden(pkg, name, s):
     assert got.size == want.size
     np.testing.assert_allclose(got, want, rtol=1e-9)
     if want.size == 40:      # stopped by the islice, not by convergence: same state as recorded
-        np.testing.assert_allclose(p.users, g['sigmas_U'], rtol=1e-7, atol=1e-9)
-        np.testing.assert_allclose([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq], g['sigmas_final'], rtol=1e-8)
+        np.testing.assert_allclose(p.users, g['sigmas_U'], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq], g['sigmas_final'], rtol=1e-12)
 
 
 @pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
@@ -645,8 +645,8 @@ def test_full_variational_fit(pkg, name):
     np.testing.assert_allclose(gm, g['g_mean'], rtol=1e-9, atol=1e-9 * np.abs(g['g_mean']).max())
     np.testing.assert_allclose(gc, g['g_cov'], rtol=1e-9, atol=1e-9 * np.abs(g['g_cov']).max())
     kls = list(islice(a.fit_normal_kls(), g['kl_trace'].size))
-    np.testing.assert_allclose(kls, g['kl_trace'], rtol=1e-8)
-    np.testing.assert_allclose(a.mean, g['mean_fit'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(kls, g['kl_trace'], rtol=1e-10)
+    np.testing.assert_allclose(a.mean, g['mean_fit'], rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(a.cov, g['cov_fit'], rtol=1e-5, atol=1e-7 * np.abs(g['cov_fit']).max())
     # the KL of the fitted state: device routine == the host composition the reference uses, and the
     # whole fit in one device call walks the same steps as the generator
@@ -681,7 +681,7 @@ def test_mn_lookahead_golden(pkg):
     assert abs(a.prob_ge_3_5(cand) - g['prob_ge_3_5']) <= 1e-7 * abs(g['prob_ge_3_5']) + 1e-300
     for key in ('exp_total_variance', 'exp_total_variance_byapprox', 'exp_approx_entropy', 'onestep_ge_3_5'):
         got = getattr(a, key)(cand)
-        assert abs(got - g[key]) <= 2e-4 * abs(g[key]), (key, got, float(g[key]))
+        np.testing.assert_allclose(got, float(g[key]), rtol=1e-9, err_msg=key)
 
 
 def test_full_lookahead_golden(pkg):
@@ -699,7 +699,7 @@ def test_full_lookahead_golden(pkg):
     assert abs(a._approx_entropy() - g['approx_entropy']) <= 1e-10 * abs(g['approx_entropy'])
     for key in ('exp_total_variance', 'exp_approx_entropy', 'onestep_ge_3_5'):
         got = getattr(a, key)(cand)
-        assert abs(got - g[key]) <= 5e-4 * abs(g[key]), (key, got, float(g[key]))
+        np.testing.assert_allclose(got, float(g[key]), rtol=1e-10, err_msg=key)
 
 
 def test_mn_refit_lookahead_golden(pkg, monkeypatch):
@@ -719,7 +719,7 @@ def test_mn_refit_lookahead_golden(pkg, monkeypatch):
         for key in ('exp_total_variance', 'exp_approx_entropy', 'onestep_ge_3_5'):
             seed(46)
             got = getattr(a, key)(cand)
-            assert abs(got - g[key]) <= 5e-4 * abs(g[key]), (batch, key, got, float(g[key]))
+            np.testing.assert_allclose(got, float(g[key]), rtol=1e-10, err_msg='%s %s' % (batch, key))
 
 
 # ------------------------------------------------------------------ the reference's own checks
@@ -1256,11 +1256,11 @@ def test_configs3_golden_fit_and_selection(pkg):
     assert tuple(a.pick_query_point(key=MN.pred_variance)) == tuple(g['pick0'])
     kls = list(islice(a.fit_normal_kls(), 3))
     np.testing.assert_allclose(kls, g['kl_trace3'], rtol=1e-9)
-    np.testing.assert_allclose(a.mean, g['mean3'], rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(a.cov_latents, g['cov_latents3'], rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(np.diag(a.cov_useritems), g['cov_diag3'], rtol=1e-8)
+    np.testing.assert_allclose(a.mean, g['mean3'], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(a.cov_latents, g['cov_latents3'], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(np.diag(a.cov_useritems), g['cov_diag3'], rtol=1e-12)
     pm, pv = a.approx_pred_means_vars()
-    np.testing.assert_allclose(pv, g['p_var3'], rtol=1e-8)
+    np.testing.assert_allclose(pv, g['p_var3'], rtol=1e-12)
     # The reference then needed 220 more accepted steps to "converge" - by meeting one step that
     # improved the KL by < .005 (-0.0026 after a run of -1.5 steps: a chance event of its trajectory;
     # KL -159 where the descent, continued, reaches -381).  The search is chaotic in that sense: the
@@ -1268,7 +1268,7 @@ def test_configs3_golden_fit_and_selection(pkg):
     # it is meaningful - the first 150 steps - and the converged quantities are checked on the
     # reference's own final state below.
     rest = list(islice(a.fit_normal_kls(), 150))
-    np.testing.assert_allclose(rest, g['kl_trace_fit'][:150], rtol=1e-6)
+    np.testing.assert_allclose(rest, g['kl_trace_fit'][:150], rtol=1e-8)
     assert np.all(np.diff(rest) < 0)
     b = _c4_model(pkg, g, 'fit')
     assert abs(b.kl_divergence() - g['kl_fit']) <= 1e-9 * abs(g['kl_fit'])
@@ -1291,7 +1291,7 @@ def test_configs3_golden_lookahead(pkg):
     a = _c4_model(pkg, g, 'fit')
     cand = tuple(int(x) for x in g['cand'])
     got = a.exp_total_variance(cand)
-    assert abs(got - g['exp_total_variance']) <= 2e-4 * abs(g['exp_total_variance']), (got, float(g['exp_total_variance']))
+    np.testing.assert_allclose(got, float(g['exp_total_variance']), rtol=2e-6)
     # and through the pool interface, together with a neighbour
     vals = a._get_key_vals([cand, sorted(a.unrated)[12]], pkg.mn.KEY_FUNCS['total-variance'])
     assert vals[0] == got
@@ -1314,7 +1314,7 @@ def test_configs3_golden_lookahead_pool_pick(pkg):
     pool = [tuple(int(x) for x in ij) for ij in t['pool']]
     key = pkg.mn.KEY_FUNCS['total-variance']
     vals = np.asarray(a._get_key_vals(pool, key), float)
-    np.testing.assert_allclose(vals[:2], t['vals'][:2], rtol=2e-6)
+    np.testing.assert_allclose(vals[:2], t['vals'][:2], rtol=1e-6)
     np.testing.assert_allclose(vals[2], t['vals'][2], rtol=.1)
     assert abs(float(t['vals'][0]) - float(g['exp_total_variance'])) <= 1e-9 * abs(float(g['exp_total_variance']))
     assert a.pick_query_point(pool=pool, key=key) == tuple(int(x) for x in t['pick'])
@@ -1330,7 +1330,7 @@ def test_configs3_golden_lookahead_pool_pick(pkg):
         if v == 1:
             assert kls.size == ref.size
             np.testing.assert_allclose(kls, ref, rtol=1e-7)
-            np.testing.assert_allclose(b._total_variance(), tr['total_variance_1'], rtol=1e-8)
+            np.testing.assert_allclose(b._total_variance(), tr['total_variance_1'], rtol=1e-11)
 
 
 def test_configs3_golden_lookahead_pool_ranking(pkg):
@@ -1507,8 +1507,8 @@ def test_headline_shape_golden_scoring_and_selection(pkg):
     ctx.mn_score_grid(np.float32, 1, n, m, d, ld, dm, dc, dd, do, mask=dmask, var=var, dsum=dsum, want=1,
                       best_val=bv, best_idx=bi)
     v32 = ctx.download_grid(var, m)
-    np.testing.assert_allclose(v32[g['rows']], g['p_var_rows'], rtol=3e-5, atol=3e-5 * scale)
-    np.testing.assert_allclose(v32[g['si'], g['sj']], g['p_var_s'], rtol=3e-5, atol=3e-5 * scale)
+    np.testing.assert_allclose(v32[g['rows']], g['p_var_rows'], rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(v32[g['si'], g['sj']], g['p_var_s'], rtol=1e-5, atol=1e-5 * scale)
     i32, j32 = divmod(int(bi.to_host()[0]), m)
     assert not rated[i32, j32]
     assert abs(pv[i32, j32] - float(g['pick_var'])) <= 3e-5 * abs(float(g['pick_var']))
@@ -1532,11 +1532,11 @@ def test_headline_shape_golden_variational_fit(pkg):
     assert abs(a.kl_divergence() - g['kl0']) <= 1e-10 * abs(g['kl0'])
     kls = list(islice(a.fit_normal_kls(), 3))
     np.testing.assert_allclose(kls, g['kl_trace3'], rtol=1e-9)
-    np.testing.assert_allclose(a.mean, g['mean3'], rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(a.cov_latents, g['cov_latents3'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(a.mean, g['mean3'], rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(a.cov_latents, g['cov_latents3'], rtol=1e-10, atol=1e-14)
     S = np.asarray(a.cov_useritems)
-    np.testing.assert_allclose(np.diag(S), g['cov_diag3'], rtol=1e-8)
-    np.testing.assert_allclose(S[g['si'], g['sj']], g['cov_s3'], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(np.diag(S), g['cov_diag3'], rtol=1e-12)
+    np.testing.assert_allclose(S[g['si'], g['sj']], g['cov_s3'], rtol=1e-10, atol=1e-14)
 
 
 def test_minibatch_golden(pkg):
@@ -1559,8 +1559,8 @@ def test_minibatch_golden(pkg):
     q = model()
     seed(int(g['seed_valid']))
     q.fit_minibatches_until_validation(bs, int(g['valid_size']))
-    np.testing.assert_allclose(q.users, g['users_valid'], rtol=1e-8, atol=1e-10)
-    np.testing.assert_allclose(q.items, g['items_valid'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(q.users, g['users_valid'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(q.items, g['items_valid'], rtol=1e-11, atol=1e-13)
     q2 = model()
     seed(int(g['seed_pairs']))
     pairs = list(islice(q2.fit_minibatches_validation(bs, int(g['valid_size'])), 3))
@@ -1581,14 +1581,14 @@ def test_configs2_gibbs_golden(pkg):
     seed(int(g['seed_chain']))
     samps = list(islice(b.samples(), 3))
     ru, rv = g['rows_u'], g['rows_v']
-    np.testing.assert_allclose([u[ru] for u, v in samps], g['chain_U_rows'], rtol=1e-6, atol=1e-8)
-    np.testing.assert_allclose([v[rv] for u, v in samps], g['chain_V_rows'], rtol=1e-6, atol=1e-8)
-    np.testing.assert_allclose([u.sum() for u, v in samps], g['chain_U_sum'], rtol=1e-7)
-    np.testing.assert_allclose([v.sum() for u, v in samps], g['chain_V_sum'], rtol=1e-7)
+    np.testing.assert_allclose([u[ru] for u, v in samps], g['chain_U_rows'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose([v[rv] for u, v in samps], g['chain_V_rows'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose([u.sum() for u, v in samps], g['chain_U_sum'], rtol=1e-11)
+    np.testing.assert_allclose([v.sum() for u, v in samps], g['chain_V_sum'], rtol=1e-11)
     pv, pr = b.pred_variance(samps), b.predict(samps)
     sub = np.ix_(g['pi'], g['pj'])
-    np.testing.assert_allclose(pv[sub], g['pred_variance_sub'], rtol=1e-5, atol=1e-9)
-    np.testing.assert_allclose(pr[sub], g['predict_sub'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pv[sub], g['pred_variance_sub'], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(pr[sub], g['predict_sub'], rtol=1e-10, atol=1e-11)
     assert abs(pv.sum() - g['pred_variance_sum']) <= 1e-6 * abs(g['pred_variance_sum'])
     assert tuple(np.unravel_index(np.argmax(pv), pv.shape)) == tuple(g['pick_argmax'])
 
@@ -1687,8 +1687,8 @@ def test_bayes_exp_variance_reference_fixture(pkg, monkeypatch):
     b.users, b.items = g0['users'].copy(), g0['items'].copy()
     seed(5)
     samps = list(islice(b.samples(), 5))
-    np.testing.assert_allclose(np.array([u for u, v in samps]), g['chain_U'], rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(np.array([v for u, v in samps]), g['chain_V'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.array([u for u, v in samps]), g['chain_U'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(np.array([v for u, v in samps]), g['chain_V'], rtol=1e-10, atol=1e-12)
     which = tuple(g['which'])
     assert np.array_equal(np.array(sorted(b.unrated)[:4]).T, g['which'])
     for batch in ('1', '0'):
@@ -1696,7 +1696,7 @@ def test_bayes_exp_variance_reference_fixture(pkg, monkeypatch):
         for fit_first in (True, False):
             seed(6)
             ev = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
-            np.testing.assert_allclose(ev, g['exp_variance_fit%d' % int(fit_first)], rtol=1e-6)
+            np.testing.assert_allclose(ev, g['exp_variance_fit%d' % int(fit_first)], rtol=1e-12)
             assert np.array_equal(np.random.get_state()[1][:8], g['rng_after_fit%d' % int(fit_first)])
 
 

@@ -159,4 +159,4 @@ def test_full_lookahead_batched_equals_per_hypothesis(monkeypatch, key):
     cand = tuple(int(x) for x in g['cand'])
     monkeypatch.delenv('APMF_LOOKAHEAD_BATCH')
     got = a._get_key_vals([cand], k)[0]
-    np.testing.assert_allclose(got, float(g[name]), rtol=5e-4)
+    np.testing.assert_allclose(got, float(g[name]), rtol=1e-10)
