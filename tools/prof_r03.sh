@@ -4,11 +4,13 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r03
 mkdir -p $O
 part=${1:-all}
+# (kernel-trace runs use ONE stream group: with three groups - six host threads launching at once - rocprofv3's
+# kernel-trace tool segfaults inside a launch; its counter-collection passes and unprofiled runs are fine)
 stats() { f=$(find $1 -name "*kernel_stats.csv" | head -1); cp "$f" $2; rm -rf $1; }
 ctr() { f=$(find $1 -name "*counter_collection.csv" | head -1); cp "$f" $2; rm -rf $1; }
-if [ $part = all ] || [ $part = bench ]; then
+if [ $part = all ] || [ $part = bench ] || [ $part = traces ]; then
   (cd $R && python3 bench.py > $O/r03_bench_default.json 2> $O/bench_default.err)
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bench -o kt -- python3 $R/bench.py --no-cpu-baseline > $O/r03_bench_profiled.json 2> $O/bench_profiled.err
+  APMF_LOOKAHEAD_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bench -o kt -- python3 $R/bench.py --no-cpu-baseline > $O/r03_bench_profiled.json 2> $O/bench_profiled.err
   stats $O/kt_bench $O/r03_bench_kernel_stats.csv
   echo bench done
 fi
@@ -21,9 +23,14 @@ if [ $part = all ] || [ $part = pmck2 ]; then
   python3 $R/tools/pmc_summary.py "k_mn_grid<double" $O/r03_pmc_FETCH_SIZE.csv $O/r03_pmc_WRITE_SIZE.csv > $O/r03_pmc_k2_f64_both_legs.json
   echo pmck2 done
 fi
+if [ $part = traces ]; then
+  APMF_LOOKAHEAD_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_la -o kt -- python3 $R/tools/bench_lookahead.py 100 > $O/lookahead_H500_profiled.json 2> $O/la_profiled.err
+  stats $O/kt_la $O/r03_lookahead_H500_kernel_stats.csv
+  echo traces done
+fi
 if [ $part = all ] || [ $part = lookahead ]; then
   (cd $R && python3 tools/bench_lookahead.py 100 > $O/lookahead_H500.json 2>/dev/null)
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_la -o kt -- python3 $R/tools/bench_lookahead.py 100 > $O/lookahead_H500_profiled.json 2> $O/la_profiled.err
+  APMF_LOOKAHEAD_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_la -o kt -- python3 $R/tools/bench_lookahead.py 100 > $O/lookahead_H500_profiled.json 2> $O/la_profiled.err
   stats $O/kt_la $O/r03_lookahead_H500_kernel_stats.csv
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/pmc_la_sq -o pmc -- python3 $R/tools/bench_lookahead.py 100 > $O/la_sq.json 2> $O/la_sq.err
   ctr $O/pmc_la_sq $O/la_sq.csv
