@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: the quadrature predictor of the continuous lookahead and the packing of
 the Gibbs hyper-parameter variates."""
+import os
 import warnings
 
 import numpy as np
@@ -75,3 +76,19 @@ def test_pack_variates_layouts():
     np.random.seed(2)
     b = bp._wishart_from_variates(s, bp._wishart_variates(d, 10))
     assert np.array_equal(a, b)
+
+
+def test_lookahead_streams_knob(monkeypatch):
+    """Stream groups of a batched lookahead: 3 by default, APMF_LOOKAHEAD_STREAMS overrides, and ONE under
+    rocprofv3's tracing (its kernel-trace tool does not survive six threads launching at once)."""
+    from active_matrix_factorization_amd import mn_active_pmf as mn
+    for k in [k for k in os.environ if k.startswith('ROCPROF_')] + ['APMF_LOOKAHEAD_STREAMS']:
+        monkeypatch.delenv(k, raising=False)
+    assert mn.lookahead_streams() == 3
+    monkeypatch.setenv('ROCPROF_KERNEL_TRACE', '1')
+    assert mn.lookahead_streams() == 1
+    monkeypatch.setenv('APMF_LOOKAHEAD_STREAMS', '2')
+    assert mn.lookahead_streams() == 2
+    monkeypatch.delenv('APMF_LOOKAHEAD_STREAMS')
+    monkeypatch.setenv('ROCPROF_KERNEL_TRACE', 'False')
+    assert mn.lookahead_streams() == 3

@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r03
 mkdir -p $O
 part=${1:-all}
-# (kernel-trace runs use ONE stream group: with three groups - six host threads launching at once - rocprofv3's
+# (kernel-trace runs use ONE stream group - the package picks that itself under rocprofv3 tracing, set here too for clarity: with three groups - six host threads launching at once - rocprofv3's
 # kernel-trace tool segfaults inside a launch; its counter-collection passes and unprofiled runs are fine)
 stats() { f=$(find $1 -name "*kernel_stats.csv" | head -1); cp "$f" $2; rm -rf $1; }
 ctr() { f=$(find $1 -name "*counter_collection.csv" | head -1); cp "$f" $2; rm -rf $1; }
