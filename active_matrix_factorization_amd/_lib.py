@@ -43,6 +43,7 @@ _SIGS = {
     'apmf_ctx_destroy': (_i, [_vp]),
     'apmf_ctx_set_stream': (_i, [_vp, _vp]),
     'apmf_ctx_sync': (_i, [_vp]),
+    'apmf_ctx_trim': (_i, [_vp]),
     'apmf_grid_ld': (_i, [_i]),
     'apmf_profile_begin': (_i, [_vp, _i]),
     'apmf_profile_end': (_i, [_vp, _vp, _i, C.POINTER(_i)]),
@@ -620,6 +621,10 @@ class Context(object):
     # -- plumbing ------------------------------------------------------------------
     def sync(self):
         _check(self._lib.apmf_ctx_sync(self._h))
+
+    def trim(self):
+        """Return the context's cache of freed device blocks to the driver (after a sync)."""
+        _check(self._lib.apmf_ctx_trim(self._h))
 
     def set_stream(self, hip_stream):
         _check(self._lib.apmf_ctx_set_stream(self._h, hip_stream))

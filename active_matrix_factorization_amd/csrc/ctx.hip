@@ -159,6 +159,15 @@ int apmf_ctx_sync(apmf_ctx *ctx)
     return APMF_OK;
 }
 
+int apmf_ctx_trim(apmf_ctx *ctx)
+{
+    APMF_REQUIRE(ctx, "ctx is NULL");
+    APMF_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lock(ctx->pool->mu);
+    pool_release(ctx);
+    return APMF_OK;
+}
+
 int apmf_profile_begin(apmf_ctx *ctx, int max_records)
 {
     APMF_REQUIRE(ctx && max_records >= 1 && max_records <= 4096, "bad profile request");

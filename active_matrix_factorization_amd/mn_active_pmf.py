@@ -419,8 +419,8 @@ class MNActivePMF(_ActiveBase):
                 try:
                     return self._lookahead_run(wctx, wrt, base, part, fn, pass_v, special, budget)
                 finally:
-                    wctx.sync()
                     wrt.free()
+                    wctx.trim()         # (sync + the worker context's block cache back to the driver)
             return [v for vals in _stream_workers(groups).map(run, parts) for v in vals]
         return self._lookahead_run(ctx, rt, base, hyps, fn, pass_v, special, lookahead_budget_bytes())
 

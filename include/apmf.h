@@ -58,6 +58,9 @@ int apmf_ctx_destroy(apmf_ctx *ctx);
  * NULL switches back to the ctx's own stream */
 int apmf_ctx_set_stream(apmf_ctx *ctx, void *hip_stream);
 int apmf_ctx_sync(apmf_ctx *ctx);
+/* give the context's cache of freed device blocks (up to 16 GB, kept to spare the classes' many same-sized
+ * allocations a hipMalloc each) back to the driver; synchronises the stream first.  No reference counterpart. */
+int apmf_ctx_trim(apmf_ctx *ctx);
 int apmf_grid_ld(int m); /* m rounded up to APMF_GRID_ALIGN */
 
 /* In-library timing of the dominant kernel of each instrumented entry point (the sweep
