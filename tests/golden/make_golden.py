@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3d': sections V, W, X, Y (round 3)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3e': sections V, W, X, Y, Z (round 3)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -166,6 +166,9 @@ def main():
         return
     if args.only == 'r3d':
         round3d(np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r3e':
+        round3e(np, pmf_cy, save, seed, _print)
         return
     if args.only == 'r3b':
         round3b(np, mn_active_pmf, save, seed, _print)
@@ -1100,6 +1103,34 @@ def round3d(np, mn_active_pmf, save, seed, _print):
     for k, name in enumerate(('map0', 'map1', 'approx0', 'approx1')):
         out['evals_' + name] = got[k][1]
     save('lookahead_c1_mn_continuous', **out)
+
+
+def round3e(np, pmf_cy, save, seed, _print):
+    """Z. The minibatch fit (pmf_cy.pyx:308-381) at the HEADLINE shape - 943 x 1682, rank 10, N = 100 000 (section
+    H holds it at 50 x 40 only): two epochs of fit_minibatches(1000) - 100 minibatches each, momentum carried across -
+    and three (train, validation) pairs of fit_minibatches_validation(1000, 5000) under fixed seeds.  Stored: the
+    training errors, sampled rows and the sums of the fitted factors, the head of the shuffled ratings array."""
+    from itertools import islice
+    ratings = headline_inputs(np, seed)
+    t0 = time.perf_counter()
+    seed(90)
+    p = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    U0, V0 = p.users.copy(), p.items.copy()
+    seed(91)
+    errs = list(islice(p.fit_minibatches(1000), 2))
+    ru, rv = np.array([0, 1, 470, 942]), np.array([0, 1, 840, 1681])
+    out = dict(seed_ctor=90, seed_fit=91, batch_size=1000, U0_sum=U0.sum(), V0_sum=V0.sum(),
+               train_errs=np.array(errs, np.float64), rows_u=ru, rows_v=rv, U_rows=p.users[ru], V_rows=p.items[rv],
+               U_sum=p.users.sum(), V_sum=p.items.sum(), U_abs_sum=np.abs(p.users).sum(), V_abs_sum=np.abs(p.items).sum(),
+               ratings_after_head=p.ratings[:64].copy(), ratings_after_weighted=(p.ratings * np.arange(1, 100001)[:, None]).sum(0))
+    seed(92)
+    q = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    q.users, q.items = U0.copy(), V0.copy()
+    seed(93)
+    pairs = list(islice(q.fit_minibatches_validation(1000, 5000), 3))
+    out.update(seed_pairs=93, valid_size=5000, valid_pairs=np.array(pairs, np.float64), Uv_rows=q.users[ru], Vv_rows=q.items[rv])
+    _print('headline minibatch: train errs %r, pairs %r, %.0f s' % (errs, pairs, time.perf_counter() - t0))
+    save('pmf_minibatch_c2_943x1682_d10', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

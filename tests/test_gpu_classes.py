@@ -1567,6 +1567,38 @@ def test_minibatch_golden(pkg):
     np.testing.assert_allclose(pairs, g['valid_pairs'], rtol=1e-6)
 
 
+def test_minibatch_headline_shape_golden(pkg):
+    """The minibatch fit at the HEADLINE shape (943 x 1682, rank 10, N = 100 000) against the reference itself
+    (make_golden.py section Z): two epochs of fit_minibatches(1000) - 100 minibatches each on
+    apmf_pmf_minibatch_epoch, the shuffle on the host like the reference's - and three (train, validation) pairs of
+    fit_minibatches_validation(1000, 5000), all under the reference's seeds."""
+    from conftest import c2_inputs
+    g = load_golden('pmf_minibatch_c2_943x1682_d10')
+    ratings, _, _ = c2_inputs()
+    bs = int(g['batch_size'])
+    seed(int(g['seed_ctor']))
+    p = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    U0, V0 = p.users.copy(), p.items.copy()
+    np.testing.assert_allclose([U0.sum(), V0.sum()], [g['U0_sum'], g['V0_sum']], rtol=1e-13)
+    seed(int(g['seed_fit']))
+    errs = list(islice(p.fit_minibatches(bs), 2))
+    np.testing.assert_allclose(errs, g['train_errs'], rtol=1e-12)              # (a C float in the reference: the same bits here)
+    np.testing.assert_array_equal(p.ratings[:64], g['ratings_after_head'])     # the same shuffles
+    np.testing.assert_allclose((p.ratings * np.arange(1, 100001)[:, None]).sum(0), g['ratings_after_weighted'], rtol=1e-13)
+    ru, rv = g['rows_u'], g['rows_v']
+    np.testing.assert_allclose(p.users[ru], g['U_rows'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(p.items[rv], g['V_rows'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose([p.users.sum(), p.items.sum(), np.abs(p.users).sum(), np.abs(p.items).sum()],
+                               [g['U_sum'], g['V_sum'], g['U_abs_sum'], g['V_abs_sum']], rtol=1e-13)
+    q = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    q.users, q.items = U0.copy(), V0.copy()
+    seed(int(g['seed_pairs']))
+    pairs = list(islice(q.fit_minibatches_validation(bs, int(g['valid_size'])), 3))
+    np.testing.assert_allclose(pairs, g['valid_pairs'], rtol=1e-12)
+    np.testing.assert_allclose(q.users[ru], g['Uv_rows'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(q.items[rv], g['Vv_rows'], rtol=1e-11, atol=1e-13)
+
+
 def test_configs2_gibbs_golden(pkg):
     """BASELINE.json configs[2]: rank-15 BayesianPMF at 943 x 1682 on the headline synthetic ratings
     (regenerated from seed 0; only sampled outputs are stored): the first three samples() yields
