@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3e': sections V, W, X, Y, Z (round 3)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3f': sections V, W, X, Y, Z, AA (round 3)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -169,6 +169,9 @@ def main():
         return
     if args.only == 'r3e':
         round3e(np, pmf_cy, save, seed, _print)
+        return
+    if args.only == 'r3f':
+        round3f(np, active_pmf, nx, save, seed, fake, _print)
         return
     if args.only == 'r3b':
         round3b(np, mn_active_pmf, save, seed, _print)
@@ -519,6 +522,12 @@ def main():
     round2l(np, mn_active_pmf, save, seed, _print)
     round2m(np, mn_active_pmf, save, seed, _print)
     round2n(np, active_pmf, save, seed, _print)
+    round3a(np, active_pmf, save, seed, _print)
+    round3b(np, mn_active_pmf, save, seed, _print)
+    round3c(np, mn_active_pmf, save, seed, _print)
+    round3d(np, mn_active_pmf, save, seed, _print)
+    round3e(np, pmf_cy, save, seed, _print)
+    round3f(np, active_pmf, nx, save, seed, fake, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -1131,6 +1140,47 @@ def round3e(np, pmf_cy, save, seed, _print):
     out.update(seed_pairs=93, valid_size=5000, valid_pairs=np.array(pairs, np.float64), Uv_rows=q.users[ru], Vv_rows=q.items[rv])
     _print('headline minibatch: train errs %r, pairs %r, %.0f s' % (errs, pairs, time.perf_counter() - t0))
     save('pmf_minibatch_c2_943x1682_d10', **out)
+
+
+def round3f(np, active_pmf, nx, save, seed, fake, _print):
+    """AA. The full-covariance class at ranks 10 and 16 (section C holds ranks 3 and 5): the scoring grids of
+    approx_pred_means_vars (normal_exps_cy.exp_dotprod_sq, normal_exps_cy.pyx:111-135 - on the device the sweep for
+    9 <= d <= 16, the headline rank among them), the pool values and the pick, the KL, its gradient and three accepted
+    fit_normal_kls steps - exactly what section C records."""
+    def full_case(name, ratings, d):
+        a = active_pmf.ActivePMF(ratings.copy(), latent_d=d)
+        a.do_fit()
+        a.initialize_approx()
+        a.cov /= 8.0
+        p_mean, p_var = a.approx_pred_means_vars()
+        pool = list(a.unrated)
+        vals = a._get_key_vals(pool, active_pmf.ActivePMF.pred_variance, 1, None)
+        pick = a.pick_query_point(key=active_pmf.ActivePMF.pred_variance)
+        out = dict(ratings=ratings, d=d, users=a.users, items=a.items,
+                   mean=a.mean, cov=a.cov, p_mean=p_mean, p_var=p_var,
+                   pool=np.array(pool), pool_vals=np.array(vals), pick_max=np.array(pick),
+                   kl=a.kl_divergence(), u_idx=a.u, v_idx=a.v,
+                   sigma=np.array([a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq]))
+        g_mean, g_cov = nx.normal_gradient(a)
+        out.update(g_mean=g_mean, g_cov=g_cov)
+        kls = []
+        for k, kl in enumerate(a.fit_normal_kls()):
+            kls.append(kl)
+            if k >= 2:
+                break
+        out.update(kl_trace=np.array(kls), mean_fit=a.mean, cov_fit=a.cov)
+        save(name, **out)
+
+    t0 = time.perf_counter()
+    seed(24)
+    r, _, _ = fake(11, 14, 10, 4)
+    seed(25)
+    full_case('full_11x14_d10', r, 10)
+    seed(26)
+    r, _, _ = fake(7, 9, 16, 3)
+    seed(27)
+    full_case('full_7x9_d16', r, 16)
+    _print('full-covariance ranks 10 and 16: %.0f s' % (time.perf_counter() - t0))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

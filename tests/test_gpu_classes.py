@@ -516,7 +516,7 @@ def test_mn_lookahead_total_variance(pkg):
 
 
 # ------------------------------------------------------------------ ActivePMF (full covariance)
-@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
+@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5', 'full_11x14_d10', 'full_7x9_d16'])
 def test_full_class(pkg, name):
     g = load_golden(name)
     a = pkg.full.ActivePMF(g['ratings'].copy(), latent_d=int(g['d']))
@@ -633,7 +633,7 @@ def test_pmf_fit_with_sigmas_golden(pkg, name, s):
         np.testing.assert_allclose([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq], g['sigmas_final'], rtol=1e-12)
 
 
-@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
+@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5', 'full_11x14_d10', 'full_7x9_d16'])
 def test_full_variational_fit(pkg, name):
     """ActivePMF: KL gradient (normal_exps_cy.pyx:217-303, quirks included) and the first accepted
     steps of fit_normal_kls vs the reference."""
@@ -643,7 +643,9 @@ def test_full_variational_fit(pkg, name):
     a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
     gm, gc = pkg.full.normal_gradient(a)
     np.testing.assert_allclose(gm, g['g_mean'], rtol=1e-9, atol=1e-9 * np.abs(g['g_mean']).max())
-    np.testing.assert_allclose(gc, g['g_cov'], rtol=1e-9, atol=1e-9 * np.abs(g['g_cov']).max())
+    # (the covariance gradient carries -1/2 cov^-1: both sides invert a matrix of condition ~1e7 - LAPACK's LU there, the
+    # blocked Cholesky here - and part by cond * eps of the largest entry: 8e-11 at K = 33, 5e-10 at 105, 1.5e-9 at 250)
+    np.testing.assert_allclose(gc, g['g_cov'], rtol=1e-9, atol=5e-9 * np.abs(g['g_cov']).max())
     kls = list(islice(a.fit_normal_kls(), g['kl_trace'].size))
     np.testing.assert_allclose(kls, g['kl_trace'], rtol=1e-10)
     np.testing.assert_allclose(a.mean, g['mean_fit'], rtol=1e-11, atol=1e-13)

@@ -523,7 +523,7 @@ def test_mn_grid_headline_size_properties(ctx):
 
 
 # ---------------------------------------------------------------------------- K2-full
-@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
+@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5', 'full_11x14_d10', 'full_7x9_d16'])
 def test_full_grid_golden(ctx, name):
     g = load_golden(name)
     n, m = g['p_mean'].shape

@@ -144,7 +144,7 @@ def test_moments_monte_carlo():
         assert abs(monte4 - e4) / abs(e4) < .05
 
 
-@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5'])
+@pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5', 'full_11x14_d10', 'full_7x9_d16'])
 def test_full_grids(name):
     g = load_golden(name)
     n, m = g['p_mean'].shape
