@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3f': sections V, W, X, Y, Z, AA (round 3)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3g': sections V, W, X, Y, Z, AA, AB (round 3)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -172,6 +172,9 @@ def main():
         return
     if args.only == 'r3f':
         round3f(np, active_pmf, nx, save, seed, fake, _print)
+        return
+    if args.only == 'r3g':
+        round3g(np, bayes_pmf, save, seed, fake, _print)
         return
     if args.only == 'r3b':
         round3b(np, mn_active_pmf, save, seed, _print)
@@ -528,6 +531,7 @@ def main():
     round3d(np, mn_active_pmf, save, seed, _print)
     round3e(np, pmf_cy, save, seed, _print)
     round3f(np, active_pmf, nx, save, seed, fake, _print)
+    round3g(np, bayes_pmf, save, seed, fake, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -1181,6 +1185,37 @@ def round3f(np, active_pmf, nx, save, seed, fake, _print):
     seed(27)
     full_case('full_7x9_d16', r, 16)
     _print('full-covariance ranks 10 and 16: %.0f s' % (time.perf_counter() - t0))
+
+
+def round3g(np, bayes_pmf, save, seed, fake, _print):
+    """AB. BayesianPMF.exp_variance (bayes_pmf.py:457-525, 560-598) at 100 x 90, rank 15, subtract_mean (section M
+    holds the 10 x 10 rank-2 case): fake ratings (pmf_cy.fake_ratings, seed 9) rounded to 1 ... 5, four chain samples
+    from seed 7, then the expected total variance of the first three unrated entries from seed 8, with and without
+    fit_first, three lookahead samples per hypothesis; sequential (pool=None); expectation over the five rating
+    values - the branch this SciPy still runs: the continuous one calls scipy.integrate.trapz (bayes_pmf.py:585),
+    removed from SciPy since."""
+    from itertools import islice
+    t0 = time.perf_counter()
+    seed(9)
+    r, _, _ = fake(100, 90, 15, 20)
+    r[:, 2] = np.clip(np.round(3 + r[:, 2] / r[:, 2].std() * 1.2), 1, 5)
+    seed(10)
+    b = bayes_pmf.BayesianPMF(r.copy(), latent_d=15, subtract_mean=True, rating_values=(1, 2, 3, 4, 5),
+                              discrete_expectations=True)
+    U0, V0 = b.users.copy(), b.items.copy()
+    seed(7)
+    samps = list(islice(b.samples(), 4))
+    unr = np.array(sorted(b.unrated)[:3]).T
+    which = tuple(unr)
+    out = dict(ratings=r, U0=U0, V0=V0, which=unr, chain_U=np.array([u for u, v in samps]),
+               chain_V=np.array([v for u, v in samps]))
+    for fit_first in (True, False):
+        seed(8)
+        ev = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
+        out['exp_variance_fit%d' % int(fit_first)] = np.asarray(ev, float)
+        out['rng_after_fit%d' % int(fit_first)] = np.random.get_state()[1][:8].copy()
+        _print('exp_variance 100x90 fit_first=%s: %s, %.0f s' % (fit_first, ev, time.perf_counter() - t0))
+    save('bayes_100x90_exp_variance', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

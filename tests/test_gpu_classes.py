@@ -1734,6 +1734,33 @@ def test_bayes_exp_variance_reference_fixture(pkg, monkeypatch):
             assert np.array_equal(np.random.get_state()[1][:8], g['rng_after_fit%d' % int(fit_first)])
 
 
+def test_bayes_exp_variance_reference_fixture_100x90(pkg, monkeypatch):
+    """The same at 100 x 90, rank 15, subtract_mean (make_golden.py section AB: seeds 10 / 7 / 8, fake ratings rounded
+    to 1 ... 5, three candidates x five rating values x three lookahead samples, with and without fit_first - the MAP
+    re-fits of fit_first are one apmf_pmf_batch_fit_lls, the chains batched K3 half-sweeps): the reference's values
+    and the NumPy random stream it leaves behind, from the batched evaluation and from the one-at-a-time one."""
+    g = load_golden('bayes_100x90_exp_variance')
+    seed(10)
+    b = pkg.bayes.BayesianPMF(g['ratings'].copy(), latent_d=15, subtract_mean=True, rating_values=(1, 2, 3, 4, 5),
+                              discrete_expectations=True)
+    np.testing.assert_allclose(b.users, g['U0'], rtol=1e-13)
+    np.testing.assert_allclose(b.items, g['V0'], rtol=1e-13)
+    seed(7)
+    samps = list(islice(b.samples(), 4))
+    np.testing.assert_allclose(np.array([u for u, v in samps]), g['chain_U'], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(np.array([v for u, v in samps]), g['chain_V'], rtol=1e-9, atol=1e-11)
+    which = tuple(g['which'])
+    assert np.array_equal(np.array(sorted(b.unrated)[:3]).T, g['which'])
+    for batch in ('1', '0'):
+        monkeypatch.setenv('APMF_LOOKAHEAD_BATCH', batch)
+        for fit_first in (True, False):
+            seed(8)
+            ev = b.exp_variance(samps, which=which, fit_first=fit_first, num_samps=3)
+            np.testing.assert_allclose(ev, g['exp_variance_fit%d' % int(fit_first)], rtol=1e-12,
+                                       err_msg='batch=%s fit_first=%s' % (batch, fit_first))
+            assert np.array_equal(np.random.get_state()[1][:8], g['rng_after_fit%d' % int(fit_first)])
+
+
 def test_bayes_exp_variance_batched_equals_sequential(pkg, monkeypatch):
     """BayesianPMF.exp_variance (bayes_pmf.py:457-525, 560-598): all hypotheses (candidate x rating
     value) sampled together - batched K3 half-sweeps with the hypothesis' extra rating, K4 on the
