@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3g': sections V, W, X, Y, Z, AA, AB (round 3)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3h': sections V, W, X, Y, Z, AA, AB, AC (round 3)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -175,6 +175,9 @@ def main():
         return
     if args.only == 'r3g':
         round3g(np, bayes_pmf, save, seed, fake, _print)
+        return
+    if args.only == 'r3h':
+        round3h(np, pmf_cy, save, seed, _print)
         return
     if args.only == 'r3b':
         round3b(np, mn_active_pmf, save, seed, _print)
@@ -532,6 +535,7 @@ def main():
     round3e(np, pmf_cy, save, seed, _print)
     round3f(np, active_pmf, nx, save, seed, fake, _print)
     round3g(np, bayes_pmf, save, seed, fake, _print)
+    round3h(np, pmf_cy, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -1216,6 +1220,32 @@ def round3g(np, bayes_pmf, save, seed, fake, _print):
         out['rng_after_fit%d' % int(fit_first)] = np.random.get_state()[1][:8].copy()
         _print('exp_variance 100x90 fit_first=%s: %s, %.0f s' % (fit_first, ev, time.perf_counter() - t0))
     save('bayes_100x90_exp_variance', **out)
+
+
+def round3h(np, pmf_cy, save, seed, _print):
+    """AC. fit_with_sigmas_lls and the closed-form variance updates (pmf_cy.pyx:225-255, 384-403) at the HEADLINE
+    shape - 943 x 1682, rank 10, N = 100 000 (section A holds them up to 50 x 40): update_sigma / update_sigma_uv at
+    the seeded start, then the first 12 yields of fit_with_sigmas_lls - the variances re-estimated between steps -
+    with sampled rows of the factors and the variances it ends with."""
+    from itertools import islice
+    ratings = headline_inputs(np, seed)
+    t0 = time.perf_counter()
+    seed(94)
+    p = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    U0, V0 = p.users.copy(), p.items.copy()
+    p.update_sigma()
+    p.update_sigma_uv()
+    out = dict(seed_ctor=94, U0_sum=U0.sum(), V0_sum=V0.sum(),
+               sigma_after=np.array([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq]))
+    q = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    q.users, q.items = U0.copy(), V0.copy()
+    trace = np.array(list(islice(q.fit_with_sigmas_lls(), 12)))
+    ru, rv = np.array([0, 1, 470, 942]), np.array([0, 1, 840, 1681])
+    out.update(sigmas_ll_trace=trace, rows_u=ru, rows_v=rv, U_rows=q.users[ru], V_rows=q.items[rv],
+               U_sum=q.users.sum(), V_sum=q.items.sum(),
+               sigmas_final=np.array([q.sigma_sq, q.sigma_u_sq, q.sigma_v_sq]))
+    _print('headline fit_with_sigmas_lls: %r ... %r, sigmas %r, %.0f s' % (trace[0], trace[-1], out['sigmas_final'], time.perf_counter() - t0))
+    save('pmf_sigmas_c2_943x1682_d10', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

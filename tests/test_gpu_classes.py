@@ -633,6 +633,31 @@ def test_pmf_fit_with_sigmas_golden(pkg, name, s):
         np.testing.assert_allclose([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq], g['sigmas_final'], rtol=1e-12)
 
 
+def test_pmf_fit_with_sigmas_headline_shape_golden(pkg):
+    """fit_with_sigmas_lls and the closed-form variance updates (pmf_cy.pyx:225-255, 384-403) at the HEADLINE shape
+    (943 x 1682, rank 10, N = 100 000) against the reference itself (make_golden.py section AC): update_sigma /
+    update_sigma_uv at the seeded start, then 12 yields of the search with the variances re-estimated between steps."""
+    from conftest import c2_inputs
+    g = load_golden('pmf_sigmas_c2_943x1682_d10')
+    ratings, _, _ = c2_inputs()
+    seed(int(g['seed_ctor']))
+    p = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    U0, V0 = p.users.copy(), p.items.copy()
+    np.testing.assert_allclose([U0.sum(), V0.sum()], [g['U0_sum'], g['V0_sum']], rtol=1e-13)
+    p.update_sigma()
+    p.update_sigma_uv()
+    np.testing.assert_allclose([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq], g['sigma_after'], rtol=1e-13)
+    q = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10)
+    q.users, q.items = U0.copy(), V0.copy()
+    want = g['sigmas_ll_trace']
+    got = np.array(list(islice(q.fit_with_sigmas_lls(), want.size)))
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    np.testing.assert_allclose(q.users[g['rows_u']], g['U_rows'], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(q.items[g['rows_v']], g['V_rows'], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose([q.users.sum(), q.items.sum()], [g['U_sum'], g['V_sum']], rtol=1e-13)
+    np.testing.assert_allclose([q.sigma_sq, q.sigma_u_sq, q.sigma_v_sq], g['sigmas_final'], rtol=1e-12)
+
+
 @pytest.mark.parametrize('name', ['full_6x5_d3', 'full_12x9_d5', 'full_11x14_d10', 'full_7x9_d16'])
 def test_full_variational_fit(pkg, name):
     """ActivePMF: KL gradient (normal_exps_cy.pyx:217-303, quirks included) and the first accepted
