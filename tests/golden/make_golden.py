@@ -113,6 +113,13 @@ def main():
         np.random.seed(s)
         random.seed(s)
 
+    def one_thread(fn, *a):
+        # round-3 sections: one BLAS thread in this process too (their worker processes limit themselves), so that
+        # the recorded bits do not depend on OMP_NUM_THREADS / the core count of the machine that regenerates them
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(1):
+            return fn(*a)
+
     def fake(n, m, d, per_user, noise=.25):
         # same recipe as pmf_cy.fake_ratings (pmf_cy.pyx:461-474)
         return pmf_cy.fake_ratings(noise=noise, num_users=n, num_items=m,
@@ -162,25 +169,25 @@ def main():
         round3a(np, active_pmf, save, seed, _print)
         return
     if args.only == 'r3c':
-        round3c(np, mn_active_pmf, save, seed, _print)
+        one_thread(round3c, np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r3d':
-        round3d(np, mn_active_pmf, save, seed, _print)
+        one_thread(round3d, np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r3e':
-        round3e(np, pmf_cy, save, seed, _print)
+        one_thread(round3e, np, pmf_cy, save, seed, _print)
         return
     if args.only == 'r3f':
-        round3f(np, active_pmf, nx, save, seed, fake, _print)
+        one_thread(round3f, np, active_pmf, nx, save, seed, fake, _print)
         return
     if args.only == 'r3g':
-        round3g(np, bayes_pmf, save, seed, fake, _print)
+        one_thread(round3g, np, bayes_pmf, save, seed, fake, _print)
         return
     if args.only == 'r3h':
-        round3h(np, pmf_cy, save, seed, _print)
+        one_thread(round3h, np, pmf_cy, save, seed, _print)
         return
     if args.only == 'r3b':
-        round3b(np, mn_active_pmf, save, seed, _print)
+        one_thread(round3b, np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r2':
         round2(np, pmf_cy, mn_active_pmf, bayes_pmf, save, seed, fake, _print)
@@ -529,13 +536,13 @@ def main():
     round2m(np, mn_active_pmf, save, seed, _print)
     round2n(np, active_pmf, save, seed, _print)
     round3a(np, active_pmf, save, seed, _print)
-    round3b(np, mn_active_pmf, save, seed, _print)
-    round3c(np, mn_active_pmf, save, seed, _print)
-    round3d(np, mn_active_pmf, save, seed, _print)
-    round3e(np, pmf_cy, save, seed, _print)
-    round3f(np, active_pmf, nx, save, seed, fake, _print)
-    round3g(np, bayes_pmf, save, seed, fake, _print)
-    round3h(np, pmf_cy, save, seed, _print)
+    one_thread(round3b, np, mn_active_pmf, save, seed, _print)
+    one_thread(round3c, np, mn_active_pmf, save, seed, _print)
+    one_thread(round3d, np, mn_active_pmf, save, seed, _print)
+    one_thread(round3e, np, pmf_cy, save, seed, _print)
+    one_thread(round3f, np, active_pmf, nx, save, seed, fake, _print)
+    one_thread(round3g, np, bayes_pmf, save, seed, fake, _print)
+    one_thread(round3h, np, pmf_cy, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
