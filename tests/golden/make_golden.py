@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3h': sections V, W, X, Y, Z, AA, AB, AC (round 3)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -185,6 +185,9 @@ def main():
         return
     if args.only == 'r3h':
         one_thread(round3h, np, pmf_cy, save, seed, _print)
+        return
+    if args.only == 'r3i':
+        one_thread(round3i, np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r3b':
         one_thread(round3b, np, mn_active_pmf, save, seed, _print)
@@ -543,6 +546,7 @@ def main():
     one_thread(round3f, np, active_pmf, nx, save, seed, fake, _print)
     one_thread(round3g, np, bayes_pmf, save, seed, fake, _print)
     one_thread(round3h, np, pmf_cy, save, seed, _print)
+    one_thread(round3i, np, mn_active_pmf, save, seed, _print)
 
     with open(os.path.join(HERE, 'reference_timings.json'), 'w') as f:
         import json
@@ -1253,6 +1257,41 @@ def round3h(np, pmf_cy, save, seed, _print):
                sigmas_final=np.array([q.sigma_sq, q.sigma_u_sq, q.sigma_v_sq]))
     _print('headline fit_with_sigmas_lls: %r ... %r, sigmas %r, %.0f s' % (trace[0], trace[-1], out['sigmas_final'], time.perf_counter() - t0))
     save('pmf_sigmas_c2_943x1682_d10', **out)
+
+
+def round3i(np, mn_active_pmf, save, seed, _print):
+    """W2. The pool of section W with every hypothesis fitted TO CONVERGENCE, as the reference's lookahead runs it
+    (mn_active_pmf.py:660-681): 48 stopped searches of 250 ... 700 accepted steps each (an hour of single-threaded
+    reference time over seven workers).  The searches are chaotic past ~100 steps (section T2), so a device run
+    cannot reproduce these values to rounding; the fixture answers the question that leaves: how far do the
+    CONVERGED criterion values and their ranking move."""
+    import math
+    import multiprocessing as mp
+    from scipy import stats
+    g = np.load(os.path.join(HERE, 'mn_c4_94x425_d5.npz'))
+    w = np.load(os.path.join(HERE, 'lookahead_c4_pool_ranked.npz'))
+    MN = mn_active_pmf.MNActivePMF
+    a = MN(g['ratings'].copy(), latent_d=5, rating_values=(0., 1.), discrete_expectations=True)
+    a.users, a.items = g['users'].copy(), g['items'].copy()
+    a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq = (float(x) for x in g['sigma'])
+    a.mean, a.cov_useritems, a.cov_latents = g['mean_fit'].copy(), g['cov_useritems_fit'].copy(), g['cov_latents_fit'].copy()
+    pool = [tuple(int(x) for x in ij) for ij in w['pool']]
+    t0 = time.perf_counter()
+    jobs = [(a, i, j, v, None) for i, j in pool for v in a.rating_values]
+    got = []
+    with mp.Pool(7) as workers:
+        for r in workers.imap(_hyp_trunc_mn, jobs, chunksize=1):
+            got.append(r)
+            _print('  hypothesis %d/%d: %d steps, %.0f s' % (len(got), len(jobs), len(r[0]), time.perf_counter() - t0))
+    steps = np.array([len(r[0]) for r in got])
+    tv = np.array([r[1] for r in got]).reshape(len(pool), 2)
+    est = []
+    for (i, j), evals in zip(pool, tv):
+        mean = np.dot(a.users[i, :], a.items[j, :])
+        cdfs = stats.norm.cdf(a.rating_bounds, loc=mean, scale=math.sqrt(a.sigma_sq))
+        est.append((evals * np.diff(cdfs)).sum())
+    save('lookahead_c4_pool_converged', pool=np.array(pool), steps=steps, final_kl=np.array([r[0][-1] for r in got]),
+         tv=tv, vals=np.array(est), order=np.argsort(est, kind='stable'))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -1493,6 +1493,28 @@ def test_configs3_d20_refit_golden(pkg):
     b.free()
 
 
+def test_configs3_golden_lookahead_pool_converged(pkg):
+    """The pool of fixture W with every hypothesis fitted TO CONVERGENCE, as the lookahead really runs (make_golden.py
+    section W2: 48 stopped searches of 49 ... 1164 accepted steps; 470 s of reference time on seven cores, 3 s here).
+    Measured: 20 of the 24 criterion values agree with the reference's to 7e-8 (median 9e-12) - whole searches of
+    several hundred steps retraced - and four do not (+6.7 %, -1.6 %, +1.0 %, +0.26 %): hypotheses whose search stops at a different
+    step (the x1.25 learning-rate search at the edge of stability, fixture T2).  What the selection needs survives:
+    the arg-min, the order of the best eight, Kendall's tau 0.94 over the pool (whose values spread by 27 %)."""
+    from scipy import stats
+    g = load_golden('mn_c4_94x425_d5')
+    z = load_golden('lookahead_c4_pool_converged')
+    a = _c4_model(pkg, g, 'fit')
+    pool = [tuple(int(x) for x in ij) for ij in z['pool']]
+    vals = np.array(a._get_key_vals(pool, pkg.mn.KEY_FUNCS['total-variance']))
+    rel = np.abs(vals / z['vals'] - 1)
+    order = np.argsort(vals, kind='stable')
+    print('relative differences:', np.array2string(rel, precision=2), 'order', order.tolist(), 'reference', z['order'].tolist())
+    assert np.median(rel) < 1e-9 and (rel < 1e-6).sum() >= 20 and rel.max() < 0.1
+    assert order[0] == z['order'][0]                                   # the selected entry
+    assert order[:5].tolist() == z['order'][:5].tolist()               # and the best five in order
+    assert stats.kendalltau(vals, z['vals'])[0] > 0.9
+
+
 def test_headline_shape_golden_scoring_and_selection(pkg):
     """BASELINE.json's metric shape - 943 x 1682, rank 10 - recorded from the real reference
     (make_golden.py section J: approx_pred_means_vars over all 1 586 126 entries, pick_query_point over
