@@ -96,7 +96,7 @@ class Comm(object):
     store on MASTER_PORT - is skipped."""
 
     def __init__(self, rank=0, world=1, addr='127.0.0.1', port=None, ctx=None, rccl=None, tag='',
-                 timeout=300., span=32):
+                 timeout=300., span=32, fallback=False):
         self.rank, self.world = int(rank), int(world)
         self.ctx = ctx
         self._peers = None        # rank 0: sockets of ranks 1..world-1
@@ -104,6 +104,7 @@ class Comm(object):
         self._server = None
         self._nccl = None
         self._libc = None
+        self.rccl_error = None    # fallback=True: why the job runs on the socket transport instead of RCCL
         if self.world > 1:
             if port is None:
                 raise ValueError('a port is needed for world > 1')
@@ -112,17 +113,45 @@ class Comm(object):
         if want_rccl:
             if ctx is None:
                 raise ValueError('the RCCL communicator needs a Context')
+            self._start_rccl(ctx, fallback)
+
+    def _start_rccl(self, ctx, fallback):
+        """The RCCL communicator over the socket rendezvous.  A failure is fatal for the caller (the product has no
+        host path for a broken fabric) - unless `fallback`: then the ranks agree, over the sockets, whether EVERY one
+        of them came up; if not, all drop RCCL together, the exchanges run host-staged over the sockets and
+        `rccl_error` says why (bench.py does this so that a first multi-GPU run still reports, loudly labelled)."""
+        import ctypes as C
+        err = None
+        ident = np.zeros(128, np.uint8)
+        try:
             self._libc = _lib.load_comm()
-            ident = np.zeros(128, np.uint8)
             if self.rank == 0:
                 _lib._check(self._libc.apmf_comm_unique_id(ident.ctypes.data))
-            ident = np.frombuffer(self.bcast_bytes(ident.tobytes()), np.uint8).copy()
-            import ctypes as C
-            h = C.c_void_p()
-            # a failure here is fatal for the caller: there is no host fallback for a broken fabric
-            _lib._check(self._libc.apmf_comm_create(ctx._h, self.rank, self.world, ident.ctypes.data,
-                                                    C.byref(h)))
+        except Exception as e:      # noqa: BLE001 - reported, and fatal unless fallback
+            if not fallback:
+                raise
+            err = 'unique id: %s' % e
+        ident = np.frombuffer(self.bcast_bytes(ident.tobytes()), np.uint8).copy()
+        h = C.c_void_p()
+        if err is None:
+            try:
+                _lib._check(self._libc.apmf_comm_create(getattr(ctx, '_h', None), self.rank, self.world,
+                                                        ident.ctypes.data, C.byref(h)))
+            except Exception as e:  # noqa: BLE001
+                if not fallback:
+                    raise
+                err = 'communicator: %s' % e
+        if not fallback:
             self._nccl = h.value
+            return
+        flags = self.all_gather_blocks(np.array([0. if err is None else 1.]))      # sockets: _nccl is still None
+        if flags.sum() == 0:
+            self._nccl = h.value
+            return
+        if err is None and h.value:
+            self._libc.apmf_comm_destroy(h.value)
+        bad = [r for r in range(self.world) if flags.reshape(-1)[r] != 0]
+        self.rccl_error = 'ranks %s failed to start RCCL%s' % (bad, '' if err is None else ' (this rank: %s)' % err)
 
     # -- set-up / tear-down -------------------------------------------------------------------
     def _connect(self, addr, port, tag, timeout, span):
@@ -320,7 +349,7 @@ class Comm(object):
         return self.all_gather_blocks(row)
 
 
-def comm_from_env(ctx=None, port_offset=1):
+def comm_from_env(ctx=None, port_offset=1, fallback=False):
     """Comm of a process started by `python -m torch.distributed.run` / torchrun (used purely as
     a process launcher: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) or by hand.  The listening port
     is searched from MASTER_PORT + port_offset on (MASTER_PORT itself belongs to the launcher)."""
@@ -331,7 +360,7 @@ def comm_from_env(ctx=None, port_offset=1):
     tag = os.environ.get('TORCHELASTIC_RUN_ID', '') + ':' + os.environ.get('MASTER_PORT', '')
     t0 = time.time()
     try:
-        comm = Comm(rank, world, addr, port, ctx=ctx, tag=tag)
+        comm = Comm(rank, world, addr, port, ctx=ctx, tag=tag, fallback=fallback)
     except Exception as e:
         sys.stderr.write('[apmf comm] rank %d/%d device %s: communicator set-up FAILED after %.1f s (%s:%d+): %s\n'
                          % (rank, world, getattr(ctx, 'device', None), time.time() - t0, addr, port, e))
@@ -346,7 +375,8 @@ def comm_from_env(ctx=None, port_offset=1):
             version = v.value
     sys.stderr.write('[apmf comm] rank %d/%d device %s: %s up in %.2f s (rendezvous %s:%d+, RCCL version %s)\n'
                      % (rank, world, getattr(ctx, 'device', None), 'RCCL communicator' if comm.has_rccl else
-                        'socket transport', time.time() - t0, addr, port, version))
+                        'socket transport' + (' (FALLBACK: %s)' % comm.rccl_error if comm.rccl_error else ''),
+                        time.time() - t0, addr, port, version))
     sys.stderr.flush()
     return comm
 

@@ -116,11 +116,13 @@ def main():
     os.dup2(2, 1)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if rehearsal:
+        if rehearsal and os.environ.get('APMF_BENCH_SHARE_GPU') != 'rccl':
             comm = sharding.Comm(rank, world, os.environ['MASTER_ADDR'],
                                  int(os.environ.get('MASTER_PORT', '29500')) + 1, ctx=ctx, rccl=False)
         else:
-            comm = sharding.comm_from_env(ctx)
+            # (fallback: if RCCL does not come up on every rank, all ranks drop to the host-staged exchange together
+            # and the line says so - a labelled number instead of no number from a first multi-GPU run)
+            comm = sharding.comm_from_env(ctx, fallback=True)
     else:
         comm = sharding.Comm(0, 1, ctx=ctx, rccl=bool(os.environ.get('APMF_BENCH_FORCE_EXCHANGE')))
     comm.barrier()
@@ -165,7 +167,7 @@ def main():
     libc = _lib.load_comm() if comm.has_rccl else None
     if world > 1 or comm.has_rccl:
         exchange_note = ('%s all-gather of the per-state results (%d B per rank) after every sweep, on the '
-                         'sweep\'s stream' % ('RCCL' if comm.has_rccl else 'REHEARSAL host-staged', 20 * B))
+                         'sweep\'s stream' % ('RCCL' if comm.has_rccl else ('FALLBACK host-staged (%s)' % comm.rccl_error) if comm.rccl_error else 'REHEARSAL host-staged', 20 * B))
 
     def step():
         ctx.mn_score_grid(np.float32, B, n, m, d, ld, d_mean, d_cross, d_diag, d_omega, mask=d_mask,
@@ -402,7 +404,8 @@ def bench_c5(args, ctx, comm, rank, world):
             'config': {'workload': '%dx%d-d%d-N%d' % (n, m, d, N), 'rows_per_rank': nl,
                        'parallelism': 'user rows split over %d rank(s), cross block and mask resident per rank' % world,
                        'exchange': '%s all-gather of one 32-byte (sum, value, index) record per rank after every sweep'
-                                   % ('RCCL' if comm.has_rccl else 'host-staged' if world > 1 else 'single rank: local copy')},
+                                   % ('RCCL' if comm.has_rccl else ('FALLBACK host-staged (%s)' % comm.rccl_error) if getattr(comm, 'rccl_error', None)
+                                      else 'host-staged' if world > 1 else 'single rank: local copy')},
             'roofline': {'bound': 'hbm', 'kernel': 'k_mn_grid_mfma<64,...> (rank 0\'s rows)', 'achieved': ach, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS if ach else None, 'traffic': None,
                          'algorithmic_bytes_per_launch': algo, 'avg_kernel_ms': avg_ms, 'launches_timed': int(kern_ms.size)},

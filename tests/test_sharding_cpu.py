@@ -167,3 +167,50 @@ def test_block_ranges():
             rows = [sh.block_range(n, r, w) for r in range(w)]
             assert sum(hi - lo for lo, hi in rows) == n
             assert all(hi - lo <= sh.block_size(n, w) for lo, hi in rows)
+
+
+def _fallback_worker(rank, world, port, q):
+    try:
+        from active_matrix_factorization_amd import sharding as sh
+
+        class NoDevice(object):      # stands where a Context would: no GPU in this process
+            _h = None
+            device = None
+
+            def sync(self):
+                pass
+        comm = sh.Comm(rank, world, '127.0.0.1', port, ctx=NoDevice(), rccl=True, tag='f', fallback=True)
+        assert not comm.has_rccl and comm.rccl_error and 'failed to start RCCL' in comm.rccl_error, comm.rccl_error
+        assert str(list(range(world))) in comm.rccl_error          # every rank reported its failure to every other
+        got = comm.all_gather_scalars([rank])                      # and the host transport carries the exchanges
+        assert np.array_equal(got.reshape(-1), np.arange(world))
+        comm.barrier()
+        comm.close()
+        q.put((rank, 'ok'))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_rccl_fallback_is_agreed_and_labelled():
+    """bench.py's safety net for a first multi-GPU run (Comm(..., fallback=True)): RCCL cannot come up here (no GPU:
+    the unique id / communicator calls fail), every rank learns over the sockets that not all of them did, all drop
+    RCCL TOGETHER, `rccl_error` names the ranks, and the host-staged exchanges work.  (Without fallback=True the same
+    failure raises: the product has no silent host path.)"""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(msg == 'ok' for _, msg in res), '\n'.join(str(x) for x in res)
+    from active_matrix_factorization_amd import sharding as sh
+
+    class NoDevice(object):
+        _h = None
+    with pytest.raises(Exception):
+        sh.Comm(0, 1, ctx=NoDevice(), rccl=True)                   # strict by default

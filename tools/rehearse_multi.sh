@@ -8,3 +8,6 @@ echo "== c5 N=1 (reduced)"; APMF_BENCH_SHARE_GPU= timeout -k 10 200 python bench
 echo "== c5 N=2 (reduced)"; run 2 29611 --workload c5 --c5-rows 20000 --c5-ratings 5000000 --steps 10 --warmup 2 > $O/c5_n2.json 2> $O/c5_n2.err; tail -3 $O/c5_n2.err; cut -c1-600 $O/c5_n2.json
 echo "== c2 strong N=2"; run 2 29631 --scaling strong --steps 20 --warmup 2 --no-cpu-baseline > $O/c2s_n2.json 2> $O/c2s_n2.err; tail -3 $O/c2s_n2.err; cut -c1-900 $O/c2s_n2.json
 echo "== c2 weak N=3"; run 3 29651 --steps 20 --warmup 2 --no-cpu-baseline > $O/c2w_n3.json 2> $O/c2w_n3.err; tail -3 $O/c2w_n3.err; cut -c1-500 $O/c2w_n3.json
+# the agreed fallback: two ranks on ONE device make RCCL's communicator fail (duplicate GPU); every rank must learn it,
+# drop to the host-staged exchange together and say so in the line
+echo "== c2 weak N=2, RCCL attempted on a shared device (expected: FALLBACK in the exchange note)"; APMF_BENCH_SHARE_GPU=rccl run 2 29671 --steps 20 --warmup 2 --no-cpu-baseline > $O/c2w_n2_fallback.json 2> $O/c2w_n2_fallback.err; grep "apmf comm" $O/c2w_n2_fallback.err | cut -c1-300; python3 -c "import json; o=json.load(open('$O/c2w_n2_fallback.json')); print(o['n_gpus'], o['value'], o['config']['exchange'][:200])"
