@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void kf_value(const FRefs R, const int *__rest
     sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = bu; sh[2][threadIdx.x] = bv; sh[3][threadIdx.x] = ld;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o)
+        if ((int)threadIdx.x < o)
             for (int z = 0; z < 4; z++) sh[z][threadIdx.x] += sh[z][threadIdx.x + o];
         __syncthreads();
     }
