@@ -922,6 +922,22 @@ def test_pmf_batch_fit_lls_equals_rebuilt(ctx, d):
     _batch_fit_case(ctx, ratings, n, m, d, hyps[:4], subtract_mean=True, max_steps=25, seed=1)
 
 
+def test_pmf_batch_fit_lls_rows_without_ratings(ctx):
+    """Hypotheses about a user and an item that have NO rating yet (the extra rating is the row's only entry: the row
+    moves from the tail of the descending-nnz order the partial sums follow to the one-rating rows), about an entry
+    whose user AND item are both empty, and H = 1; against fits on rebuilt containers, bit for bit."""
+    rs = np.random.RandomState(77)
+    n, m, d, N = 19, 26, 4, 110
+    flat = rs.choice((n - 2) * (m - 3), N, replace=False)          # users n-2, n-1 and items m-3 .. m-1 stay empty
+    ratings = np.column_stack([flat // (m - 3), flat % (m - 3), rs.randint(1, 6, N)]).astype(float)
+    hyps = [(n - 1, 0, 4.), (0, m - 1, 2.), (n - 2, m - 2, 5.), (n - 1, m - 1, 1.), (3, 4, 3.) if (3, 4) not in
+            set(zip(ratings[:, 0].astype(int), ratings[:, 1].astype(int))) else (n - 2, 1, 3.)]
+    steps = _batch_fit_case(ctx, ratings, n, m, d, hyps, max_steps=50)
+    assert steps.min() > 3
+    _batch_fit_case(ctx, ratings, n, m, d, hyps[2:3], max_steps=30, seed=3)                 # H = 1
+    _batch_fit_case(ctx, ratings, n, m, d, hyps[:2], subtract_mean=True, max_steps=20, seed=4)
+
+
 def test_pmf_batch_fit_lls_headline_shape(ctx):
     """The batched MAP re-fit at the metric's own shape - 943 x 1682, rank 10, N = 100 000 (106 ratings per user: the
     4-waves-per-row kernels, some rows beyond 192 ratings) - six hypotheses against six fits on rebuilt containers,
