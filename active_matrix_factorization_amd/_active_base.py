@@ -595,9 +595,15 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
         """Whether this model's hypotheses can go through the class' device batch (_lookahead_batch)."""
         return True
 
-    def _hypothesis_model(self, i, j, v):
-        """deepcopy(self) with R_ij = v added: the model a hypothesis is evaluated on."""
+    def _hypothesis_model(self, i, j, v, keep_rng=False):
+        """deepcopy(self) with R_ij = v added: the model a hypothesis is evaluated on.  The copy's constructor
+        draws n d + m d uniforms from np.random (pmf_cy.pyx:74-75, overwritten by the copied state); keep_rng
+        puts the generator back where it was - the batched paths account for those draws in ONE place
+        (_hypothesis_values), whatever they build afterwards."""
+        state = np.random.get_state() if keep_rng else None
         apmf = deepcopy(self)
+        if state is not None:
+            np.random.set_state(state)
         apmf.add_rating(i, j, v)
         return apmf
 
@@ -612,7 +618,8 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
             # hypothesis about an entry that is already rated (pmf_cy.pyx:143-150), and - when the reference
             # evaluates in-process (procs == 1; its default hands the pool to forked workers, whose draws the
             # parent never sees) - consume the n d + m d uniform draws of every copy's constructor
-            # (pmf_cy.pyx:74-75), so that a seeded run continues with the same random stream
+            # (pmf_cy.pyx:74-75), so that a seeded run continues with the same random stream.  This is the ONLY
+            # place the batched path touches the generator: model objects it builds later copy with keep_rng
             for i, j, _ in hyps:
                 if self._is_rated(i, j):
                     raise ValueError("can't rate already rated items")
@@ -709,7 +716,7 @@ class _ActiveBase(ProbabilisticMatrixFactorization):
                             cache[x] = y
                         val = cache[v]
                     else:
-                        val = cache[v] = self._hypothesis_values([(i, j, v)], fn, pass_v, 1)[0]
+                        val = cache[v] = self._hypothesis_values([(i, j, v)], fn, pass_v, procs)[0]
                 return val
             est = stats.norm.expect(integrand, loc=mean, scale=std, lb=left, ub=right, epsrel=.02,
                                     limit=self.quadrature_limit)

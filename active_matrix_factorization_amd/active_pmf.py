@@ -202,7 +202,7 @@ class ActivePMF(_ActiveBase):
                 else:
                     hm, hc = ctx.empty(K), ctx.empty((K, K))
                     for k, (i, j, v) in enumerate(part):
-                        apmf = self._hypothesis_model(i, j, v)
+                        apmf = self._hypothesis_model(i, j, v, keep_rng=True)
                         batch.get_state(k, hm, hc)
                         apmf.mean, apmf.cov = hm.to_host(), hc.to_host()
                         out.append(fn(apmf, v=v) if pass_v else fn(apmf))

@@ -466,7 +466,7 @@ class MNActivePMF(_ActiveBase):
                                                      (n_all - n_u) * d * 8, (n_all - n_u) * d * 8, H))
                     means = d_means
                 else:
-                    models = [self._hypothesis_model(i, j, v) for i, j, v in part]
+                    models = [self._hypothesis_model(i, j, v, keep_rng=True) for i, j, v in part]
                     for apmf in models:
                         apmf.do_fit()
                     means = np.stack([np.vstack((apmf.users, apmf.items)) for apmf in models])
@@ -489,7 +489,7 @@ class MNActivePMF(_ActiveBase):
             else:
                 dm, ds, do = ctx.empty((n_all, d)), ctx.empty((n_all, n_all)), ctx.empty((d, d))
                 for k, (i, j, v) in enumerate(part):
-                    apmf = models[k] if models is not None else self._hypothesis_model(i, j, v)
+                    apmf = models[k] if models is not None else self._hypothesis_model(i, j, v, keep_rng=True)
                     batch.get_state(k, dm, ds, do)
                     apmf.mean, apmf.cov_useritems, apmf.cov_latents = dm.to_host(), ds.to_host(), do.to_host()
                     out.append(fn(apmf, v=v) if pass_v else fn(apmf))

@@ -993,6 +993,34 @@ def test_lookahead_batched_equals_per_hypothesis(pkg, monkeypatch, key):
         assert batched == alone
 
 
+@pytest.mark.parametrize('key', ['1step-ge-3.5', 'total-variance', 'uv-entropy'])
+def test_lookahead_batched_rng_accounting(pkg, key):
+    """The reference's in-process evaluation (procs == 1) deep-copies the model once per hypothesis and every copy's
+    constructor draws n d + m d uniforms (pmf_cy.pyx:74-75); its default hands the pool to forked workers whose
+    draws the parent never sees.  The batched path accounts for exactly that, in one place, whether or not the
+    criterion makes it build model objects afterwards (1step-ge does, through fn(apmf, v)): with procs == 1 the
+    generator ends where len(hyps) constructor calls leave it, otherwise where it was."""
+    g = load_golden('lookahead_c1_mn')
+    a = _lookahead_model(pkg, g)
+    pool = sorted(a.unrated)[:3]
+    k = pkg.mn.KEY_FUNCS[key]
+    n_hyps = len(pool) * len(a.rating_values)
+    draws = n_hyps * (a.num_users + a.num_items) * a.latent_d
+    np.random.seed(1234)
+    np.random.random(draws)
+    want = np.random.get_state()
+    np.random.seed(1234)
+    v1 = a._get_key_vals(pool, k, procs=1)
+    got = np.random.get_state()
+    assert np.array_equal(got[1], want[1]) and got[2] == want[2]
+    np.random.seed(1234)
+    before = np.random.get_state()
+    v2 = a._get_key_vals(pool, k)
+    after = np.random.get_state()
+    assert np.array_equal(before[1], after[1]) and before[2] == after[2]
+    assert v1 == v2
+
+
 def test_lookahead_continuous_batched_equals_one_at_a_time(pkg, monkeypatch):
     """The CONTINUOUS lookahead (no rating_values: the class default; mn_active_pmf.py:686-691 integrates the
     criterion over R_ij with stats.norm.expect = adaptive Gauss-Kronrod quadrature, one rating value per call): the

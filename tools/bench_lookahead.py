@@ -11,6 +11,11 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get('APMF_SEGV_BT'):       # diagnosis runs (tools/repro_trace_segv.sh): native + Python stacks on a fault
+    import ctypes
+    import faulthandler
+    faulthandler.enable(all_threads=True)
+    ctypes.CDLL(os.environ['APMF_SEGV_BT'])
 from active_matrix_factorization_amd import mn_active_pmf as mn  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 50
