@@ -16,6 +16,7 @@
 // launch: the factor of a matrix is bit-identical whether it is factored alone or in a batch.
 #pragma once
 #include <stdlib.h>
+#include <atomic>
 #include "common.h"
 
 // every launch of this header goes through APMF_LAUNCH so that a translation unit can count them
@@ -623,9 +624,19 @@ static inline int chol_lower_jobs_on(hipStream_t stream, const ChJobs &J, int nj
     static const int fuse_jobs = getenv("APMF_CHOL_FUSE_JOBS") ? atoi(getenv("APMF_CHOL_FUSE_JOBS")) : CH_FUSE_JOBS;
     const bool next = njobs <= fuse_jobs;
     constexpr size_t next_lds = 2 * (size_t)CH_NB * TP * sizeof(double);
-    if (next && next_lds > 64 * 1024)      // (67.6 KB; set per call: the attribute is per device)
-        (void)hipFuncSetAttribute((const void *)k_chol_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)next_lds);
+    if (next && next_lds > 64 * 1024) {
+        // 67.6 KB of dynamic LDS: the attribute is per device and stays set - once per device and process, not per
+        // call (several host threads drive batches of their own through here at the same time)
+        static std::atomic<unsigned long long> attr_set{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+            (void)hipFuncSetAttribute((const void *)k_chol_update<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)next_lds);
+            attr_set.fetch_or(bit, std::memory_order_release);
+        }
+    }
     static const bool by_column = !(getenv("APMF_CHOL_COL") && getenv("APMF_CHOL_COL")[0] == '0');   // 0: comparison runs
     if (!next && by_column) {
         // many matrices: block column by block column, each tile updated once with all earlier panels

@@ -62,15 +62,12 @@ _MIN_STREAM_GROUP = 16          # hypotheses: smaller pools stay one batch
 
 def lookahead_streams():
     """Streams (groups of hypotheses advancing side by side) of a batched lookahead: APMF_LOOKAHEAD_STREAMS,
-    default 3; 1 = one batch on the model's own stream."""
+    default 3; 1 = one batch on the model's own stream.  (Profiled and unprofiled runs execute the same code: to
+    take a `rocprofv3 --kernel-trace` of a lookahead set APMF_LOOKAHEAD_STREAMS=1 on its command line - ROCm 7.2's
+    tracing tool faults in its own packet interceptor when several host threads submit at once, DESIGN.md section 4,
+    K6.)"""
     if 'APMF_LOOKAHEAD_STREAMS' in os.environ:
         return max(1, min(8, int(os.environ['APMF_LOOKAHEAD_STREAMS'])))
-    # under rocprofv3's tracing (it exports ROCPROF_KERNEL_TRACE & co.) stay on one stream: with three groups - six
-    # host threads launching at once - its kernel-trace tool segfaults inside a launch (ROCm 7.2; counter-collection
-    # passes and unprofiled runs are unaffected)
-    for k, v in os.environ.items():
-        if k.startswith('ROCPROF_') and k.endswith('_TRACE') and v.strip().lower() not in ('', '0', 'false', 'no', 'off'):
-            return 1
     return 3
 
 

@@ -119,24 +119,36 @@ class Comm(object):
         """The RCCL communicator over the socket rendezvous.  A failure is fatal for the caller (the product has no
         host path for a broken fabric) - unless `fallback`: then the ranks agree, over the sockets, whether EVERY one
         of them came up; if not, all drop RCCL together, the exchanges run host-staged over the sockets and
-        `rccl_error` says why (bench.py does this so that a first multi-GPU run still reports, loudly labelled)."""
+        `rccl_error` says why (bench.py does this so that a first multi-GPU run still reports, loudly labelled).
+        Rank 0's own verdict on the unique-id step travels WITH the id: when it failed nobody calls
+        ncclCommInitRank at all (an all-zero id would not fail there, it would wait).  What the agreement cannot
+        cover is a PARTIAL failure inside ncclCommInitRank itself - some ranks return an error while the others wait
+        in it for them: those never reach the flag exchange, so that case ends in the socket timeout of the ranks
+        that did fail (a labelled ConnectionError), not in a fallback."""
         import ctypes as C
         err = None
-        ident = np.zeros(128, np.uint8)
+        ident = np.zeros(129, np.uint8)       # [rank 0's ok flag | ncclUniqueId]
         try:
             self._libc = _lib.load_comm()
             if self.rank == 0:
-                _lib._check(self._libc.apmf_comm_unique_id(ident.ctypes.data))
+                _lib._check(self._libc.apmf_comm_unique_id(ident[1:].ctypes.data))
+                ident[0] = 1
         except Exception as e:      # noqa: BLE001 - reported, and fatal unless fallback
             if not fallback:
                 raise
             err = 'unique id: %s' % e
         ident = np.frombuffer(self.bcast_bytes(ident.tobytes()), np.uint8).copy()
+        root_ok = bool(ident[0])
+        if not root_ok and not fallback:
+            raise _lib.ApmfError(_lib.EHIP, 'rank 0 could not draw the RCCL unique id')
+        if not root_ok and err is None:
+            err = 'rank 0 has no unique id'
+        uid = np.ascontiguousarray(ident[1:])
         h = C.c_void_p()
         if err is None:
             try:
                 _lib._check(self._libc.apmf_comm_create(getattr(ctx, '_h', None), self.rank, self.world,
-                                                        ident.ctypes.data, C.byref(h)))
+                                                        uid.ctypes.data, C.byref(h)))
             except Exception as e:  # noqa: BLE001
                 if not fallback:
                     raise

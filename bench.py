@@ -22,7 +22,11 @@ data-path collective.  --scaling strong: the B states are split over the ranks (
 the PMF fit is ONE fit row-sharded over the ranks (sharding.sharded_fit_lls: per trial ONE grouped
 device-to-device all-gather carrying the log-likelihood partial sums and the U / V row blocks of both
 speculative next trial points).
-A communicator that cannot be set up is fatal (non-zero exit): no number is printed.
+The product is strict about its fabric (a communicator that cannot be set up raises).  bench.py alone sets it up with
+fallback=True: if RCCL does not come up on EVERY rank the ranks agree on that over the rendezvous sockets, all drop to
+the host-staged exchange together, and the line says so at the top level ("exchange_fallback": "<which ranks, why>")
+as well as in config.exchange - a number measured over the fallback is labelled, never silent.  A rendezvous that
+fails, or ranks stuck inside ncclCommInitRank while others failed, end in a time-out and a non-zero exit.
 """
 import argparse
 import json
@@ -38,6 +42,21 @@ if ROOT not in sys.path:
 
 N_USERS, N_ITEMS, LATENT_D, N_RATINGS = 943, 1682, 10, 100000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def build_id():
+    """First 16 hex digits of the sha256 over the three product libraries: says which build a number (or a committed
+    PMC pass, tools/pmc_*.py stamp the same id) belongs to."""
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, 'active_matrix_factorization_amd')
+    for name in ('libapmf_hip.so', 'libapmf_dense.so', 'libapmf_comm.so'):
+        try:
+            with open(os.path.join(pkg, name), 'rb') as f:
+                h.update(f.read())
+        except OSError:
+            h.update(b'missing:' + name.encode())
+    return h.hexdigest()[:16]
 
 
 def synth_ratings(seed):
@@ -133,6 +152,9 @@ def main():
     if args.workload == 'c5':
         out = bench_c5(args, ctx, comm, rank, world)
         if rank == 0:
+            out['build_id'] = build_id()
+            if getattr(comm, 'rccl_error', None):
+                out['exchange_fallback'] = comm.rccl_error
             print(json.dumps(out))
         comm.barrier()
         comm.close()
@@ -248,17 +270,21 @@ def main():
         avg_ms = float(kern_ms.mean()) if kern_ms.size else None
         algo_bytes = 8.0 * cand_per_step  # 4 B Sigma_ij read + 4 B score written
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else None
-        traffic = None
+        # HBM bytes per launch from the PMC counters: separate rocprofv3 passes of this same command (FETCH_SIZE and
+        # WRITE_SIZE each in a pass of its own, the guide's gfx950 correction applied by tools/pmc_summary.py), so
+        # they come from a committed file - quoted only for the workload they were collected on, with their
+        # provenance beside them
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_k2_latest.json')
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
-                # PMC passes are separate rocprofv3 runs of this same command; only quote them
-                # for the workload they were measured on
-                if rec.get('workload') == '943x1682-d10-B%d' % B:
+                if abs(float(rec.get('algorithmic_bytes_per_launch', 0)) - algo_bytes) < 1.:
                     traffic = rec.get('hbm_bytes_per_launch')
+                    traffic_source = {'file': 'profiles/pmc_k2_latest.json', 'collected': rec.get('collected', 'round 3 (unstamped)'),
+                                      'same_build': rec.get('build_id') == build_id() if rec.get('build_id') else None}
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         # grad-step algorithmic bytes, SURVEY 8(d) f32/int32 COO basis
         gs_bytes = N_RATINGS * (12 + 16 * d) + N_RATINGS * (12 + 8 * d) + 16 * (n + m) * d
         out = {
@@ -281,8 +307,10 @@ def main():
             'roofline': {'bound': 'hbm', 'kernel': 'k_mn_grid<float,10,4>',
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS if achieved else None,
-                         'traffic': traffic, 'algorithmic_bytes_per_launch': algo_bytes,
+                         'traffic': traffic, 'traffic_source': traffic_source,
+                         'algorithmic_bytes_per_launch': algo_bytes,
                          'avg_kernel_ms': avg_ms, 'launches_timed': int(kern_ms.size)},
+            'build_id': build_id(),
             'grad_steps': {'value': grad_steps_per_s, 'unit': 'PMF grad-steps/s', 'dtype': 'f64',
                            'ms_per_grad_step': 1e3 * t_grad / max(per_gpu_steps, 1),
                            'grad_steps_timed_per_gpu': per_gpu_steps,
@@ -310,6 +338,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             print('bench.py: CPU baseline (about 30 s) ...', file=sys.stderr, flush=True)
             out['cpu_baseline'] = cpu_baseline(mean[0], diag[0], omega[0], rs, ratings, U0, V0)
+        if getattr(comm, 'rccl_error', None):
+            out['exchange_fallback'] = comm.rccl_error      # top level: this number was measured host-staged
         print(json.dumps(out))
     comm.barrier()
     comm.close()
@@ -587,12 +617,24 @@ def lookahead_leg(n_cand):
         flops = (fact + 2 * stats.get('gradients', 0)) * (N ** 3 / 3.)
         out['mfma_model'] = {'flops': flops, 'tflops': flops / dt / 1e12, 'frac_of_peak': flops / dt / 1e12 / F64_MFMA_PEAK_TFLOPS,
                              'peak_tflops': F64_MFMA_PEAK_TFLOPS, 'note': 'operation count of the factorisations / inverses'}
+    # Counters (not rates) of a separate rocprofv3 --pmc pass of this same leg, when one is on file for this
+    # hypothesis count: the flops and bytes a run executes do not depend on the clock, so the RATES are formed with
+    # THIS run's seconds; the file, when it was collected and whether it was this build are stated beside them
     pmc = os.path.join(ROOT, 'profiles', 'pmc_lookahead_latest.json')
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             if rec.get('hypotheses') == H:
-                out['pmc'] = rec
+                flops, hbm = float(rec['mfma_f64_flops']), float(rec['hbm_bytes'])
+                out['pmc_counters'] = {
+                    'source': 'profiles/pmc_lookahead_latest.json', 'collected': rec.get('collected', 'round 3 (unstamped)'),
+                    'same_build': rec.get('build_id') == build_id() if rec.get('build_id') else None,
+                    'mfma_f64_flops': flops, 'hbm_bytes': hbm, 'dispatches': rec.get('dispatches'),
+                    'mfma_f64_tflops_at_this_runs_seconds': flops / dt / 1e12,
+                    'mfma_f64_frac_of_peak': flops / dt / 1e12 / F64_MFMA_PEAK_TFLOPS, 'peak_tflops': F64_MFMA_PEAK_TFLOPS,
+                    'hbm_GBs_at_this_runs_seconds': hbm / dt / 1e9, 'hbm_frac_of_8TBs': hbm / dt / 8e12,
+                    'note': 'counter totals of a separate profiled pass (possibly an earlier build: same_build); '
+                            'rates = those totals / the seconds of the run printed here'}
         except Exception:
             pass
     return out

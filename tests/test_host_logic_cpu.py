@@ -79,16 +79,16 @@ def test_pack_variates_layouts():
 
 
 def test_lookahead_streams_knob(monkeypatch):
-    """Stream groups of a batched lookahead: 3 by default, APMF_LOOKAHEAD_STREAMS overrides, and ONE under
-    rocprofv3's tracing (its kernel-trace tool does not survive six threads launching at once)."""
+    """Stream groups of a batched lookahead: 3 by default, APMF_LOOKAHEAD_STREAMS overrides - and nothing else does:
+    a run under a profiler executes the code an unprofiled run executes (tools/prof_*.sh pass
+    APMF_LOOKAHEAD_STREAMS=1 to their kernel-trace passes explicitly)."""
     from active_matrix_factorization_amd import mn_active_pmf as mn
     for k in [k for k in os.environ if k.startswith('ROCPROF_')] + ['APMF_LOOKAHEAD_STREAMS']:
         monkeypatch.delenv(k, raising=False)
     assert mn.lookahead_streams() == 3
     monkeypatch.setenv('ROCPROF_KERNEL_TRACE', '1')
-    assert mn.lookahead_streams() == 1
+    assert mn.lookahead_streams() == 3
     monkeypatch.setenv('APMF_LOOKAHEAD_STREAMS', '2')
     assert mn.lookahead_streams() == 2
-    monkeypatch.delenv('APMF_LOOKAHEAD_STREAMS')
-    monkeypatch.setenv('ROCPROF_KERNEL_TRACE', 'False')
-    assert mn.lookahead_streams() == 3
+    monkeypatch.setenv('APMF_LOOKAHEAD_STREAMS', '1')
+    assert mn.lookahead_streams() == 1

@@ -214,3 +214,56 @@ def test_rccl_fallback_is_agreed_and_labelled():
         _h = None
     with pytest.raises(Exception):
         sh.Comm(0, 1, ctx=NoDevice(), rccl=True)                   # strict by default
+
+
+def _root_fails_worker(rank, world, port, q):
+    try:
+        from active_matrix_factorization_amd import _lib, sharding as sh
+        created = []
+
+        class FakeComm(object):          # stands where libapmf_comm.so would
+            def apmf_comm_unique_id(self, ptr):
+                return -2                # rank 0 cannot draw the id
+
+            def apmf_comm_create(self, *a):
+                created.append(a)        # must never be reached: with a zeroed id ncclCommInitRank would wait
+                return 0
+
+            def apmf_comm_destroy(self, h):
+                return 0
+        _lib.load_comm = lambda: FakeComm()
+        _lib._check = lambda rc: (_ for _ in ()).throw(_lib.ApmfError(rc, 'fake failure')) if rc else None
+
+        class NoDevice(object):
+            _h = None
+            device = None
+
+            def sync(self):
+                pass
+        comm = sh.Comm(rank, world, '127.0.0.1', port, ctx=NoDevice(), rccl=True, tag='g', fallback=True)
+        assert not created, 'apmf_comm_create was called although rank 0 had no id'
+        assert not comm.has_rccl and str(list(range(world))) in comm.rccl_error, comm.rccl_error
+        if rank:
+            assert 'rank 0 has no unique id' in comm.rccl_error, comm.rccl_error
+        comm.barrier()
+        comm.close()
+        q.put((rank, 'ok'))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_rccl_fallback_when_only_rank0_fails_to_draw_the_id():
+    """Rank 0's verdict on the unique-id step travels with the id: when it failed, NO rank calls
+    apmf_comm_create (ncclCommInitRank with an all-zero id would wait, not fail) and all fall back together."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_root_fails_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(msg == 'ok' for _, msg in res), '\n'.join(str(x) for x in res)

@@ -24,6 +24,22 @@ def totals(path):
     return tot, per_kernel, len(disp)
 
 
+def stamp():
+    """When and on which build the counters were collected (bench.py quotes both beside anything it takes from here)."""
+    import datetime
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ('libapmf_hip.so', 'libapmf_dense.so', 'libapmf_comm.so'):
+        try:
+            with open(os.path.join(root, 'active_matrix_factorization_amd', name), 'rb') as f:
+                h.update(f.read())
+        except OSError:
+            h.update(b'missing:' + name.encode())
+    return {'collected': datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%MZ'), 'build_id': h.hexdigest()[:16]}
+
+
 def main():
     run = json.load(open(sys.argv[1]))
     sq, sq_k, ndisp = totals(sys.argv[2])
@@ -42,6 +58,7 @@ def main():
            'bytes_per_hypothesis': hbm / run['hypotheses'], 'flops_per_hypothesis': flops / run['hypotheses'],
            'correction': 'FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported; MOPS x 512 flops',
            'mfma_flops_by_kernel': {k: v.get('SQ_INSTS_VALU_MFMA_MOPS_F64', 0) * 512. for k, v in top}}
+    out.update(stamp())
     print(json.dumps(out, indent=1))
 
 

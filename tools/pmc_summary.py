@@ -18,6 +18,22 @@ def mean_counter(path, kernel, counter):
     return sum(vals) / len(vals), len(vals)
 
 
+def stamp():
+    """When and on which build the counters were collected (bench.py quotes both beside anything it takes from here)."""
+    import datetime
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for name in ('libapmf_hip.so', 'libapmf_dense.so', 'libapmf_comm.so'):
+        try:
+            with open(os.path.join(root, 'active_matrix_factorization_amd', name), 'rb') as f:
+                h.update(f.read())
+        except OSError:
+            h.update(b'missing:' + name.encode())
+    return {'collected': datetime.datetime.utcnow().strftime('%Y-%m-%dT%H:%MZ'), 'build_id': h.hexdigest()[:16]}
+
+
 def main():
     kernel, fpath, wpath = sys.argv[1:4]
     fetch_kib, nf = mean_counter(fpath, kernel, 'FETCH_SIZE')
@@ -30,6 +46,7 @@ def main():
     if len(sys.argv) > 4:
         out['algorithmic_bytes_per_launch'] = float(sys.argv[4])
         out['traffic_over_algorithmic'] = out['hbm_bytes_per_launch'] / out['algorithmic_bytes_per_launch']
+    out.update(stamp())
     print(json.dumps(out, indent=1))
 
 
