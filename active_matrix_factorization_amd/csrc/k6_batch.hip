@@ -92,6 +92,7 @@ struct HypState {
     long long max_steps;          // < 0: no limit
     int status, need_grad, slow, accepted;
     int cert_skipped, inv_ok;     // trial certificates settled by the eigenvalue bound; the bound's input is current
+    int bnd_ok, pad_;             // the structured bound's inputs (bndp) belong to the current gradient
 };
 
 struct OmegaConsts {
@@ -116,6 +117,8 @@ struct Refs {
     double *trace;        // [H][trace_cap]
     double *invp;         // [H][nbk (nbk + 1) / 2] partial sums of |S^-1|_F^2 at the current point (kb_lauum)
     double *stepp;        // [H][nt32 (nt32 + 1) / 2] partial sums of |lr g_S|_F^2 of the trial (kb_trial_S)
+    double *c2row;        // [H][n] per user row: sum of the squared cross entries of g_S's rating part (kb_kl_rows)
+    double *bndp;         // [H][ceil(N / 256)][2] per kb_finish_rows block: max_t q_t, sum of c2row (cert_by_bound)
     int *skipword;        // one int, 1: the info word of a factorisation job that is not to run
     int *ei, *ej;         // extra rating of the hypothesis (ei < 0: none)
     double *ev;
@@ -281,14 +284,43 @@ __device__ __forceinline__ int cert_by_bound(const Refs &R, int h, int nstep, do
 {
     // one wave
     const int lane = threadIdx.x & 63;
-    if (!R.hs[h].inv_ok) return 0;
-    const int ninv = R.nbk * (R.nbk + 1) / 2;
-    double a = 0., b = 0.;
-    for (int i = lane; i < ninv; i += 64) a += R.invp[(size_t)h * ninv + i];
-    for (int i = lane; i < nstep; i += 64) b += R.stepp[(size_t)h * nstep + i];
-    a = wave_sum(a);
-    b = wave_sum(b);
-    return a > 0. && .99 / sqrt(a) - sqrt(b) >= min_eig * (1. + 1e-6);
+    const HypState &s = R.hs[h];
+    double a = 0.;
+    int ok = 0;
+    if (s.inv_ok) {
+        const int ninv = R.nbk * (R.nbk + 1) / 2;
+        double b = 0.;
+        for (int i = lane; i < ninv; i += 64) a += R.invp[(size_t)h * ninv + i];
+        for (int i = lane; i < nstep; i += 64) b += R.stepp[(size_t)h * nstep + i];
+        a = wave_sum(a);
+        b = wave_sum(b);
+        ok = a > 0. && .99 / sqrt(a) - sqrt(b) >= min_eig * (1. + 1e-6);
+    }
+    // The structured bound (kb_finish_rows has the algebra): l_min(cand) >= l_min(cur + 2c cur^-1) - l_max(lr Rs + c D).
+    // cur is positive definite (it has a Cholesky factor, or came out of the projection), so every eigenvalue of the
+    // first bracket is l + 2c / l >= 2 sqrt(2c) - and >= L + 2c / L when all of cur's are >= L >= sqrt(2c), L the
+    // Frobenius bound above.  Rigorous like the plain Weyl bound, and it does not lose the entropy term's size: it
+    // settles most of the trials the plain one cannot.  1 % is kept to spare on either side.
+    if (!ok && s.bnd_ok && s.lr > 0.) {
+        const int nfr = (R.N + 255) / 256;
+        double qmax = -INFINITY, c2 = 0.;
+        for (int i = lane; i < nfr; i += 64) {
+            qmax = fmax(qmax, R.bndp[((size_t)h * nfr + i) * 2]);
+            c2 += R.bndp[((size_t)h * nfr + i) * 2 + 1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) qmax = fmax(qmax, __shfl_xor(qmax, o, 64));
+        c2 = wave_sum(c2);
+        const double c = s.lr * R.d / 2.;
+        double low = 2. * sqrt(2. * c);
+        if (s.inv_ok && a > 0.) {
+            const double L = .99 / sqrt(a);
+            if (L >= 1.01 * sqrt(2. * c)) low = fmax(low, L + 2. * c / L);
+        }
+        const double up = s.lr * (fmax(qmax, 0.) + sqrt(c2));
+        ok = c2 == c2 && qmax == qmax && .99 * low - 1.01 * up >= min_eig * (1. + 1e-6);
+    }
+    return ok;
 }
 
 __global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *__restrict__ sel,
@@ -549,7 +581,7 @@ __device__ __forceinline__ void kl_rows_body(const Refs &R, const int *__restric
     const int xc = SIDE == 0 ? xj : xi;
     const double xv = has_extra ? R.ev[h] : 0.;
     const int64_t end = end0 + (has_extra ? 1 : 0);
-    double gm = 0., wv = 0., gs_d = 0., cv = 0., s2 = 0., rs = 0.;
+    double gm = 0., wv = 0., gs_d = 0., cv = 0., s2 = 0., rs = 0., c2 = 0.;
     for (int64_t t0 = beg + g; t0 < end; t0 += (int64_t)G * UN6) {
 #pragma unroll
         for (int u = 0; u < UN6; u++) {
@@ -582,6 +614,7 @@ __device__ __forceinline__ void kl_rows_body(const Refs &R, const int *__restric
                         const double gij = inv_sig * (cross + 2. * s * (oc.sdd + oc.off2 + oc.D2) - r * oc.T);
                         gS[(size_t)row * N + other] += gij;
                         gS[(size_t)other * N + row] += gij;
+                        c2 += gij * gij;
                     }
                 }
             }
@@ -590,6 +623,10 @@ __device__ __forceinline__ void kl_rows_body(const Refs &R, const int *__restric
     gm = xgsum<DP>(gm);
     wv = xgsum<DP>(wv);
     gs_d = xgsum<DP>(gs_d); cv = xgsum<DP>(cv); s2 = xgsum<DP>(s2); rs = xgsum<DP>(rs);
+    if (SIDE == 0) {
+        c2 = xgsum<DP>(c2);          // (only the k == 0 lanes added: lane 0 ends with the row's total)
+        if (lane == 0) R.c2row[(size_t)h * n + row] = c2;
+    }
     const int stride = SIDE == 0 ? 2 * d + 4 : d + 2;
     double *out = (SIDE == 0 ? R.racc_u + (size_t)h * n * (2 * d + 4) : R.racc_v + (size_t)h * R.m * (d + 2)) +
                   (size_t)row * stride;
@@ -618,25 +655,47 @@ __global__ __launch_bounds__(256) void kb_kl_rows(const Refs R, const int *__res
     else kl_rows_body<DP, 1>(R, sel, (int)blockIdx.x - nbu, ptr_v, idx_v, val_v, inv_sig);
 }
 
-// g_mean rows and the diagonal of g_S from the per-row sums
+// g_mean rows and the diagonal of g_S from the per-row sums.  Also the inputs of the structured eigenvalue bound
+// (cert_by_bound): with g_S = Rs - (d/2)(2 S^-1 - diag S^-1), Rs the sparse rating / prior part, the trial point is
+// cand = (cur + 2c cur^-1) - (lr Rs + c diag cur^-1), c = lr d / 2, and the second bracket - sparse, dominated by its
+// diagonal - has l_max <= lr (max_t q_t + |cross entries|_F), q_t = Rs_tt + (d/2) (S^-1)_tt.  Per block: max q_t and
+// the users' share of the squared cross entries, fixed order.
 __global__ __launch_bounds__(256) void kb_finish_rows(const Refs R, const int *__restrict__ sel, double inv_sig,
                                                       double sig_u, double sig_v)
 {
     const int h = sel[blockIdx.y];
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= R.N) return;
     const int d = R.d, n = R.n;
-    const double *__restrict__ M = tabp(R, T_M_CUR, h);
-    double *__restrict__ gmean = tabp(R, T_M_GRAD, h);
-    double *__restrict__ gS = tabp(R, T_S_GRAD, h);
-    const double trO = R.oc[h].T;
-    const bool user = t < n;
-    const double *acc = user ? R.racc_u + ((size_t)h * n + t) * (2 * d + 4)
-                             : R.racc_v + ((size_t)h * R.m + (t - n)) * (d + 2);
-    const double prior = user ? sig_u : sig_v;
-    for (int k = 0; k < d; k++) gmean[(size_t)t * d + k] = inv_sig * acc[k] + M[(size_t)t * d + k] / prior;
-    const double gs = user ? acc[2 * d] : acc[d];
-    gS[(size_t)t * R.N + t] += inv_sig * gs + trO / (2. * prior);
+    double q = -INFINITY, c2 = 0.;
+    if (t < R.N) {
+        const double *__restrict__ M = tabp(R, T_M_CUR, h);
+        double *__restrict__ gmean = tabp(R, T_M_GRAD, h);
+        double *__restrict__ gS = tabp(R, T_S_GRAD, h);
+        const double trO = R.oc[h].T;
+        const bool user = t < n;
+        const double *acc = user ? R.racc_u + ((size_t)h * n + t) * (2 * d + 4)
+                                 : R.racc_v + ((size_t)h * R.m + (t - n)) * (d + 2);
+        const double prior = user ? sig_u : sig_v;
+        for (int k = 0; k < d; k++) gmean[(size_t)t * d + k] = inv_sig * acc[k] + M[(size_t)t * d + k] / prior;
+        const double gs = user ? acc[2 * d] : acc[d];
+        const double ent = gS[(size_t)t * R.N + t];            // -(d/2) (S^-1)_tt
+        const double add = inv_sig * gs + trO / (2. * prior);
+        gS[(size_t)t * R.N + t] = ent + add;
+        q = add - ent;
+        if (user) c2 = R.c2row[(size_t)h * n + t];
+    }
+    __shared__ double redq[4], redc[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q = fmax(q, __shfl_xor(q, o, 64));
+    c2 = wave_sum(c2);
+    if ((threadIdx.x & 63) == 0) { redq[threadIdx.x >> 6] = q; redc[threadIdx.x >> 6] = c2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *out = R.bndp + ((size_t)h * gridDim.x + blockIdx.x) * 2;
+        out[0] = fmax(fmax(redq[0], redq[1]), fmax(redq[2], redq[3]));
+        out[1] = (redc[0] + redc[1]) + (redc[2] + redc[3]);
+        if (blockIdx.x == 0) R.hs[h].bnd_ok = 1;
+    }
 }
 
 // cov_latents' gradient: one block per (k, l); fixed-order sums over the rows
@@ -829,6 +888,7 @@ __device__ __forceinline__ void decide_one(const Refs &R, int h, int mode, int f
         s.cur_ld_o = s.ld_o;
         s.need_grad = 1;
         s.inv_ok = 0;
+        s.bnd_ok = 0;
         s.accepted = 1;
         if (s.status == ST_ACTIVE && s.max_steps >= 0 && s.steps >= s.max_steps) s.status = ST_PAUSED;
     } else {
@@ -2224,6 +2284,8 @@ int apmf_mn_batch_create(apmf_ctx *ctx, const apmf_ratings *r, int d, int H, int
     BA(R.oc, (size_t)H * sizeof(OmegaConsts));
     BA(R.invp, (size_t)H * (R.nbk * (R.nbk + 1) / 2) * sizeof(double));
     BA(R.stepp, (size_t)H * (((N + 31) / 32) * ((N + 31) / 32 + 1) / 2) * sizeof(double));
+    BA(R.c2row, (size_t)H * R.n * sizeof(double));
+    BA(R.bndp, (size_t)H * ((N + 255) / 256) * 2 * sizeof(double));
     BA(R.skipword, sizeof(int));
     // eigen sets: the synchronous one and one per slow lane.  One lane: a pass is a couple of ms of launches
     // (measured at 94 x 425: H = 10 - 1 lane 1.11 s, 2: 1.30 s; H = 250 - 1 lane 6.6 s, 2: 7.0 s; concurrent
@@ -2418,6 +2480,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         s.accepted = 0;
         s.cert_skipped = 0;
         s.inv_ok = 0;
+        s.bnd_ok = 0;
     }
     b->st_iters = b->st_trials = b->st_grads = b->st_slow_grad = 0;
     b->st_slow[0] = b->st_slow[1] = b->st_slow[2] = b->st_slow[3] = 0;
