@@ -36,7 +36,21 @@ struct ChJob {
                     // a non-zero value on entry skips the job)
     double *linv;   // inverse of the diagonal block of the current panel: CH_NB^2 doubles ...
     int linv_keep;  // ... 0: one slot reused by every panel; 1: slot p for panel p (all kept)
+    // Block-column route only (chol_route_by_column): when `src` is set, the matrix to factor is NOT in A yet - every
+    // tile is READ from src (lower triangle, same pitch) the first time the factorisation touches it, and the factor is
+    // written to A as always: the caller saves the pass that would copy src into A (K6: the trial point is written
+    // once, and both of its factorisations start from there).  shifted: the diagonal is taken as
+    // v - (eig + 1e-10 max(|v|, |eig|)) - the certificate's matrix "src - (min_eig + delta) I".
+    int shifted;
+    const double *src;
+    double eig;
 };
+
+// the value the factorisation starts from at (i, j) of a job with `src`
+__device__ __forceinline__ double ch_first(const ChJob &job, double v, bool on_diag)
+{
+    return (job.shifted && on_diag) ? v - (job.eig + 1e-10 * fmax(fabs(v), fabs(job.eig))) : v;
+}
 
 // up to two jobs by value (the single-matrix callers), or a device array of jobs
 struct ChJobs {
@@ -336,12 +350,14 @@ __global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
     const int tid = threadIdx.x;
     const int nb = min(CH_NB, N - k);
     TileRegs<CH_NB, CH_NB> t;
-    t.load(A, N, k, k, N, N);
+    const bool first = k == 0 && job.src != nullptr;       // block column 0 is first touched here
+    t.load(first ? job.src : A, N, k, k, N, N);
     if (*info != 0) return;          // an earlier panel already failed (block-uniform)
 #pragma unroll
     for (int q = 0; q < t.PER; q++) {
         const int i = t.row(q), j = t.col(q);
-        T[i][j] = (i < nb && j <= i) ? t.v[q] : (i == j ? 1. : 0.);
+        const double v = first ? ch_first(job, t.v[q], i == j) : t.v[q];
+        T[i][j] = (i < nb && j <= i) ? v : (i == j ? 1. : 0.);
         X[i][j] = 0.;
     }
     if (tid == 0) s_fail = 0;
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k
     {
         TileRegs<CH_NB, CH_NB> x, t;
         x.load(linv, CH_NB, 0, 0, CH_NB, CH_NB);
-        t.load(A, N, r0, k, N, N);
+        t.load((k == 0 && job.src != nullptr) ? job.src : A, N, r0, k, N, N);     // (off-diagonal tiles: no shift)
         if (info0 != 0) return;
 #pragma unroll
         for (int q = 0; q < t.PER; q++) {
@@ -560,9 +576,16 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
     const int j0 = jb * CH_NB, i0 = j0 + bx * 64;
     const int info0 = *gmem(job.info);   // (first: loads return in order, its wait leaves the tiles in flight)
     f64x4 old[2][2];
-    TILE_FOR_EACH(u, v, r) {
-        const int i = min(i0 + tile_row(u, r), N - 1), j = min(j0 + tile_col(v), N - 1);
-        old[u][v][r] = gmem(A)[(size_t)i * N + j];
+    {
+        // the tiles of block column jb >= 1 are touched here for the first time: from src when the job has one
+        const double *__restrict__ A0 = job.src ? job.src : A;
+        TILE_FOR_EACH(u, v, r) {
+            const int i = min(i0 + tile_row(u, r), N - 1), j = min(j0 + tile_col(v), N - 1);
+            old[u][v][r] = gmem(A0)[(size_t)i * N + j];
+        }
+        if (job.src && job.shifted && bx == 0)
+            TILE_FOR_EACH(u, v, r)
+                if (tile_row(u, r) == tile_col(v)) old[u][v][r] = ch_first(job, old[u][v][r], true);
     }
     // Two half-panels of operands are in flight: the loads of half-panel h + 2 are issued while h is multiplied, so a
     // load has two multiply phases to arrive in (one was not enough: a block spent 2.8 us per half-panel, 0.85 of them
@@ -615,6 +638,14 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
 
 // Enqueue the factorisation of `njobs` matrices (all N x N).  The jobs' info words must have
 // been zeroed (or preset non-zero to skip a job) by the caller, on the same stream.
+// whether chol_lower_jobs[_on] takes the block-column route for this many jobs (the only route that honours ChJob::src)
+static inline bool chol_route_by_column(int njobs)
+{
+    static const int fuse_jobs = getenv("APMF_CHOL_FUSE_JOBS") ? atoi(getenv("APMF_CHOL_FUSE_JOBS")) : CH_FUSE_JOBS;
+    static const bool by_column = !(getenv("APMF_CHOL_COL") && getenv("APMF_CHOL_COL")[0] == '0');
+    return njobs > fuse_jobs && by_column;
+}
+
 static inline int chol_lower_jobs_on(hipStream_t stream, const ChJobs &J, int njobs, int N)
 {
     if (njobs <= 0) return APMF_OK;

@@ -92,7 +92,8 @@ struct HypState {
     long long max_steps;          // < 0: no limit
     int status, need_grad, slow, accepted;
     int cert_skipped, inv_ok;     // trial certificates settled by the eigenvalue bound; the bound's input is current
-    int bnd_ok, pad_;             // the structured bound's inputs (bndp) belong to the current gradient
+    int bnd_ok;                   // the structured bound's inputs (bndp) belong to the current gradient
+    int cur_sym;                  // cov_useritems of the current point is EXACTLY symmetric (an accepted fast-path trial)
 };
 
 struct OmegaConsts {
@@ -196,7 +197,12 @@ __global__ __launch_bounds__(256) void kb_copy(const Refs R, const int *__restri
 // and F = cand (its factor gives log det and, if the trial is accepted, the inverse).
 // 32 x 32 tiles on or above the diagonal; the mirrored tile goes through LDS so that every
 // global access is a row segment.
-__global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__restrict__ sel, double min_eig)
+// materialize: also write F and W (the factorisations that follow run in place); 0: they read cand on their first
+// touch of every tile (ChJob::src, block-column route).  When the current point and the gradient are EXACTLY
+// symmetric - the point an accepted fast-path trial (cur_sym), the gradient kb_lauum's (inv_ok) - the mirrored tile
+// holds the same bits, (x + x) / 2 = x, and it is not read: same result, half the reads.
+__global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__restrict__ sel, double min_eig,
+                                                  int materialize, int allow_sym)
 {
     __shared__ double A[32][33], B[32][33];
     const int h = sel[blockIdx.y];
@@ -204,6 +210,7 @@ __global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__res
     int tj, ti;
     tri_tile((int)blockIdx.x, tj, ti);       // ti <= tj
     const double lr = R.hs[h].lr;
+    const bool sym = allow_sym && R.hs[h].cur_sym && R.hs[h].inv_ok;      // block-uniform
     const double *__restrict__ cur = tabp(R, T_S_CUR, h);
     const double *__restrict__ g = tabp(R, T_S_GRAD, h);
     double *__restrict__ cand = tabp(R, T_S_CAND, h);
@@ -212,7 +219,24 @@ __global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__res
     const int i0 = ti * 32, j0 = tj * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     double step2 = 0.;        // this block's share of |lr g|_F^2 >= |cur - cand|_F^2 (both tiles of the pair)
-    {
+    if (sym) {
+        double gv[4], cv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = ty + 8 * q;
+            const size_t ea = (size_t)min(i0 + r, N - 1) * N + min(j0 + tx, N - 1);
+            gv[q] = g[ea];
+            cv[q] = cur[ea];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = ty + 8 * q;
+            const bool oka = i0 + r < N && j0 + tx < N;
+            const double sa = oka ? __dmul_rn(lr, gv[q]) : 0.;
+            A[r][tx] = oka ? __dsub_rn(cv[q], sa) : 0.;
+            step2 += ti != tj ? 2. * (sa * sa) : sa * sa;
+        }
+    } else {
         // all 16 loads of the thread are requested (at clamped addresses) before any is used
         double gv[4][2], cv[4][2];
 #pragma unroll
@@ -247,13 +271,15 @@ __global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__res
         for (int r = ty; r < 32; r += 8) {
             // upper tile element (i, j), i < j, and the element (j0 + r, i0 + tx) of the lower tile
             const int i = i0 + r, j = j0 + tx;
-            if (i < N && j < N) cand[(size_t)i * N + j] = (A[r][tx] + B[tx][r]) / 2;
+            if (i < N && j < N) cand[(size_t)i * N + j] = sym ? A[r][tx] : (A[r][tx] + B[tx][r]) / 2;
             const int i2 = j0 + r, j2 = i0 + tx;
             if (i2 < N && j2 < N) {
-                const double v = (A[tx][r] + B[r][tx]) / 2;
+                const double v = sym ? A[tx][r] : (A[tx][r] + B[r][tx]) / 2;
                 cand[(size_t)i2 * N + j2] = v;
-                F[(size_t)i2 * N + j2] = v;
-                W[(size_t)i2 * N + j2] = v;
+                if (materialize) {
+                    F[(size_t)i2 * N + j2] = v;
+                    W[(size_t)i2 * N + j2] = v;
+                }
             }
         }
     } else {
@@ -263,7 +289,7 @@ __global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__res
             // (upper + lower) / 2 off the diagonal; the diagonal itself is left alone
             const double v = r == tx ? A[r][tx] : (r < tx ? (A[r][tx] + A[tx][r]) / 2 : (A[tx][r] + A[r][tx]) / 2);
             cand[(size_t)i * N + j] = v;
-            if (j <= i) {
+            if (materialize && j <= i) {
                 F[(size_t)i * N + j] = v;
                 W[(size_t)i * N + j] = i == j ? v - (min_eig + 1e-10 * fmax(fabs(v), fabs(min_eig))) : v;
             }
@@ -271,7 +297,8 @@ __global__ __launch_bounds__(256) void kb_trial_S(const Refs R, const int *__res
     }
 }
 
-__device__ __forceinline__ void make_jobs_one(const Refs &R, int y, int h, int mode, ChJob *__restrict__ jobs);
+__device__ __forceinline__ void make_jobs_one(const Refs &R, int y, int h, int mode, ChJob *__restrict__ jobs,
+                                              int from_cand = 0, double min_eig = 0.);
 
 // mean and cov_latents parts of the trial point (cov_latents symmetrised like project_psd does);
 // jobs != nullptr: also the hypothesis' pair of factorisation jobs (certificate + factor)
@@ -323,14 +350,17 @@ __device__ __forceinline__ int cert_by_bound(const Refs &R, int h, int nstep, do
     return ok;
 }
 
+// (bound_eig: the threshold the eigenvalue bounds are held to - infinity switches them off; from_cand / min_eig: see
+// make_jobs_one)
 __global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *__restrict__ sel,
-                                                      ChJob *__restrict__ jobs, int nstep, double min_eig)
+                                                      ChJob *__restrict__ jobs, int nstep, double bound_eig,
+                                                      int from_cand, double min_eig)
 {
     const int h = sel[blockIdx.y];
     if (jobs && blockIdx.x == 0 && threadIdx.x < 64) {
-        const int skip = cert_by_bound(R, h, nstep, min_eig);
+        const int skip = cert_by_bound(R, h, nstep, bound_eig);
         if (threadIdx.x == 0) {
-            make_jobs_one(R, (int)blockIdx.y, h, 2, jobs);
+            make_jobs_one(R, (int)blockIdx.y, h, 2, jobs, from_cand, min_eig);
             if (skip) {
                 jobs[2 * blockIdx.y].info = R.skipword;
                 R.hs[h].cert_skipped++;
@@ -353,14 +383,20 @@ __global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *_
 
 // ---- factorisation jobs --------------------------------------------------------------------------
 // mode 2: certificate (W) + factor (F) per selected hypothesis; mode 1: factor only
-__device__ __forceinline__ void make_jobs_one(const Refs &R, int y, int h, int mode, ChJob *__restrict__ jobs)
+// from_cand: F / W have not been written - the factorisations read the trial point (T_S_CAND) on their first touch
+__device__ __forceinline__ void make_jobs_one(const Refs &R, int y, int h, int mode, ChJob *__restrict__ jobs,
+                                              int from_cand, double min_eig)
 {
     const size_t blk = (size_t)CH_NB * CH_NB;
+    const double *src = from_cand ? tabp(R, T_S_CAND, h) : nullptr;
     ChJob f;
     f.A = tabp(R, T_S_F, h);
     f.info = R.info + 2 * h + 1;
     f.linv = R.linvF + (size_t)h * R.nbk * blk;
     f.linv_keep = 1;
+    f.shifted = 0;
+    f.src = src;
+    f.eig = 0.;
     R.info[2 * h + 1] = 0;
     if (mode == 2) {
         ChJob w;
@@ -368,6 +404,9 @@ __device__ __forceinline__ void make_jobs_one(const Refs &R, int y, int h, int m
         w.info = R.info + 2 * h;
         w.linv = R.linvW + (size_t)h * blk;
         w.linv_keep = 0;
+        w.shifted = src ? 1 : 0;
+        w.src = src;
+        w.eig = min_eig;
         R.info[2 * h] = 0;
         jobs[2 * y] = w;
         jobs[2 * y + 1] = f;
@@ -889,6 +928,7 @@ __device__ __forceinline__ void decide_one(const Refs &R, int h, int mode, int f
         s.need_grad = 1;
         s.inv_ok = 0;
         s.bnd_ok = 0;
+        s.cur_sym = forced ? 0 : 1;      // a fast-path trial point is symmetric bit for bit (kb_trial_S)
         s.accepted = 1;
         if (s.status == ST_ACTIVE && s.max_steps >= 0 && s.steps >= s.max_steps) s.status = ST_PAUSED;
     } else {
@@ -1252,6 +1292,9 @@ __global__ __launch_bounds__(256) void lp_shift(const Refs R, const LpRefs L, co
         j.info = L.info + job;
         j.linv = L.linv + (size_t)job * L.nbk * CH_NB * CH_NB;
         j.linv_keep = 1;
+        j.shifted = 0;
+        j.src = nullptr;
+        j.eig = 0.;
         L.info[job] = idle ? -1 : 0;          // non-zero: the factorisation kernels pass over the job, the host over the rung
         L.jobs[q * nt + (t - t0)] = j;
     }
@@ -2481,6 +2524,7 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
         s.cert_skipped = 0;
         s.inv_ok = 0;
         s.bnd_ok = 0;
+        s.cur_sym = 0;
     }
     b->st_iters = b->st_trials = b->st_grads = b->st_slow_grad = 0;
     b->st_slow[0] = b->st_slow[1] = b->st_slow[2] = b->st_slow[3] = 0;
@@ -2520,6 +2564,8 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
     // independent, so the order in which they advance changes nothing.  APMF_BATCH_ASYNC=0: the
     // parked hypotheses are dealt with on the main stream instead (debugging).
     const bool use_lane = !(getenv("APMF_BATCH_ASYNC") && getenv("APMF_BATCH_ASYNC")[0] == '0');
+    const bool knob_cand = !(getenv("APMF_BATCH_FROM_CAND") && getenv("APMF_BATCH_FROM_CAND")[0] == '0');
+    const bool knob_sym = !(getenv("APMF_BATCH_SYM") && getenv("APMF_BATCH_SYM")[0] == '0');
     // APMF_BATCH_CERT=factor: every trial's certificate by its factorisation, never by the eigenvalue bound
     // (comparison runs: the results are the same bits either way)
     const double bound_eig = (getenv("APMF_BATCH_CERT") && !strcmp(getenv("APMF_BATCH_CERT"), "factor")) ? INFINITY : min_eig;
@@ -2620,9 +2666,15 @@ int apmf_mn_batch_fit(apmf_ctx *ctx, apmf_mn_batch *b, double sigma_sq, double s
             const int *dsel;
             APMF_TRY(upload_sel(b, 0, active, &dsel));
             const int nt32 = (R.N + 31) / 32;
-            APMF_LAUNCH(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig);
+            // many jobs: the factorisations go block column by block column and read the trial point where
+            // kb_trial_S wrote it (ChJob::src) - no copies into F / W
+            // (APMF_BATCH_FROM_CAND=0 / APMF_BATCH_SYM=0: the copies are made / the mirrored tiles are read
+            // regardless - comparison runs, the results are the same bits)
+            const int from_cand = (knob_cand && chol_route_by_column(2 * na)) ? 1 : 0;
+            APMF_LAUNCH(kb_trial_S, dim3(nt32 * (nt32 + 1) / 2, na), dim3(256), 0, st, R, dsel, min_eig, !from_cand,
+                               knob_sym ? 1 : 0);
             APMF_LAUNCH(kb_trial_small, dim3((unsigned)(((size_t)R.N * R.d + (size_t)R.d * R.d + 255) / 256), na),
-                               dim3(256), 0, st, R, dsel, R.jobs, nt32 * (nt32 + 1) / 2, bound_eig);
+                               dim3(256), 0, st, R, dsel, R.jobs, nt32 * (nt32 + 1) / 2, bound_eig, from_cand, min_eig);
             APMF_CHECK_LAUNCH();
             {
                 ChJobs J;

@@ -388,6 +388,47 @@ def test_batch_projection_by_eigenpairs_equals_full_decomposition(ctx, monkeypat
         assert np.linalg.eigvalsh(a[1]).min() >= 1e-5 * (1 - 1e-6)
 
 
+@pytest.mark.parametrize('shape,H,steps', [((70, 90, 4), 20, 14), ((94, 425, 5), 24, 5), ((21, 44, 3), 18, 30)])
+def test_batch_trial_point_routes_same_bits(ctx, monkeypatch, shape, H, steps):
+    """The trial point of a search step is written ONCE (kb_trial_S) and, when a launch factors many matrices, both of
+    its factorisations read it from there on their first touch of every tile (ChJob::src, csrc/chol.h) instead of
+    from copies F / W; and once the current point and the gradient are exactly symmetric - after the first accepted
+    step - the mirrored tiles are not read, (x + x) / 2 being x.  APMF_BATCH_FROM_CAND=0 / APMF_BATCH_SYM=0 switch the
+    two off: states, KL traces, step counts and learning rates are the same bits in all four combinations (N = 160,
+    519 and 65: tiles on, past and one short of a block edge)."""
+    n, m, d = shape
+    N = n + m
+    rs, ratings, mean, S, O = _problem(n, m, d, 5 * n + m, per_row=2)
+    S = np.eye(N) + 0.01 * S
+    ex = _unrated(rs, ratings, n, m, H)
+    rt = ctx.ratings(ratings, n, m)
+
+    def run(cand, sym):
+        monkeypatch.setenv('APMF_BATCH_FROM_CAND', cand)
+        monkeypatch.setenv('APMF_BATCH_SYM', sym)
+        b = ctx.mn_batch(rt, d, H, trace_cap=64)
+        b.set_state(ctx.array(mean), ctx.array(S), ctx.array(np.eye(d)))
+        b.set_extra([e[0] for e in ex], [e[1] for e in ex], [[1., 5., 3., 2.][q % 4] for q in range(H)])
+        lr, kl, nsteps, conv, trace = b.fit(1., 10., 10., 1e-5, 1e-4, max_steps=steps)
+        out = [lr.copy(), kl.copy(), nsteps.copy(), trace.copy()]
+        dm, ds, do = ctx.empty((N, d)), ctx.empty((N, N)), ctx.empty((d, d))
+        for q in (0, H // 2, H - 1):
+            b.get_state(q, dm, ds, do)
+            out += [dm.to_host(), ds.to_host(), do.to_host()]
+        st = b.fit_stats()
+        b.free()
+        return out, st
+
+    ref, st0 = run('1', '1')
+    assert int(ref[2].min()) >= 2                       # accepted steps: the symmetric path was taken
+    assert np.array_equal(ref[5], ref[5].T)             # the state it leaves is symmetric bit for bit
+    for cand, sym in (('0', '1'), ('1', '0'), ('0', '0')):
+        got, st = run(cand, sym)
+        assert st['trials'] == st0['trials']
+        for x, y in zip(ref, got):
+            assert np.array_equal(x, y, equal_nan=True), (cand, sym)      # (trace slots beyond the steps taken: poison)
+
+
 def test_batch_certificate_by_eigenvalue_bound_same_bits(ctx, monkeypatch):
     """A trial point needs project_psd's eigh only to learn that nothing is clipped; the batched fit certifies
     that by factoring cand - (min_eig + delta) I - or, when the step is short, by
