@@ -109,6 +109,7 @@ def main():
     ap.add_argument('--c5-ratings', type=int, default=50000000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-class-level', action='store_true')
+    ap.add_argument('--no-grad-batch', action='store_true', help='skip the batched PMF re-fit leg')
     ap.add_argument('--no-f64', action='store_true', help='skip the float64 sweep legs (roofline_f64)')
     ap.add_argument('--no-gibbs', action='store_true', help='skip the configs[2] Gibbs / sample-statistics leg')
     ap.add_argument('--no-lookahead', action='store_true', help='skip the configs[3] batched-lookahead leg')
@@ -317,6 +318,9 @@ def main():
                            'algorithmic_GBs': gs_bytes * grad_steps_per_s / (1 if strong else world) / 1e9,
                            'workload': grad_note},
         }
+    if world == 1 and not args.no_grad_batch:
+        print('bench.py: batched PMF re-fits ...', file=sys.stderr, flush=True)
+        out['grad_steps']['batched'] = grad_steps_batched(ctx, ratings, rated_mask, U0, V0, min(K, 40))
     if world == 1 and not args.no_f64:
         # the product's precision on the same workload (every class computes in float64)
         print('bench.py: float64 sweep legs ...', file=sys.stderr, flush=True)
@@ -443,6 +447,40 @@ def bench_c5(args, ctx, comm, rank, world):
                            'ms_per_grad_step': 1e3 * t_grad / max(tr.size, 1), 'grad_steps_timed': int(tr.size),
                            'algorithmic_GBs': gs_bytes * tr.size / t_grad / 1e9,
                            'workload': 'ONE fit_lls row-sharded over %d rank(s): one grouped all-gather per trial' % world}}
+
+
+def grad_steps_batched(ctx, ratings, mask, U0, V0, steps, H=64):
+    """The PMF half of the metric as the package runs it when MANY re-fits are due at once (the MAP re-fits of a
+    lookahead with refit_lookahead, mn_active_pmf.py:660-665; exp_variance(fit_first), bayes_pmf.py:457-468; the per-key
+    models of compare()): H independent fit_lls searches - the 943 x 1682 rank-10 model on the N = 100 000 ratings, each
+    with ONE extra rating - advanced together by apmf_pmf_batch_fit_lls (one chain of launches, per-hypothesis
+    accept / reject on the device, bit-identical to H separate fits).  A single search is a dependent chain of 13 us
+    launches (grad_steps.value: latency-bound, 0.14 of the HBM roof); H of them per launch stream at the roof."""
+    n, m, d = N_USERS, N_ITEMS, LATENT_D
+    rt = ctx.ratings(ratings, n, m)
+    free_i, free_j = np.nonzero(~mask)
+    pick = np.linspace(0, free_i.size - 1, H).astype(np.int64)
+    ei, ej = free_i[pick].astype(np.int32), free_j[pick].astype(np.int32)
+    ev = (1. + np.arange(H) % 5).astype(np.float64)
+
+    def run(nsteps):
+        dU = ctx.array(np.broadcast_to(U0, (H,) + U0.shape).copy())
+        dV = ctx.array(np.broadcast_to(V0, (H,) + V0.shape).copy())
+        ctx.sync()
+        t0 = time.perf_counter()
+        _, st, _ = ctx.pmf_batch_fit_lls(rt, dU, dV, d, H, ei, ej, ev, 1., 10., 10., False, None, 1e-4, 1e-10, 0.,
+                                         max_steps=nsteps)
+        ctx.sync()
+        return time.perf_counter() - t0, int(st.sum())
+    run(3)
+    dt, done = run(max(steps, 5))
+    gs_bytes = N_RATINGS * (12 + 16 * d) + N_RATINGS * (12 + 8 * d) + 16 * (n + m) * d
+    rate = done / dt
+    return {'value': rate, 'unit': 'PMF grad-steps/s', 'dtype': 'f64', 'concurrent_fits': H,
+            'accepted_steps_timed': done, 'seconds': dt, 'us_per_grad_step': 1e6 * dt / max(done, 1),
+            'algorithmic_GBs': gs_bytes * rate / 1e9, 'frac_of_hbm_peak': gs_bytes * rate / 1e9 / HBM_PEAK_GBS,
+            'workload': '%d concurrent fit_lls searches (N=100000 ratings + one hypothesised rating each), '
+                        'apmf_pmf_batch_fit_lls' % H}
 
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X float64 matrix peak (vendor figure; the guide lists none for f64)
