@@ -10,7 +10,7 @@ from active_matrix_factorization_amd import _lib
 
 n, m, d = 943, 1682, 10
 B = int(os.environ.get('B', 256))
-ld = _lib.grid_ld(m)
+ld = int(os.environ.get("LD", _lib.grid_ld(m)))
 ctx = _lib.Context(0)
 rs = np.random.RandomState(0)
 mean = ctx.array(rs.normal(size=(B, n + m, d)), np.float32)
