@@ -31,7 +31,8 @@ constexpr int CH_FUSE_JOBS = 32;   // up to this many matrices per launch: updat
 namespace {   // one private copy of the kernels per translation unit that includes this header
 
 struct ChJob {
-    double *A;      // N x N row-major, factored in place (lower triangle)
+    double *A;      // N x N row-major, factored in place (lower triangle); NULL: the job is not to run - its blocks
+                    // leave at once (a non-zero info word says the same, but only after the tile loads are in flight)
     int *info;      // 0, or 1-based index of the first non-positive pivot (must be zeroed first;
                     // a non-zero value on entry skips the job)
     double *linv;   // inverse of the diagonal block of the current panel: CH_NB^2 doubles ...
@@ -342,6 +343,7 @@ __device__ __forceinline__ int diag_factor_invert(double (*T)[TP], double (*X)[T
 __global__ __launch_bounds__(256) void k_chol_diag(const ChJobs J, int N, int k)
 {
     const ChJob job = ch_job(J, blockIdx.y);
+    if (!job.A) return;              // a job that is not to run (ChJob::A): nothing is requested for it
     double *__restrict__ A = job.A;
     int *__restrict__ info = job.info;
     double *__restrict__ linv = ch_linv(job, k);
@@ -381,6 +383,7 @@ __global__ __launch_bounds__(256) void k_chol_panel(const ChJobs J, int N, int k
     int bx, by;
     xcd_tile_job(bx, by);
     const ChJob job = ch_job(J, by);
+    if (!job.A) return;              // a job that is not to run (ChJob::A): nothing is requested for it
     double *__restrict__ A = job.A;
     const double *__restrict__ linv = ch_linv(job, k);
     __shared__ double P[CH_NB][TP], X[CH_NB][TP];
@@ -478,6 +481,7 @@ __global__ __launch_bounds__(256) void k_chol_update(const ChJobs J, int N, int 
     int bx, by;
     xcd_tile_job(bx, by);
     const ChJob job = ch_job(J, by);
+    if (!job.A) return;              // a job that is not to run (ChJob::A): nothing is requested for it
     double *__restrict__ A = job.A;
     // the panel is staged 32 columns at a time: 35 KB of LDS per block -> 4 blocks (16 waves) per CU
     // instead of 2; this kernel is latency-bound (PMC: ~1.7 TB/s of HBM traffic), occupancy is what helps
@@ -568,6 +572,7 @@ __global__ __launch_bounds__(256) void k_chol_col(const ChJobs J, int N, int jb)
     int bx, by;
     xcd_tile_job(bx, by);
     const ChJob job = ch_job(J, by);
+    if (!job.A) return;              // a job that is not to run (ChJob::A): nothing is requested for it
     double *__restrict__ A = job.A;
     constexpr int KS = 32, KP = KS + 2;
     __shared__ double stat_lds[2 * 64 * KP];

@@ -363,6 +363,7 @@ __global__ __launch_bounds__(256) void kb_trial_small(const Refs R, const int *_
             make_jobs_one(R, (int)blockIdx.y, h, 2, jobs, from_cand, min_eig);
             if (skip) {
                 jobs[2 * blockIdx.y].info = R.skipword;
+                jobs[2 * blockIdx.y].A = nullptr;        // its blocks leave before they request anything
                 R.hs[h].cert_skipped++;
             }
         }
@@ -1288,7 +1289,7 @@ __global__ __launch_bounds__(256) void lp_shift(const Refs R, const LpRefs L, co
     const bool idle = !local && t >= 2 && lp_shift_of(L, y, t - 1, 0., min_eig, 0) < L.slb[y];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ChJob j;
-        j.A = D;
+        j.A = idle ? nullptr : D;             // (an idle rung's blocks leave before they request anything)
         j.info = L.info + job;
         j.linv = L.linv + (size_t)job * L.nbk * CH_NB * CH_NB;
         j.linv_keep = 1;
