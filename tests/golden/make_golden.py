@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a': section AD (round 4)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -188,6 +188,9 @@ def main():
         return
     if args.only == 'r3i':
         one_thread(round3i, np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r4a':
+        one_thread(round4a, np, active_pmf, nx, save, seed, _print)
         return
     if args.only == 'r3b':
         one_thread(round3b, np, mn_active_pmf, save, seed, _print)
@@ -1292,6 +1295,53 @@ def round3i(np, mn_active_pmf, save, seed, _print):
         est.append((evals * np.diff(cdfs)).sum())
     save('lookahead_c4_pool_converged', pool=np.array(pool), steps=steps, final_kl=np.array([r[0][-1] for r in got]),
          tv=tv, vals=np.array(est), order=np.argsort(est, kind='stable'))
+
+
+def round4a(np, active_pmf, nx, save, seed, _print):
+    """AD. The FULL-covariance class at BASELINE.json configs[3]'s shape (DrugBank 94 x 425, rank 5: the approximation
+    is N(mean, cov) over K = (94 + 425) 5 = 2595 numbers; sections C / AA hold it at K <= 256 only): the known entries of
+    section G, do_fit, initialize_approx under a seed (project_psd of a K x K normal draw: 54 MB, so only its diagonal
+    and 4000 sampled entries are kept - the test regenerates the draw from the seed), the KL there, the scoring grid of
+    approx_pred_means_vars over all 39 950 entries and the pick over the unrated ones (normal_exps_cy.exp_dotprod_sq,
+    normal_exps_cy.pyx:111-135), the KL gradient (normal_exps_cy.pyx:140-303: mean part whole, covariance part
+    diagonal + samples) and two accepted fit_normal_kls steps (active_pmf.py:250-288)."""
+    t0 = time.perf_counter()
+    g = np.load(os.path.join(HERE, 'mn_c4_94x425_d5.npz'))
+    ratings = g['ratings']
+    A = active_pmf.ActivePMF
+    seed(81)
+    a = A(ratings.copy(), latent_d=5)
+    a.do_fit()
+    seed(82)
+    a.initialize_approx()
+    K = a.approx_dim
+    rs = np.random.RandomState(83)
+    si, sj = rs.randint(0, K, 4000), rs.randint(0, K, 4000)
+    out = dict(ratings=ratings, d=5, users=a.users.copy(), items=a.items.copy(), seed_fit=81, seed_init=82, K=K,
+               sigma=np.array([a.sigma_sq, a.sigma_u_sq, a.sigma_v_sq]), samp_i=si, samp_j=sj,
+               mean0=a.mean.copy(), cov_diag0=np.diag(a.cov).copy(), cov_samp0=a.cov[si, sj].copy(),
+               cov_min_eig0=float(np.linalg.eigvalsh(a.cov).min()))
+    _print('full c4: initialised, %.0f s' % (time.perf_counter() - t0))
+    out['kl0'] = a.kl_divergence()
+    pm, pv = a.approx_pred_means_vars()
+    out.update(p_mean0=pm, p_var0=pv, pick0=np.array(a.pick_query_point(key=A.pred_variance)),
+               total_variance0=a._total_variance())
+    _print('full c4: scored, %.0f s' % (time.perf_counter() - t0))
+    g_mean, g_cov = nx.normal_gradient(a)
+    out.update(g_mean=g_mean, g_cov_diag=np.diag(g_cov).copy(), g_cov_samp=g_cov[si, sj].copy())
+    _print('full c4: gradient, %.0f s' % (time.perf_counter() - t0))
+    kls = []
+    for k, kl in enumerate(a.fit_normal_kls()):
+        kls.append(kl)
+        _print('full c4: step %d kl %.6f, %.0f s' % (k, kl, time.perf_counter() - t0))
+        if k >= 1:
+            break
+    pm, pv = a.approx_pred_means_vars()
+    out.update(kl_trace=np.array(kls), mean_fit=a.mean.copy(), cov_diag_fit=np.diag(a.cov).copy(),
+               cov_samp_fit=a.cov[si, sj].copy(), p_mean_fit=pm, p_var_fit=pv,
+               pick_fit=np.array(a.pick_query_point(key=A.pred_variance)))
+    save('full_c4_94x425_d5', **out)
+    _print('full covariance at configs[3]: %.0f s' % (time.perf_counter() - t0))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

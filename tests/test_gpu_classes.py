@@ -695,6 +695,54 @@ def test_full_variational_fit(pkg, name):
     assert all(x > y for x, y in zip(rest, rest[1:]))
 
 
+def test_full_class_configs3_shape_golden(pkg):
+    """The FULL-covariance class at BASELINE.json configs[3]'s shape (DrugBank 94 x 425, rank 5: K = 2595, a 54 MB
+    covariance - sections C / AA of the generator hold K <= 256): the reference's whole start of a run, under its seeds.
+    Constructor + do_fit (seed 81: the MAP factors), initialize_approx (seed 82: project_psd of a K x K normal draw,
+    half of whose eigenvalues are clipped - on the device an eigendecomposition of 2595^2), then against the recorded
+    values: the projected covariance (diagonal + 4000 sampled entries), the KL there, approx_pred_means_vars over all
+    39 950 entries (normal_exps_cy.exp_dotprod_sq per entry in the reference; one K2-full sweep here), the pick over the
+    unrated ones EXACTLY, the KL gradient (normal_exps_cy.pyx:140-303) and two accepted fit_normal_kls steps
+    (active_pmf.py:250-288; their trial points are projected again: eigenvalues from 1e-5 to 150)."""
+    g = load_golden('full_c4_94x425_d5')
+    A = pkg.full.ActivePMF
+    seed(int(g['seed_fit']))
+    a = A(g['ratings'].copy(), latent_d=int(g['d']))
+    a.do_fit()
+    np.testing.assert_allclose(a.users, g['users'], rtol=3e-7, atol=1e-9)      # (measured 1e-9: a search to convergence)
+    np.testing.assert_allclose(a.items, g['items'], rtol=3e-7, atol=1e-9)
+    a.users, a.items = g['users'].copy(), g['items'].copy()          # (the comparisons below start from the same bits)
+    seed(int(g['seed_init']))
+    a.initialize_approx()
+    K = int(g['K'])
+    si, sj = g['samp_i'], g['samp_j']
+    assert a.cov.shape == (K, K)
+    scale = np.abs(g['cov_diag0']).max()
+    np.testing.assert_array_equal(a.mean, g['mean0'])
+    np.testing.assert_allclose(np.diag(a.cov), g['cov_diag0'], rtol=0, atol=1e-12 * scale)      # measured 3e-15
+    np.testing.assert_allclose(a.cov[si, sj], g['cov_samp0'], rtol=0, atol=1e-12 * scale)
+    assert abs(a.kl_divergence() - float(g['kl0'])) <= 1e-11 * abs(float(g['kl0']))
+    pm, pv = a.approx_pred_means_vars()
+    np.testing.assert_allclose(pm, g['p_mean0'], rtol=0, atol=1e-12 * np.abs(g['p_mean0']).max())   # measured 1e-14
+    np.testing.assert_allclose(pv, g['p_var0'], rtol=1e-12, atol=1e-13 * np.abs(g['p_var0']).max())   # measured 2e-15
+    assert tuple(a.pick_query_point(key=A.pred_variance)) == tuple(g['pick0'])
+    assert abs(a._total_variance() - float(g['total_variance0'])) <= 1e-9 * float(g['total_variance0'])
+    gm, gc = pkg.full.normal_gradient(a)
+    np.testing.assert_allclose(gm, g['g_mean'], rtol=1e-9, atol=1e-10 * np.abs(g['g_mean']).max())    # measured 4e-12
+    gscale = np.abs(g['g_cov_diag']).max()
+    # (the covariance part carries cov^-1 of a matrix of condition 1.5e7: 4e-9 of the largest entry measured)
+    np.testing.assert_allclose(np.diag(gc), g['g_cov_diag'], rtol=0, atol=3e-7 * gscale)
+    np.testing.assert_allclose(gc[si, sj], g['g_cov_samp'], rtol=0, atol=3e-7 * gscale)
+    kls = list(islice(a.fit_normal_kls(), g['kl_trace'].size))
+    np.testing.assert_allclose(kls, g['kl_trace'], rtol=1e-11)               # measured 8e-14
+    np.testing.assert_allclose(a.mean, g['mean_fit'], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.diag(a.cov), g['cov_diag_fit'], rtol=0, atol=1e-9 * scale)    # measured 1e-11
+    np.testing.assert_allclose(a.cov[si, sj], g['cov_samp_fit'], rtol=0, atol=1e-9 * scale)
+    pm, pv = a.approx_pred_means_vars()
+    np.testing.assert_allclose(pv, g['p_var_fit'], rtol=1e-9, atol=1e-11 * np.abs(g['p_var_fit']).max())   # measured 8e-12
+    assert tuple(a.pick_query_point(key=A.pred_variance)) == tuple(g['pick_fit'])
+
+
 def test_mn_lookahead_golden(pkg):
     """One-step lookahead criteria of the reference (mn_active_pmf.py:600-696) on config 1:
     deepcopy + add_rating + fit_normal (to convergence) + sweep per rating value."""

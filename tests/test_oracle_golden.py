@@ -159,6 +159,37 @@ def test_full_grids(name):
     assert pick == tuple(g['pick_max'])
 
 
+def test_full_grid_configs3_shape():
+    """The full-covariance scoring at BASELINE.json configs[3]'s shape (K = 2595; fixture section AD): the 54 MB
+    covariance is not stored - it is rebuilt here the way the reference built it (seeded K x K normal draw, symmetrised,
+    eigenvalues clipped at 1e-5: active_pmf.py:190-200, mn_active_pmf.py:42-67), checked against the recorded diagonal
+    and samples, and the oracle's approx_pred_means_vars over all 39 950 entries compared with the reference's."""
+    import random
+    g = load_golden('full_c4_94x425_d5')
+    K, d = int(g['K']), int(g['d'])
+    np.random.seed(int(g['seed_init']))
+    random.seed(int(g['seed_init']))
+    s = np.random.normal(0, 2, (K, K))
+    s += s.T
+    s /= 2
+    vals, vecs = np.linalg.eigh(s)
+    cov = vecs @ np.diag(np.maximum(vals, 1e-5)) @ vecs.T
+    cov += cov.T
+    cov /= 2
+    scale = np.abs(g['cov_diag0']).max()
+    assert np.abs(np.diag(cov) - g['cov_diag0']).max() <= 1e-10 * scale
+    assert np.abs(cov[g['samp_i'], g['samp_j']] - g['cov_samp0']).max() <= 1e-10 * scale
+    n, m = g['p_mean0'].shape
+    pm, pv, e2 = orc.full_pred_means_vars(n, m, d, g['mean0'], cov, want_e2=True)
+    # (cov is the rebuilt one: its eigenvectors differ from the reference's LAPACK build in the last places)
+    assert np.all(np.abs(pm - g['p_mean0']) <= 1e-9 * (np.abs(g['p_mean0']) + 1))
+    assert np.all(np.abs(pv - g['p_var0']) <= 1e-9 * np.abs(e2))
+    unrated = np.ones((n, m), bool)
+    unrated[g['ratings'][:, 0].astype(int), g['ratings'][:, 1].astype(int)] = False
+    best = np.unravel_index(np.argmax(np.where(unrated, pv, -np.inf)), pv.shape)
+    assert tuple(int(x) for x in best) == tuple(g['pick0'])
+
+
 BAYES_CASES = ['bayes_20x15_d4', 'bayes_c1_10x10_d2', 'bayes_100x90_d15']
 
 
