@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a': section AD (round 4)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a', 'r4b': sections AD, AE (round 4)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -191,6 +191,9 @@ def main():
         return
     if args.only == 'r4a':
         one_thread(round4a, np, active_pmf, nx, save, seed, _print)
+        return
+    if args.only == 'r4b':
+        one_thread(round4b, np, pmf_cy, bayes_pmf, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r3b':
         one_thread(round3b, np, mn_active_pmf, save, seed, _print)
@@ -1342,6 +1345,68 @@ def round4a(np, active_pmf, nx, save, seed, _print):
                pick_fit=np.array(a.pick_query_point(key=A.pred_variance)))
     save('full_c4_94x425_d5', **out)
     _print('full covariance at configs[3]: %.0f s' % (time.perf_counter() - t0))
+
+
+def round4b(np, pmf_cy, bayes_pmf, mn_active_pmf, save, seed, _print):
+    """AE. BASELINE.json configs[1] and configs[2] on the data set they NAME: the reference's own
+    movielens-100k/ratings_matrix.npy.gz (943 x 1682 int8, 100 000 ratings; sections K, Z, AC and I use a synthetic matrix
+    of that shape).  The matrix is kept as data (`ml100k_real`, 124 KB); ratings = its non-zeros in row-major order.
+    PMF, rank 10, subtract_mean: the constructor's factors under seed 91, gradient and log-likelihood there, the first 20
+    accepted fit_lls steps (pmf_cy.pyx:257-291), the closed-form variance updates.  BayesianPMF, rank 15, subtract_mean: two
+    seeded samples() yields (bayes_pmf.py:227-302), pred_variance / predict over them and the arg-max pick.
+    MNActivePMF, rank 10: the KL at initialize_approx() and the scoring of the full grid there + the pick."""
+    import gzip
+    from itertools import islice
+    t0 = time.perf_counter()
+    with gzip.open(os.path.join(REF, 'movielens-100k', 'ratings_matrix.npy.gz')) as f:
+        real = np.load(f)
+    n, m = real.shape
+    ii, jj = real.nonzero()
+    ratings = np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+    save('ml100k_real', real=real.astype(np.int8))
+    # ---- PMF (configs[1])
+    seed(91)
+    p = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10, subtract_mean=True)
+    U0, V0 = p.users.copy(), p.items.copy()
+    gU, gV = p.gradient()
+    ll0 = p.log_likelihood()
+    rows_u, rows_v = np.arange(0, n, 31), np.arange(0, m, 47)
+    lls = list(islice(p.fit_lls(), 20))
+    out = dict(seed_ctor=91, d=10, N=ratings.shape[0], mean_rating=p.mean_rating, U0_sum=U0.sum(), V0_sum=V0.sum(),
+               gU=gU, gV=gV, ll0=ll0, ll_trace=np.array(lls), learning_rate=p.learning_rate,
+               rows_u=rows_u, rows_v=rows_v, U_rows=p.users[rows_u].copy(), V_rows=p.items[rows_v].copy(),
+               U_sum=p.users.sum(), V_sum=p.items.sum(), rmse=float(p.rmse(real.astype(float))))
+    p.update_sigma()
+    p.update_sigma_uv()
+    out.update(sigma_after=np.array([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq]))
+    save('ml100k_pmf_d10', **out)
+    _print('ml100k PMF: %.0f s' % (time.perf_counter() - t0))
+    # ---- BayesianPMF (configs[2])
+    seed(92)
+    b = bayes_pmf.BayesianPMF(ratings.copy(), latent_d=15, subtract_mean=True)
+    seed(93)
+    samps = list(islice(b.samples(), 2))
+    pv, pr = b.pred_variance(samps), b.predict(samps)
+    pi, pj = np.arange(0, n, 41), np.arange(0, m, 67)
+    save('ml100k_bayes_d15', seed_ctor=92, seed_chain=93, d=15, U0_sum=b.users.sum(), V0_sum=b.items.sum(),
+         rows_u=rows_u, rows_v=rows_v,
+         chain_U_rows=np.array([u[rows_u] for u, v in samps]), chain_V_rows=np.array([v[rows_v] for u, v in samps]),
+         chain_U_sum=np.array([u.sum() for u, v in samps]), chain_V_sum=np.array([v.sum() for u, v in samps]),
+         pi=pi, pj=pj, pred_variance_sub=pv[np.ix_(pi, pj)], predict_sub=pr[np.ix_(pi, pj)],
+         pred_variance_sum=pv.sum(), pick_argmax=np.array(np.unravel_index(np.argmax(pv), pv.shape)))
+    _print('ml100k Bayes: %.0f s' % (time.perf_counter() - t0))
+    # ---- MNActivePMF scoring on the real data: the metric's kernel fed by a model of the real ratings
+    seed(94)
+    a = mn_active_pmf.MNActivePMF(ratings.copy(), latent_d=10)
+    for _ in islice(a.fit_lls(), 15):
+        pass
+    a.initialize_approx()
+    pm, pv = a.approx_pred_means_vars()
+    save('ml100k_mn_d10', seed_ctor=94, d=10, fit_steps=15, users_sum=a.users.sum(), items_sum=a.items.sum(),
+         rows_u=rows_u, users_rows=a.users[rows_u].copy(), kl0=a.kl_divergence(),
+         p_mean_rows=pm[rows_u].copy(), p_var_rows=pv[rows_u].copy(), p_var_sum=pv.sum(), p_mean_sum=pm.sum(),
+         pick0=np.array(a.pick_query_point(key=mn_active_pmf.MNActivePMF.pred_variance)))
+    _print('ml100k MN: %.0f s' % (time.perf_counter() - t0))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

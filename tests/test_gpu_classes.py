@@ -1750,6 +1750,88 @@ def test_configs2_gibbs_golden(pkg):
     assert tuple(np.unravel_index(np.argmax(pv), pv.shape)) == tuple(g['pick_argmax'])
 
 
+def _ml100k_ratings():
+    real = load_golden('ml100k_real')['real']
+    ii, jj = real.nonzero()
+    return real, np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+
+
+def test_movielens_100k_pmf_golden(pkg):
+    """BASELINE.json configs[1] on the data set it names - the reference's own MovieLens-100k matrix (943 x 1682, all
+    100 000 ratings; make_golden.py section AE), rank 10, subtract_mean - from the reference's constructor under its seed:
+    starting factors, gradient and log-likelihood there (K1), the first 20 accepted fit_lls steps (the one-launch search:
+    the reference's log-likelihood trace, i.e. its accept / reject sequence), the fitted rows, and the closed-form variance
+    updates on the fitted state (pmf_cy.pyx:225-255)."""
+    g = load_golden('ml100k_pmf_d10')
+    real, ratings = _ml100k_ratings()
+    assert ratings.shape[0] == int(g['N']) == 100000
+    seed(int(g['seed_ctor']))
+    p = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=int(g["d"]), subtract_mean=True)
+    assert abs(p.users.sum() - g['U0_sum']) <= 1e-12 * abs(g['U0_sum'])
+    assert abs(p.items.sum() - g['V0_sum']) <= 1e-12 * abs(g['V0_sum'])
+    assert p.mean_rating == float(g['mean_rating'])
+    gU, gV = p.gradient()
+    np.testing.assert_allclose(gU, g['gU'], rtol=1e-12, atol=1e-13 * np.abs(g['gU']).max())      # measured 2e-15
+    np.testing.assert_allclose(gV, g['gV'], rtol=1e-12, atol=1e-13 * np.abs(g['gV']).max())
+    assert abs(p.log_likelihood() - float(g['ll0'])) <= 1e-12 * abs(float(g['ll0']))
+    lls = list(islice(p.fit_lls(), g['ll_trace'].size))
+    np.testing.assert_allclose(lls, g['ll_trace'], rtol=1e-12)                                    # measured 2e-14
+    np.testing.assert_allclose(p.users[g['rows_u']], g['U_rows'], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(p.items[g['rows_v']], g['V_rows'], rtol=1e-10, atol=1e-12)
+    assert abs(p.users.sum() - g['U_sum']) <= 1e-9 * abs(g['U_sum'])
+    assert p.rmse(real.astype(float)) == pytest.approx(float(g['rmse']), rel=1e-6)       # (a C float in the reference)
+    p.update_sigma()
+    p.update_sigma_uv()
+    np.testing.assert_allclose([p.sigma_sq, p.sigma_u_sq, p.sigma_v_sq], g['sigma_after'], rtol=1e-12)
+
+
+def test_movielens_100k_bayes_golden(pkg):
+    """BASELINE.json configs[2] on the real MovieLens-100k matrix: rank-15 BayesianPMF with subtract_mean, two seeded
+    samples() yields (Gaussian-Wishart hyper-parameters and N(0, 1) draws in the reference's order, the 2 x 2625 row
+    updates on K3), pred_variance / predict over them (K4) and the arg-max pick (bayes_pmf.py:227-302, 433-448, 702-713)."""
+    g = load_golden('ml100k_bayes_d15')
+    _, ratings = _ml100k_ratings()
+    seed(int(g['seed_ctor']))
+    b = pkg.bayes.BayesianPMF(ratings.copy(), latent_d=int(g['d']), subtract_mean=True)
+    assert abs(b.users.sum() - g['U0_sum']) <= 1e-12 * abs(g['U0_sum'])
+    seed(int(g['seed_chain']))
+    samps = list(islice(b.samples(), g['chain_U_sum'].size))
+    ru, rv = g['rows_u'], g['rows_v']
+    np.testing.assert_allclose([u[ru] for u, v in samps], g['chain_U_rows'], rtol=5e-10, atol=1e-12)      # measured 5e-12
+    np.testing.assert_allclose([v[rv] for u, v in samps], g['chain_V_rows'], rtol=5e-10, atol=1e-12)
+    np.testing.assert_allclose([u.sum() for u, v in samps], g['chain_U_sum'], rtol=1e-12)
+    np.testing.assert_allclose([v.sum() for u, v in samps], g['chain_V_sum'], rtol=1e-12)
+    pv, pr = b.pred_variance(samps), b.predict(samps)
+    sub = np.ix_(g['pi'], g['pj'])
+    np.testing.assert_allclose(pv[sub], g['pred_variance_sub'], rtol=3e-10, atol=1e-12)     # measured 3e-12
+    np.testing.assert_allclose(pr[sub], g['predict_sub'], rtol=1e-12, atol=1e-12)
+    assert abs(pv.sum() - g['pred_variance_sum']) <= 1e-8 * abs(g['pred_variance_sum'])
+    assert tuple(np.unravel_index(np.argmax(pv), pv.shape)) == tuple(g['pick_argmax'])
+
+
+def test_movielens_100k_mn_scoring_golden(pkg):
+    """The metric's kernel fed by a model of the REAL ratings: MNActivePMF at rank 10 on MovieLens-100k - 15 fit_lls steps
+    from the seeded constructor, initialize_approx(), the KL there (K5 / K6), approx_pred_means_vars over all 1 586 126
+    entries (K2, float64) and the reference's pick over the 1 486 126 unrated ones, exactly."""
+    g = load_golden('ml100k_mn_d10')
+    _, ratings = _ml100k_ratings()
+    MN = pkg.mn.MNActivePMF
+    seed(int(g['seed_ctor']))
+    a = MN(ratings.copy(), latent_d=int(g['d']))
+    for _ in islice(a.fit_lls(), int(g['fit_steps'])):
+        pass
+    assert abs(a.users.sum() - g['users_sum']) <= 1e-9 * abs(g['users_sum'])
+    np.testing.assert_allclose(a.users[g['rows_u']], g['users_rows'], rtol=1e-12, atol=1e-13)
+    a.initialize_approx()
+    assert abs(a.kl_divergence() - float(g['kl0'])) <= 1e-10 * abs(float(g['kl0']))
+    pm, pv = a.approx_pred_means_vars()
+    scale = np.abs(g['p_var_rows']).max()
+    np.testing.assert_allclose(pv[g['rows_u']], g['p_var_rows'], rtol=1e-12, atol=1e-13 * scale)     # measured 2e-15
+    np.testing.assert_allclose(pm[g['rows_u']], g['p_mean_rows'], rtol=1e-12, atol=1e-12)
+    assert abs(pv.sum() - g['p_var_sum']) <= 1e-9 * abs(g['p_var_sum'])
+    assert tuple(a.pick_query_point(key=MN.pred_variance)) == tuple(int(x) for x in g['pick0'])
+
+
 def test_ratings_container_from_dense(pkg):
     """apmf_ratings_create_dense (device build from the dense matrix + known mask) == the container
     built from the list make_ratings() writes (choose_training.py:13-17): K1 gradient / LL and a K3

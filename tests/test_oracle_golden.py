@@ -159,6 +159,28 @@ def test_full_grids(name):
     assert pick == tuple(g['pick_max'])
 
 
+def test_movielens_100k_pmf():
+    """The oracle's K1 restatement on the REAL MovieLens-100k matrix (fixture section AE: the reference's constructor
+    under seed 91, rank 10, subtract_mean): gradient and log-likelihood at the seeded start."""
+    import random
+    g = load_golden('ml100k_pmf_d10')
+    real = load_golden('ml100k_real')['real']
+    ii, jj = real.nonzero()
+    ratings = np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+    n, m = real.shape
+    d = int(g['d'])
+    np.random.seed(int(g['seed_ctor']))
+    random.seed(int(g['seed_ctor']))
+    U0, V0 = np.random.random((n, d)), np.random.random((m, d))          # pmf_cy.pyx:74-75
+    assert abs(U0.sum() - g['U0_sum']) <= 1e-12 * abs(g['U0_sum'])
+    kw = dict(subtract_mean=True, mean_rating=float(g['mean_rating']))
+    gU, gV = orc.pmf_gradient(ratings, U0, V0, **kw)
+    np.testing.assert_allclose(gU, g['gU'], rtol=1e-12, atol=1e-13 * np.abs(g['gU']).max())
+    np.testing.assert_allclose(gV, g['gV'], rtol=1e-12, atol=1e-13 * np.abs(g['gV']).max())
+    ll = orc.pmf_log_likelihood(ratings, U0, V0, **kw)
+    assert abs(ll - float(g['ll0'])) <= 1e-12 * abs(float(g['ll0']))
+
+
 def test_full_grid_configs3_shape():
     """The full-covariance scoring at BASELINE.json configs[3]'s shape (K = 2595; fixture section AD): the 54 MB
     covariance is not stored - it is rebuilt here the way the reference built it (seeded K x K normal draw, symmetrised,
