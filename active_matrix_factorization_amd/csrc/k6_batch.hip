@@ -1243,7 +1243,25 @@ __global__ __launch_bounds__(256) void lp_norms(const Refs R, const LpRefs L, co
         for (int i = lane; i < nstep; i += 64) b += R.stepp[(size_t)h * nstep + i];
         a = wave_sum(a);
         b = wave_sum(b);
-        if (lane == 0) L.slb[y] = (use_bound && R.hs[h].inv_ok && a > 0.) ? .99 / sqrt(a) - 1.01 * sqrt(b) : -INFINITY;
+        double lb = (use_bound && R.hs[h].inv_ok && a > 0.) ? .99 / sqrt(a) - 1.01 * sqrt(b) : -INFINITY;
+        // ... or the structured bound of cert_by_bound (entropy term by AM-GM, rating part by its diagonal + Frobenius
+        // norm), which here may well be negative: it is within a factor ~2 of the smallest eigenvalue where the plain
+        // one is far below it, and prunes more rungs
+        if (use_bound && R.hs[h].bnd_ok && R.hs[h].lr > 0.) {
+            const int nfr = (N + 255) / 256;
+            double qmax = -INFINITY, c2 = 0.;
+            for (int i = lane; i < nfr; i += 64) {
+                qmax = fmax(qmax, R.bndp[((size_t)h * nfr + i) * 2]);
+                c2 += R.bndp[((size_t)h * nfr + i) * 2 + 1];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) qmax = fmax(qmax, __shfl_xor(qmax, o, 64));
+            c2 = wave_sum(c2);
+            const double lr = R.hs[h].lr, c = lr * R.d / 2.;
+            const double lb1 = .99 * 2. * sqrt(2. * c) - 1.01 * lr * (fmax(qmax, 0.) + sqrt(c2));
+            if (lb1 == lb1) lb = fmax(lb, lb1);
+        }
+        if (lane == 0) L.slb[y] = lb;
     }
     if (row >= N) return;
     double s = 0;

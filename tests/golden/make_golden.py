@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a', 'r4b': sections AD, AE (round 4)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a' .. 'r4c': sections AD, AE, AF (round 4)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -194,6 +194,9 @@ def main():
         return
     if args.only == 'r4b':
         one_thread(round4b, np, pmf_cy, bayes_pmf, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r4c':
+        one_thread(round4c, np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r3b':
         one_thread(round3b, np, mn_active_pmf, save, seed, _print)
@@ -1407,6 +1410,46 @@ def round4b(np, pmf_cy, bayes_pmf, mn_active_pmf, save, seed, _print):
          p_mean_rows=pm[rows_u].copy(), p_var_rows=pv[rows_u].copy(), p_var_sum=pv.sum(), p_mean_sum=pm.sum(),
          pick0=np.array(a.pick_query_point(key=mn_active_pmf.MNActivePMF.pred_variance)))
     _print('ml100k MN: %.0f s' % (time.perf_counter() - t0))
+
+
+def round4c(np, mn_active_pmf, save, seed, _print):
+    """AF. BASELINE.json configs[3] as the reference's Makefile RUNS it (results/drugbank-94x425/Makefile:62-73:
+    mn_active_pmf.py --latent-d 20 --discrete-integration --refit-lookahead ... -- random pred-variance pred
+    prob-ge-3.5): the selection loop compare() end to end on the DrugBank subset with the 518 known entries of
+    section G, rank 20, under a seed - initial fit_lls + fit_normal to convergence, then per key and step: evaluate the
+    criterion over the 39 432 unrated entries, pick, add_rating, re-fit, variational re-fit.  Two query steps per key.
+    Recorded per key: the picks, the RMSEs, the number of known entries; for the first step the criterion values of
+    sampled candidates; the initial model's factors and approximation (diagonal / samples of the 519 x 519 covariance)."""
+    t0 = time.perf_counter()
+    g = np.load(os.path.join(HERE, 'mn_c4_94x425_d5.npz'))
+    real, ratings = g['real'].astype(float), g['ratings']
+    keys = ['random', 'pred-variance', 'pred', 'prob-ge-3.5']
+    seed(95)
+    res = mn_active_pmf.compare(keys, real, ratings.copy(), rating_vals=(0, 1), latent_d=20, do_threading=False,
+                                steps=3, discrete_exp=True, refit_lookahead=True)
+    init = res['_initial_apmf']
+    rs = np.random.RandomState(96)
+    N = init.cov_useritems.shape[0]
+    si, sj = rs.randint(0, N, 3000), rs.randint(0, N, 3000)
+    out = dict(seed=95, keys=np.array(keys), latent_d=20, init_users=init.users, init_items=init.items,
+               init_mean=init.mean, init_cov_latents=init.cov_latents, samp_i=si, samp_j=sj,
+               init_cov_diag=np.diag(init.cov_useritems).copy(), init_cov_samp=init.cov_useritems[si, sj].copy(),
+               init_kl=init.kl_divergence())
+    ci, cj = rs.randint(0, real.shape[0], 2000), rs.randint(0, real.shape[1], 2000)
+    out.update(cand_i=ci, cand_j=cj)
+    for key in keys:
+        steps = res[key]
+        out[key + '_n_rated'] = np.array([s[0] for s in steps])
+        out[key + '_rmse'] = np.array([s[1] for s in steps], dtype=np.float64)
+        out[key + '_picks'] = np.array([s[2] for s in steps[1:]])
+        for k, s in enumerate(steps[1:]):
+            vals = np.asarray(s[3], dtype=np.float64)
+            # (an (n, m) grid with NaN at the rated entries - get_key_evals - for the criteria; sampled)
+            out['%s_vals_%d' % (key, k)] = vals[ci, cj] if vals.ndim == 2 else vals.reshape(-1)[:2000]
+            out['%s_vals_ndim_%d' % (key, k)] = vals.ndim
+            out['%s_nanmax_%d' % (key, k)] = np.nanmax(vals)
+    save('trace_c4_mn_d20', **out)
+    _print('configs[3] compare() trace: %.0f s' % (time.perf_counter() - t0))
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

@@ -280,6 +280,45 @@ def test_config1_selection_trace(pkg):
     assert set(res) == {'_real', '_ratings', '_rating_vals', '_initial_apmf', 'random', 'pred-variance'}
 
 
+def test_configs3_makefile_selection_trace(pkg):
+    """BASELINE.json configs[3] as the reference's Makefile runs it (results/drugbank-94x425/Makefile:62-73: rank 20,
+    --discrete-integration --refit-lookahead, keys random / pred-variance / pred / prob-ge-3.5): mn_active_pmf.compare()
+    end to end on the DrugBank subset under seed 95 (make_golden.py section AF) - the initial fit_lls + fit_normal to
+    convergence, then per key two query steps: criterion over the 39 432 unrated entries, pick, add_rating, re-fit,
+    variational re-fit.  The reference's picks EXACTLY for every key and step, its RMSEs, its criterion values at 2000
+    sampled candidates, and the initial model it started every key from."""
+    g = load_golden('trace_c4_mn_d20')
+    base = load_golden('mn_c4_94x425_d5')
+    real, ratings = base['real'].astype(float), base['ratings']
+    keys = [str(k) for k in g['keys']]
+    seed(int(g['seed']))
+    res = pkg.mn.compare(keys, real, ratings.copy(), rating_vals=(0, 1), latent_d=int(g['latent_d']), do_threading=False,
+                         steps=3, discrete_exp=True, refit_lookahead=True)
+    init = res['_initial_apmf']
+    np.testing.assert_allclose(init.users, g['init_users'], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(init.items, g['init_items'], rtol=1e-8, atol=1e-10)
+    # (the initial variational fit runs several hundred accepted steps of a search that amplifies rounding: its end
+    # point agrees with the reference's as far as the stopping rule lets it - DESIGN.md section 2)
+    np.testing.assert_allclose(init.mean, g['init_mean'], rtol=1e-3, atol=1e-4)
+    cov = np.asarray(init.cov_useritems)
+    scale = np.abs(g['init_cov_diag']).max()
+    np.testing.assert_allclose(np.diag(cov), g['init_cov_diag'], rtol=0, atol=1e-2 * scale)
+    np.testing.assert_allclose(cov[g['samp_i'], g['samp_j']], g['init_cov_samp'], rtol=0, atol=1e-2 * scale)
+    ci, cj = g['cand_i'], g['cand_j']
+    for key in keys:
+        steps = res[key]
+        assert [s[0] for s in steps] == list(g[key + '_n_rated'])
+        picks = np.array([s[2] for s in steps[1:]])
+        np.testing.assert_array_equal(picks, g[key + '_picks'])       # selected indices: exact
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-3)
+        for k, s in enumerate(steps[1:]):
+            vals = np.asarray(s[3], dtype=np.float64)[ci, cj]
+            ref = g['%s_vals_%d' % (key, k)]
+            assert np.array_equal(np.isnan(vals), np.isnan(ref))
+            ok = ~np.isnan(ref)
+            np.testing.assert_allclose(vals[ok], ref[ok], rtol=1e-2, atol=1e-6)
+
+
 def test_config1_lookahead_selection_step(pkg):
     """One selection step of the matrix-normal loop under the LOOKAHEAD criteria 'total-variance', 'uv-entropy'
     and '1step-ge-3.5' (mn_active_pmf.py:660-755 under compare(): 90 unrated entries x 5 rating values, each a
