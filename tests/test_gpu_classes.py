@@ -287,6 +287,10 @@ def test_configs3_makefile_selection_trace(pkg):
     convergence, then per key two query steps: criterion over the 39 432 unrated entries, pick, add_rating, re-fit,
     variational re-fit.  The reference's picks EXACTLY for every key and step, its RMSEs, its criterion values at 2000
     sampled candidates, and the initial model it started every key from."""
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, 'trace_c4_mn_d20.npz')):
+        pytest.skip('fixture trace_c4_mn_d20 not generated (make_golden.py --only r4c, 20 min of reference time)')
     g = load_golden('trace_c4_mn_d20')
     base = load_golden('mn_c4_94x425_d5')
     real, ratings = base['real'].astype(float), base['ratings']
