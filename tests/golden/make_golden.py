@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a' .. 'r4c': sections AD, AE, AF (round 4)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a' .. 'r4d': sections AD, AE, AF, AF2 (round 4)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -197,6 +197,9 @@ def main():
         return
     if args.only == 'r4c':
         one_thread(round4c, np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r4d':
+        one_thread(round4d, np, mn_active_pmf, save, seed, _print)
         return
     if args.only == 'r3b':
         one_thread(round3b, np, mn_active_pmf, save, seed, _print)
@@ -1437,6 +1440,11 @@ def round4c(np, mn_active_pmf, save, seed, _print):
                init_kl=init.kl_divergence())
     ci, cj = rs.randint(0, real.shape[0], 2000), rs.randint(0, real.shape[1], 2000)
     out.update(cand_i=ci, cand_j=cj)
+    # the whole initial approximation (2.1 MB): every key's FIRST pick is a function of it alone, so the test can
+    # separate "the criterion and the pick from a given state" (exact) from "where the chaotic fit ended" (1e-3)
+    out.update(init_cov_useritems=init.cov_useritems.copy())
+    pool0 = list(init.unrated)
+    out.update(pool0_head=np.array(pool0[:2000]))
     for key in keys:
         steps = res[key]
         out[key + '_n_rated'] = np.array([s[0] for s in steps])
@@ -1447,9 +1455,45 @@ def round4c(np, mn_active_pmf, save, seed, _print):
             # (an (n, m) grid with NaN at the rated entries - get_key_evals - for the criteria; sampled)
             out['%s_vals_%d' % (key, k)] = vals[ci, cj] if vals.ndim == 2 else vals.reshape(-1)[:2000]
             out['%s_vals_ndim_%d' % (key, k)] = vals.ndim
+            if k == 0 and vals.ndim == 1 and vals.size == len(pool0):
+                # the thirty best of the first step, in the criterion's order (max; all four keys maximise)
+                top = np.argsort(-vals, kind='stable')[:30]
+                out[key + '_top_vals'] = vals[top]
+                out[key + '_top_ij'] = np.array([pool0[t] for t in top])
             out['%s_nanmax_%d' % (key, k)] = np.nanmax(vals)
     save('trace_c4_mn_d20', **out)
     _print('configs[3] compare() trace: %.0f s' % (time.perf_counter() - t0))
+
+
+def round4d(np, mn_active_pmf, save, seed, _print):
+    """AF2. The criteria of section AF evaluated by the reference ON A GIVEN STATE - the initial model of that run, which
+    its fixture holds whole (rank 20, 519 x 519 covariance): pred-variance, pred and prob-ge-3.5 over all 39 432 unrated
+    entries (mn_active_pmf.py:404-511 through get_key_evals, :764-779) and the pick of each (:701-729).  compare() itself
+    re-fits every key's copy before its first pick, so the picks of section AF are NOT functions of this state; these are."""
+    t0 = time.perf_counter()
+    g = np.load(os.path.join(HERE, 'trace_c4_mn_d20.npz'))
+    base = np.load(os.path.join(HERE, 'mn_c4_94x425_d5.npz'))
+    MN = mn_active_pmf.MNActivePMF
+    a = MN(base['ratings'].copy(), latent_d=int(g['latent_d']), rating_values=(0, 1), discrete_expectations=True,
+           refit_lookahead=True)
+    a.users, a.items = g['init_users'].copy(), g['init_items'].copy()
+    a.mean, a.cov_useritems, a.cov_latents = g['init_mean'].copy(), g['init_cov_useritems'].copy(), g['init_cov_latents'].copy()
+    out = dict(kl=a.kl_divergence())
+    rs = np.random.RandomState(97)
+    ci, cj = rs.randint(0, a.num_users, 3000), rs.randint(0, a.num_items, 3000)
+    out.update(cand_i=ci, cand_j=cj)
+    for key in ('pred-variance', 'pred', 'prob-ge-3.5'):
+        kf = mn_active_pmf.KEY_FUNCS[key]
+        ev = a.get_key_evals(key=kf, procs=1)
+        flat = np.where(np.isnan(ev), -np.inf, ev).reshape(-1)
+        top = np.argsort(-flat, kind='stable')[:50]
+        out[key + '_top_ij'] = np.column_stack(np.unravel_index(top, ev.shape))
+        out[key + '_top_vals'] = flat[top]
+        out[key + '_samp'] = ev[ci, cj]
+        out[key + '_nansum'] = np.nansum(ev)
+        out[key + '_pick'] = np.array(a.pick_query_point(key=kf, procs=1))
+        _print('  %s: pick %s, %.0f s' % (key, out[key + '_pick'], time.perf_counter() - t0))
+    save('c4_d20_init_criteria', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):
