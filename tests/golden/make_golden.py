@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a' .. 'r4d': sections AD, AE, AF, AF2 (round 4)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a' .. 'r4e': sections AD, AE, AF, AF2, AG (round 4)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -200,6 +200,9 @@ def main():
         return
     if args.only == 'r4d':
         one_thread(round4d, np, mn_active_pmf, save, seed, _print)
+        return
+    if args.only == 'r4e':
+        one_thread(round4e, np, bayes_pmf, save, seed, _print)
         return
     if args.only == 'r3b':
         one_thread(round3b, np, mn_active_pmf, save, seed, _print)
@@ -1494,6 +1497,50 @@ def round4d(np, mn_active_pmf, save, seed, _print):
         out[key + '_pick'] = np.array(a.pick_query_point(key=kf, procs=1))
         _print('  %s: pick %s, %.0f s' % (key, out[key + '_pick'], time.perf_counter() - t0))
     save('c4_d20_init_criteria', **out)
+
+
+def round4e(np, bayes_pmf, save, seed, _print):
+    """AG. The Bayesian selection loop end to end at BASELINE.json configs[2]'s size on the REAL MovieLens-100k matrix
+    (bayes_pmf.py:682-826: compare_active -> full_test): rank 15, subtract_mean, a seeded half of the 100 000 ratings known,
+    the other half the candidates (compare_active's `pickable`), keys random / pred-variance / prob-ge-3.5, 12 chain samples,
+    two query steps each, sequential (procs=0) under seed 98.  Picks, RMSEs, sampled criterion values."""
+    t0 = time.perf_counter()
+    real = np.load(os.path.join(HERE, 'ml100k_real.npz'))['real'].astype(float)
+    ii, jj = real.nonzero()
+    # known entries: the first rating of every user and of every item (the reference's chain raises KeyError on a
+    # row or column without one, bayes_pmf.py:287,296), then a seeded fill up to 50 000; the order of the list is the
+    # row-major order of the matrix
+    rs = np.random.RandomState(99)
+    first_u = np.unique(ii, return_index=True)[1]
+    order_j = np.argsort(jj, kind='stable')
+    first_v = order_j[np.unique(jj[order_j], return_index=True)[1]]
+    mask = np.zeros(ii.size, bool)
+    mask[first_u] = True
+    mask[first_v] = True
+    rest = np.flatnonzero(~mask)
+    mask[rs.permutation(rest)[:50000 - int(mask.sum())]] = True
+    known = np.flatnonzero(mask)
+    ratings = np.column_stack([ii[known], jj[known], real[ii[known], jj[known]]]).astype(float)
+    keys = ['random', 'pred-variance', 'prob-ge-3.5']
+    seed(98)
+    res = bayes_pmf.compare_active(keys, 15, real, ratings.copy(), rating_vals=(1, 2, 3, 4, 5), num_steps=3,
+                                   procs=0, num_samps=12, subtract_mean=True)
+    out = dict(seed=98, seed_known=99, n_known=50000, keys=np.array(keys), latent_d=15, num_samps=12)
+    for key in keys:
+        steps = res[key]
+        out[key + '_n_rated'] = np.array([s[0] for s in steps])
+        out[key + '_rmse'] = np.array([s[1] for s in steps], dtype=np.float64)
+        out[key + '_picks'] = np.array([s[2] for s in steps[1:]])
+        for k, s in enumerate(steps[1:]):
+            vals = np.asarray(s[3], dtype=np.float64)
+            out['%s_vals_shape_%d' % (key, k)] = np.array(vals.shape)
+            flat = np.where(np.isnan(vals), -np.inf, vals).reshape(-1)
+            top = np.argsort(-flat, kind='stable')[:20]
+            out['%s_top_idx_%d' % (key, k)] = top
+            out['%s_top_vals_%d' % (key, k)] = flat[top]
+            out['%s_head_%d' % (key, k)] = vals.reshape(-1)[:3000]
+        _print('bayes ml100k %s: picks %s, %.0f s' % (key, out[key + '_picks'].tolist(), time.perf_counter() - t0))
+    save('trace_ml100k_bayes_d15', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

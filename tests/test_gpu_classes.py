@@ -394,6 +394,53 @@ def test_config1_bayes_selection_trace(pkg):
             np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-11, atol=1e-10)
 
 
+def test_movielens_100k_bayes_selection_trace(pkg):
+    """The Bayesian selection loop end to end at BASELINE.json configs[2]'s size on the REAL MovieLens-100k matrix
+    (make_golden.py section AG; bayes_pmf.py:682-826): rank 15, subtract_mean, a seeded half of the ratings known, the other
+    half the candidates, keys random / pred-variance / prob-ge-3.5, 12 chain samples, two query steps each under seed 98.
+    The REAL reference's picks (exact), its RMSEs, its twenty best criterion values per step and the head of each
+    evaluation."""
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, 'trace_ml100k_bayes_d15.npz')):
+        pytest.skip('fixture trace_ml100k_bayes_d15 not generated (make_golden.py --only r4e)')
+    g = load_golden('trace_ml100k_bayes_d15')
+    real = load_golden('ml100k_real')['real'].astype(float)
+    ii, jj = real.nonzero()
+    # the known half exactly as the generator chose it: first rating of every user and item, then a seeded fill
+    rs = np.random.RandomState(int(g['seed_known']))
+    first_u = np.unique(ii, return_index=True)[1]
+    order_j = np.argsort(jj, kind='stable')
+    first_v = order_j[np.unique(jj[order_j], return_index=True)[1]]
+    mask = np.zeros(ii.size, bool)
+    mask[first_u] = True
+    mask[first_v] = True
+    rest = np.flatnonzero(~mask)
+    mask[rs.permutation(rest)[:int(g['n_known']) - int(mask.sum())]] = True
+    known = np.flatnonzero(mask)
+    ratings = np.column_stack([ii[known], jj[known], real[ii[known], jj[known]]]).astype(float)
+    keys = [str(k) for k in g['keys']]
+    seed(int(g['seed']))
+    res = pkg.bayes.compare_active(keys, int(g['latent_d']), real, ratings.copy(), rating_vals=(1, 2, 3, 4, 5),
+                                   num_steps=3, procs=0, num_samps=int(g['num_samps']), subtract_mean=True)
+    for key in keys:
+        steps = res[key]
+        assert [s[0] for s in steps] == list(g[key + '_n_rated'])
+        picks = np.array([s[2] for s in steps[1:]])
+        np.testing.assert_array_equal(picks, g[key + '_picks'])       # selected indices: exact
+        np.testing.assert_allclose([s[1] for s in steps], g[key + '_rmse'], rtol=1e-9)
+        for k, s in enumerate(steps[1:]):
+            vals = np.asarray(s[3], dtype=np.float64)
+            assert tuple(vals.shape) == tuple(g['%s_vals_shape_%d' % (key, k)])
+            flat = np.where(np.isnan(vals), -np.inf, vals).reshape(-1)
+            np.testing.assert_allclose(flat[g['%s_top_idx_%d' % (key, k)]], g['%s_top_vals_%d' % (key, k)],
+                                       rtol=1e-8, atol=1e-10)
+            ref = g['%s_head_%d' % (key, k)]
+            got = vals.reshape(-1)[:ref.size]
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            np.testing.assert_allclose(got[~np.isnan(ref)], ref[~np.isnan(ref)], rtol=1e-8, atol=1e-10)
+
+
 def test_config1_bayes_lookahead_selection_step(pkg):
     """One selection step of the Bayesian loop under its LOOKAHEAD criterion 'exp-variance' (bayes_pmf.py:457-468,
     560-605 under compare_active -> full_test): 90 unrated entries x 5 rating values, each a copy + add_rating +
