@@ -77,7 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scratch', default='/tmp/apmf_ref_build')
     ap.add_argument('--keep', action='store_true')
-    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a' .. 'r4e': sections AD, AE, AF, AF2, AG (round 4)")
+    ap.add_argument('--only', default='', help="'r2': only the fixtures added in round 2 (sections G-I); 'r2b' .. 'r2n': only section J .. U; 'r3a' .. 'r3i': sections V, W, X, Y, Z, AA, AB, AC, W2 (round 3); 'r4a' .. 'r4f': sections AD, AE, AF, AF2, AG, AH (round 4)")
     args = ap.parse_args()
 
     build_reference(args.scratch)
@@ -203,6 +203,9 @@ def main():
         return
     if args.only == 'r4e':
         one_thread(round4e, np, bayes_pmf, save, seed, _print)
+        return
+    if args.only == 'r4f':
+        one_thread(round4f, np, pmf_cy, save, seed, _print)
         return
     if args.only == 'r3b':
         one_thread(round3b, np, mn_active_pmf, save, seed, _print)
@@ -1541,6 +1544,38 @@ def round4e(np, bayes_pmf, save, seed, _print):
             out['%s_head_%d' % (key, k)] = vals.reshape(-1)[:3000]
         _print('bayes ml100k %s: picks %s, %.0f s' % (key, out[key + '_picks'].tolist(), time.perf_counter() - t0))
     save('trace_ml100k_bayes_d15', **out)
+
+
+def round4f(np, pmf_cy, save, seed, _print):
+    """AH. BASELINE.json configs[1] - "PMF SGD fit" - on the REAL MovieLens-100k matrix: the minibatch momentum fit
+    (pmf_cy.pyx:308-381), rank 10, subtract_mean, ratings = the matrix' non-zeros in row-major order: two epochs of
+    fit_minibatches(1000) and three (train, validation) pairs of fit_minibatches_validation(1000, 5000) under fixed
+    seeds - what section Z records on the synthetic matrix of that shape."""
+    from itertools import islice
+    t0 = time.perf_counter()
+    real = np.load(os.path.join(HERE, 'ml100k_real.npz'))['real']
+    ii, jj = real.nonzero()
+    ratings = np.column_stack([ii, jj, real[ii, jj]]).astype(float)
+    seed(100)
+    p = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10, subtract_mean=True)
+    U0, V0 = p.users.copy(), p.items.copy()
+    seed(101)
+    errs = list(islice(p.fit_minibatches(1000), 2))
+    ru, rv = np.array([0, 1, 470, 942]), np.array([0, 1, 840, 1681])
+    out = dict(seed_ctor=100, seed_fit=101, batch_size=1000, U0_sum=U0.sum(), V0_sum=V0.sum(),
+               train_errs=np.array(errs, np.float64), rows_u=ru, rows_v=rv, U_rows=p.users[ru], V_rows=p.items[rv],
+               U_sum=p.users.sum(), V_sum=p.items.sum(), U_abs_sum=np.abs(p.users).sum(), V_abs_sum=np.abs(p.items).sum(),
+               ratings_after_head=p.ratings[:64].copy(),
+               ratings_after_weighted=(p.ratings * np.arange(1, ratings.shape[0] + 1)[:, None]).sum(0))
+    seed(102)
+    q = pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10, subtract_mean=True)
+    q.users, q.items = U0.copy(), V0.copy()
+    seed(103)
+    pairs = list(islice(q.fit_minibatches_validation(1000, 5000), 3))
+    out.update(seed_ctor2=102, seed_pairs=103, valid_size=5000, valid_pairs=np.array(pairs, np.float64),
+               Uv_rows=q.users[ru], Vv_rows=q.items[rv])
+    _print('ml100k minibatch: train errs %r, pairs %r, %.0f s' % (errs, pairs, time.perf_counter() - t0))
+    save('ml100k_minibatch_d10', **out)
 
 
 def round2b(np, mn_active_pmf, save, seed, _print):

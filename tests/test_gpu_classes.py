@@ -1838,6 +1838,39 @@ def test_minibatch_headline_shape_golden(pkg):
     np.testing.assert_allclose(q.items[rv], g['Vv_rows'], rtol=1e-11, atol=1e-13)
 
 
+def test_movielens_100k_minibatch_golden(pkg):
+    """BASELINE.json configs[1] - "PMF SGD fit" - on the REAL MovieLens-100k matrix (make_golden.py section AH): two
+    epochs of fit_minibatches(1000) with subtract_mean (100 momentum steps each on apmf_pmf_minibatch_epoch, the shuffle on
+    the host in the reference's order) and three (train, validation) pairs of fit_minibatches_validation(1000, 5000),
+    under the reference's seeds: its training / validation errors, the same shuffles, the fitted factors."""
+    g = load_golden('ml100k_minibatch_d10')
+    _, ratings = _ml100k_ratings()
+    bs = int(g['batch_size'])
+    seed(int(g['seed_ctor']))
+    p = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10, subtract_mean=True)
+    U0, V0 = p.users.copy(), p.items.copy()
+    np.testing.assert_allclose([U0.sum(), V0.sum()], [g['U0_sum'], g['V0_sum']], rtol=1e-13)
+    seed(int(g['seed_fit']))
+    errs = list(islice(p.fit_minibatches(bs), 2))
+    np.testing.assert_allclose(errs, g['train_errs'], rtol=1e-12)              # (a C float in the reference: the same bits here)
+    np.testing.assert_array_equal(p.ratings[:64], g['ratings_after_head'])     # the same shuffles
+    np.testing.assert_allclose((p.ratings * np.arange(1, ratings.shape[0] + 1)[:, None]).sum(0), g['ratings_after_weighted'],
+                               rtol=1e-13)
+    ru, rv = g['rows_u'], g['rows_v']
+    np.testing.assert_allclose(p.users[ru], g['U_rows'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(p.items[rv], g['V_rows'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose([p.users.sum(), p.items.sum(), np.abs(p.users).sum(), np.abs(p.items).sum()],
+                               [g['U_sum'], g['V_sum'], g['U_abs_sum'], g['V_abs_sum']], rtol=1e-12)
+    seed(int(g['seed_ctor2']))
+    q = pkg.pmf_cy.ProbabilisticMatrixFactorization(ratings.copy(), latent_d=10, subtract_mean=True)
+    q.users, q.items = U0.copy(), V0.copy()
+    seed(int(g['seed_pairs']))
+    pairs = list(islice(q.fit_minibatches_validation(bs, int(g['valid_size'])), 3))
+    np.testing.assert_allclose(pairs, g['valid_pairs'], rtol=1e-12)
+    np.testing.assert_allclose(q.users[ru], g['Uv_rows'], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(q.items[rv], g['Vv_rows'], rtol=1e-11, atol=1e-13)
+
+
 def test_configs2_gibbs_golden(pkg):
     """BASELINE.json configs[2]: rank-15 BayesianPMF at 943 x 1682 on the headline synthetic ratings
     (regenerated from seed 0; only sampled outputs are stored): the first three samples() yields
