@@ -39,6 +39,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL's peer buffers): exported by the driver's shell already,
+# set here too in case a launcher scrubbed the environment - before the HSA runtime comes up
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 N_USERS, N_ITEMS, LATENT_D, N_RATINGS = 943, 1682, 10, 100000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
