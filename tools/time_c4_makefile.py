@@ -2,9 +2,15 @@
 """configs[3] as the reference's Makefile runs it (results/drugbank-94x425/Makefile:62-73: rank 20, keys random / pred-variance /
 pred / prob-ge-3.5), two query steps per key through mn_active_pmf.compare() under the seed of fixture section AF: wall time
 and the picks (the reference needs 19 minutes for the same run).  python tools/time_c4_makefile.py"""
-import sys, time, random, io, contextlib
-import numpy as np
+import contextlib
+import io
 import os
+import random
+import sys
+import time
+
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from active_matrix_factorization_amd import mn_active_pmf as mn
